@@ -1,0 +1,171 @@
+/* include/zpaq_amd.h -- the drop-in boundary: a thin C ABI over the MI355X engine.
+ *
+ * Plain C types, caller-owned buffers, integer status codes, no exceptions and
+ * no torch types across this line.  Everything above it (the libzpaq-compatible
+ * C++ classes in include/libzpaq.h, the Python mirror in zpaq_amd/) is host
+ * plumbing; everything below it is HIP for gfx950.
+ *
+ * Each entry point names the reference interface it replaces (file:line into
+ * zpaq 7.15's libzpaq.h / libzpaq.cpp).  The library is thread-safe: concurrent
+ * callers are serialised on the device queue, mirroring how zpaq.cpp:1947 calls
+ * compressBlock() from many threads.
+ *
+ * There is NO CPU fallback for the modelled path: if no gfx950 device/kernels
+ * are available these functions return ZPQ_E_DEVICE, they never silently code
+ * on the host.
+ */
+#ifndef ZPAQ_AMD_H
+#define ZPAQ_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (per call and per block) ---- */
+enum {
+  ZPQ_OK = 0,
+  ZPQ_E_NOMEM = 1,     /* "Out of memory" (libzpaq.h:925)                         */
+  ZPQ_E_CORRUPT = 2,   /* "archive corrupted" (libzpaq.cpp:2108)                 */
+  ZPQ_E_OVERFLOW = 3,  /* caller's output buffer too small                        */
+  ZPQ_E_HEADER = 4,    /* bad COMP/HCOMP header (libzpaq.cpp:887-931, 1776-1846) */
+  ZPQ_E_VM = 5,        /* "ZPAQL execution error" (libzpaq.cpp:1265)             */
+  ZPQ_E_EOF = 6,       /* "unexpected end of file" (libzpaq.cpp:2120)            */
+  ZPQ_E_DEVICE = 7,    /* no usable gfx950 device / HIP runtime error            */
+  ZPQ_E_UNSUPPORTED = 8, /* valid ZPAQ feature outside this build's hot-path scope */
+  ZPQ_E_ARG = 9
+};
+
+/* Thread-local text for the last failing call on this thread. */
+const char* zpq_last_error(void);
+const char* zpq_version(void);
+
+/* ---- device ---- */
+/* Bind the engine to one HIP device (one process per GPU; LOCAL_RANK picks it).
+ * Idempotent.  Uploads the predictor's constant tables (squash/stretch/dt/
+ * dt2k/state table; Predictor::init libzpaq.cpp:1731-1761) after verifying the
+ * reference's two table checksums (1759-1760) on the host. */
+int zpq_init(int device);
+int zpq_device_count(void);
+void zpq_shutdown(void);
+/* Cap on device bytes the engine may hold for model state (default: 85% of
+ * free HBM at init).  Batches needing more are run in several residency waves. */
+int zpq_set_state_budget(uint64_t bytes);
+/* Select the coding kernel: 0 = auto (wave-parallel when the plan allows it),
+ * 1 = force the one-lane generic kernel, 2 = force wave-parallel. */
+int zpq_set_kernel(int which);
+
+/* ---- model plan: a parsed block header + device arena layout ---- */
+typedef struct zpq_plan zpq_plan;
+/* header = hsize_lo hsize_hi hh hm ph pm n COMP.. 0 HCOMP.. 0 exactly as stored
+ * in the archive.  Replaces ZPAQL::read (libzpaq.cpp:887) + the sizing half of
+ * Predictor::init (1776-1846). */
+int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out);
+void zpq_plan_destroy(zpq_plan*);
+int zpq_plan_ncomp(const zpq_plan*);
+/* ZPAQL::memory() (libzpaq.cpp:986-1006): what findBlock(&mem) reports. */
+double zpq_plan_memory(const zpq_plan*);
+/* Device bytes one in-flight block of this plan occupies. */
+uint64_t zpq_plan_state_bytes(const zpq_plan*);
+/* ALGORITHMIC model-state bytes moved per coded input byte,
+ * excluding init and I/O: the roofline numerator. */
+double zpq_plan_algo_bytes_per_byte(const zpq_plan*);
+
+/* ---- the hot path: batches of independent blocks ---- */
+/* Encoder::compress over in[b][0..in_len[b]) then EOS, for every block
+ * (libzpaq.cpp:2419-2447 driving Predictor::predict/update 1854-2066 and
+ * ZPAQL::run 1027).  `in[b]` is what the Compressor feeds the Encoder: PP header
+ * byte(s) then data.  out[b] receives the coded bytes including the 4 EOS
+ * flush bytes (not the 00 00 00 00 terminator).  status[b] is per block.
+ * Host pointers; the call copies in, runs, copies out. */
+int zpq_encode_batch(const zpq_plan* const* plans, const uint8_t* const* in,
+                     const uint32_t* in_len, uint32_t nblocks,
+                     uint8_t* const* out, const uint32_t* out_cap,
+                     uint32_t* out_len, int32_t* status);
+
+/* Decoder::decompress until EOS for every block (libzpaq.cpp:2127-2155).
+ * in[b] = coded bytes starting at the first coded byte and including at least
+ * the 4-zero terminator.  out[b] gets the decoded bytes (PP header included);
+ * consumed[b] = coded bytes read (terminator included).  max_out[b] bounds the
+ * decode ("decode first k bytes", Decompresser::decompress(n) 2315): decoding
+ * stops early with status ZPQ_OK and consumed = 0 when max_out is reached
+ * before EOS. */
+int zpq_decode_batch(const zpq_plan* const* plans, const uint8_t* const* in,
+                     const uint32_t* in_len, uint32_t nblocks,
+                     uint8_t* const* out, const uint32_t* max_out,
+                     uint32_t* out_len, uint32_t* consumed, int32_t* status);
+
+/* Device-resident variants (inputs already in HBM; used by bench.py and by
+ * callers that keep data on the GPU).  d_in/d_out are DEVICE pointers; block b
+ * reads d_in + in_off[b] and writes d_out + out_off[b] (in_off/in_len/out_off/
+ * out_cap are HOST arrays).  Per-block results land in the DEVICE array d_res.
+ * `stream` is a hipStream_t (NULL = the engine's own stream).  One plan for the
+ * whole batch, which must fit the state budget.  The call enqueues
+ * init_arena + the coding kernel on `stream`; with timed!=0 it also brackets
+ * them with hipEvents on that stream, waits, and makes the durations available
+ * through zpq_last_timing(). */
+typedef struct zpq_block_result {
+  uint32_t out_len;    /* bytes produced                                   */
+  uint32_t consumed;   /* decode: coded bytes read incl. terminator, 0 if stopped at max_out */
+  int32_t status;      /* ZPQ_* per block                                  */
+  uint32_t steps;      /* predict/update steps executed (coded bits)       */
+} zpq_block_result;
+
+int zpq_encode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
+                      const uint32_t* in_len, uint32_t nblocks, void* d_out,
+                      const uint64_t* out_off, const uint32_t* out_cap,
+                      zpq_block_result* d_res, void* stream, int timed);
+int zpq_decode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
+                      const uint32_t* in_len, uint32_t nblocks, void* d_out,
+                      const uint64_t* out_off, const uint32_t* max_out,
+                      zpq_block_result* d_res, void* stream, int timed);
+/* Durations (ms, hipEvent) of the last timed call on this process: Predictor
+ * init kernel and coding kernel(s); blocks = blocks they covered. */
+int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
+/* Runs a tiny kernel exercising the cross-lane idioms (DPP reduction, readlane,
+ * bpermute); out8[0..4] must equal {2016, 83640, 123, 2016, 133}. */
+int zpq_selftest(int32_t out8[8]);
+
+/* ---- block-level drop-ins (host side + hot path) ---- */
+/* Batched libzpaq::compressBlock (libzpaq.h:1505, libzpaq.cpp:7543): each
+ * in[b] becomes one ZPAQ block with one segment, bit-identical to the
+ * reference's output for the same (method, filename, comment, dosha1).
+ * in[b] may be modified in place exactly where the reference would (E8E9).
+ * out_len[b] always receives the needed size; ZPQ_E_OVERFLOW if cap too small. */
+int zpq_compress_blocks(const char* method, uint8_t* const* in, const uint32_t* in_len,
+                        uint32_t nblocks, const char* const* filename,
+                        const char* const* comment, int dosha1,
+                        uint8_t* const* out, const uint64_t* out_cap, uint64_t* out_len);
+
+/* libzpaq::decompress (libzpaq.h:1268, libzpaq.cpp:2378) over a whole archive
+ * (any number of blocks/segments): all blocks are located on the host, decoded
+ * on the device as one batch, and concatenated in order.  Verifies segment
+ * SHA-1 trailers when present (status ZPQ_E_CORRUPT on mismatch). */
+int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t cap,
+                   uint64_t* out_len);
+
+/* ---- host-side pieces of the boundary, exposed for reuse and for tests ---- */
+/* SHA1 (libzpaq.h:934-954). */
+void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]);
+/* compressBlock's level->method expansion (libzpaq.cpp:7579-7691), including
+ * level-5 period detection on the data.  Writes a NUL-terminated "x..." /
+ * "0..." string. */
+int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char* out, size_t cap);
+/* makeConfig + Compiler (libzpaq.cpp:6887, 2698): "x..." method -> block header
+ * bytes as stored (hcomp) and the PCOMP bytes the Compressor codes through the
+ * model (len16 + code, empty if none); args9 receives $1..$9. */
+int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t hcap,
+                         size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);
+/* Compiler alone (libzpaq.cpp:2698): ZPAQL source text -> header / PCOMP bytes. */
+int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hcap,
+                 size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);
+/* Host copies of the predictor's constant tables (for tests): which = 0 squash
+ * u16[4096], 1 stretch i16[32768], 2 dt i32[1024], 3 dt2k i32[256], 4 state
+ * table u8[1024].  Returns bytes written. */
+size_t zpq_table(int which, void* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,174 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle, the
+golden vectors made by the reference, and (when oracle/_ref travelled here) the
+reference itself.  Bit-exact everywhere: this is integer/byte work."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import b64, gen_input
+from oracle.oracle_py import have_ref, parse_block
+from zpaq_amd import corpus
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [2, 1]   # wave-parallel, generic one-lane
+
+
+def test_cross_lane_selftest(gpu):
+    assert gpu.selftest()[:5] == [2016, 83640, 123, 2016, 133]
+
+
+def test_native_library_is_the_one_running(gpu):
+    maps = open("/proc/self/maps").read()
+    assert "libzpaq_amd.so" in maps and gpu.device_count() >= 1
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_encode_matches_oracle_and_golden(gpu, oracle, golden, kernel):
+    """zpq_encode_batch over every small golden case: coded stream == oracle == reference archive slice."""
+    gpu.set_kernel(kernel)
+    try:
+        entries = [e for e in golden["method_cases"] if e["n"] <= 65536 and bytes.fromhex(e["header"])[6]]
+        if kernel == 1:
+            entries = [e for e in entries if e["n"] <= 20000]
+        plans, inputs = [], []
+        cache = {}
+        for e in entries:
+            hdr = bytes.fromhex(e["header"])
+            if hdr not in cache:
+                cache[hdr] = gpu.Plan(hdr)
+            plans.append(cache[hdr])
+            inputs.append(b"\0" + gen_input(e).tobytes())
+        coded = gpu.encode_batch(plans, inputs)
+        for e, inp, c in zip(entries, inputs, coded):
+            hdr = bytes.fromhex(e["header"])
+            assert c == oracle.encode(hdr, inp), (e["kind"], e["n"], e["method"])
+            if "archive_b64" in e:
+                a = b64(e)
+                ps = e["payload_start"]
+                assert a[ps:ps + len(c) + 4] == c + b"\0\0\0\0"
+    finally:
+        gpu.set_kernel(0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_compress_blocks_bit_identical_archives(gpu, golden, kernel):
+    """Batched compressBlock: whole archives (tag .. 255) hash-identical to the reference's."""
+    gpu.set_kernel(kernel)
+    try:
+        lim = 262144 if kernel == 2 else 20000
+        by_method = {}
+        for e in golden["method_cases"]:
+            if e["n"] <= lim:
+                by_method.setdefault(e["method"], []).append(e)
+        for method, es in by_method.items():
+            archives = gpu.compress_blocks([gen_input(e) for e in es], method, [e["filename"] for e in es],
+                                           [e["comment"] for e in es])
+            for e, a in zip(es, archives):
+                assert len(a) == e["len"] and hashlib.sha1(a).hexdigest() == e["sha1"], (e["kind"], e["n"], method)
+    finally:
+        gpu.set_kernel(0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_all_nine_component_types(gpu, oracle, golden, kernel):
+    gpu.set_kernel(kernel)
+    try:
+        e = golden["config_cases"][0]
+        a = b64(e)
+        hdr = bytes.fromhex(e["header"])
+        d = gen_input(e).tobytes()
+        plan = gpu.Plan(hdr)
+        c = gpu.encode_batch([plan], [b"\0" + d])[0]
+        ps = e["payload_start"]
+        assert a[ps:ps + len(c) + 4] == c + b"\0\0\0\0"
+        (dec, used), = gpu.decode_batch([plan], [a[ps:]], [len(d) + 64])
+        assert dec == b"\0" + d and used == len(c) + 4
+    finally:
+        gpu.set_kernel(0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_legacy_min_mid_max_models(gpu, golden, kernel, idx):
+    """BASELINE.json names mid.cfg / max.cfg: the built-in chains, encode + decode, from reference archives."""
+    gpu.set_kernel(kernel)
+    try:
+        e = golden["level_cases"][idx]
+        a = b64(e)
+        hdr = bytes.fromhex(e["header"])
+        d = gen_input(e).tobytes()
+        plan = gpu.Plan(hdr)
+        ps = e["payload_start"]
+        c = gpu.encode_batch([plan], [b"\0" + d])[0]
+        assert a[ps:ps + len(c) + 4] == c + b"\0\0\0\0"
+        assert gpu.decompress(a) == d
+    finally:
+        gpu.set_kernel(0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_decode_reference_archives(gpu, golden, kernel):
+    gpu.set_kernel(kernel)
+    try:
+        es = [e for e in golden["method_cases"] if "archive_b64" in e]
+        stream = b"".join(b64(e) for e in es)           # multi-block archive, decoded as one batch
+        want = b"".join(gen_input(e).tobytes() for e in es)
+        assert gpu.decompress(stream) == want
+    finally:
+        gpu.set_kernel(0)
+
+
+def test_decoder_status_codes(gpu, golden):
+    e = [x for x in golden["method_cases"] if x["kind"] == "text" and x["n"] == 20000 and x["method"] == "5"][0]
+    hdr = bytes.fromhex(e["header"])
+    plan = gpu.Plan(hdr)
+    d = gen_input(e).tobytes()
+    c = gpu.encode_batch([plan], [b"\0" + d])[0]
+    # truncated input -> EOF; "decode first k bytes" -> OK with consumed == 0; garbage -> not the original
+    res, st = gpu.decode_batch([plan], [c[:len(c) // 2]], [len(d) + 8], check=False)
+    assert st[0] in (6, 2)
+    (dec, used), = gpu.decode_batch([plan], [c + b"\0\0\0\0"], [1001])
+    assert used == 0 and dec == (b"\0" + d)[:1001]
+    bad = bytearray(c + b"\0\0\0\0")
+    bad[7] ^= 0x40
+    res, st = gpu.decode_batch([plan], [bytes(bad)], [len(d) + 8], check=False)
+    assert st[0] != 0 or res[0][0] != b"\0" + d
+    # output overflow on encode is reported, not silently truncated
+    outs, st, lens = gpu.encode_batch([plan], [b"\0" + d], out_cap=[100], check=False)
+    assert st[0] == 3 and lens[0] == len(c)
+
+
+def test_mixed_plans_in_one_batch_and_ragged_sizes(gpu, oracle):
+    """Blocks with different chains (period detection!) and ragged sizes, incl. empty, in ONE batch."""
+    blocks = [corpus.block("records", 30000, 5), corpus.block("text", 0, 6), corpus.block("text", 1, 7),
+              corpus.block("lcg", 12345, 8), corpus.block("pattern", 4097, 9), corpus.block("zeros", 70000, 10)]
+    archives = gpu.compress_blocks(blocks, "5")
+    ncomps = set()
+    for d, a in zip(blocks, archives):
+        f = parse_block(a)
+        ncomps.add(f["header"][6])
+        coded = oracle.encode(f["header"], b"\0" + d.tobytes())
+        ps = f["payload_start"]
+        assert a[ps:ps + len(coded) + 4] == coded + b"\0\0\0\0"
+    assert len(ncomps) >= 2
+    assert gpu.decompress(b"".join(archives)) == b"".join(b.tobytes() for b in blocks)
+
+
+def test_full_size_blocks_roundtrip_and_reference_cross_check(gpu):
+    """BASELINE block size (1 MiB, -m5): known-answer SHA-1s from BASELINE.md §2, round trip, and the
+    reference decoding our archives / us decoding the reference's when oracle/_ref is here."""
+    blocks = [corpus.block("zeros", 1 << 20, corpus.BASE_SEED), corpus.block("lcg", 1 << 20, corpus.BASE_SEED),
+              corpus.block("text", 1 << 20, corpus.BASE_SEED), corpus.block("records", 1 << 20, corpus.BASE_SEED)]
+    archives = gpu.compress_blocks(blocks, "5")
+    assert hashlib.sha1(archives[0]).hexdigest() == "33f41ec44b376e492954d759ddd560f07ee7734b" and len(archives[0]) == 341
+    assert hashlib.sha1(archives[1]).hexdigest() == "6e0850c1a89c9647a9ba954eaf143d297c8cf2d5" and len(archives[1]) == 1049128
+    back = gpu.decompress(b"".join(archives))
+    assert back == b"".join(b.tobytes() for b in blocks)
+    if have_ref():
+        from oracle.oracle_py import Ref
+        ref = Ref()
+        for d, a in zip(blocks[2:], archives[2:]):
+            assert ref.compress_block(d, "5") == a
+            assert ref.decompress(a, len(d)) == d.tobytes()

@@ -1,0 +1,159 @@
+"""CPU: the host side of the boundary (no compute calls, no GPU): ABI exports,
+SHA-1, constant tables, method expansion, ZPAQL assembler, container scan."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, gen_input
+from zpaq_amd import corpus
+
+
+def test_abi_exports_every_declared_symbol(zlib_):
+    hdr = open(os.path.join(ROOT, "include", "zpaq_amd.h")).read()
+    names = set(re.findall(r"\b(zpq_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    L = zlib_.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_library_fails_loudly_without_gpu(zlib_):
+    if zlib_.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(zlib_.ZpaqError) as ei:
+        zlib_.init(0)
+    assert "no CPU fallback" in str(ei.value)
+    with pytest.raises(zlib_.ZpaqError):
+        zlib_.compress_block(b"hello world" * 10, "5")
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under zpaq_amd/ may import, link or load anything from oracle/."""
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "zpaq_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hpp", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"oracle[/_.]|zpaq_oracle|libzpaq_ref", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_sha1(zlib_):
+    for n in [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 1000, 70000]:
+        d = corpus.lcg_bytes(n, 3)
+        assert zlib_.sha1(d) == hashlib.sha1(d.tobytes()).digest()
+
+
+def test_tables_match_oracle_and_checksums(zlib_, oracle):
+    for name in ["squash", "stretch", "dt", "dt2k", "state"]:
+        assert (zlib_.table(name) == oracle.table(name)).all(), name
+    st = zlib_.table("stretch").astype(np.int64)
+    sq = zlib_.table("squash").astype(np.int64)
+    s1 = 0
+    for v in st[::-1]:
+        s1 = (s1 * 3 + int(v)) & 0xFFFFFFFF
+    s2 = 0
+    for v in sq[::-1]:
+        s2 = (s2 * 3 + int(v)) & 0xFFFFFFFF
+    assert s1 == 3887533746 and s2 == 2278286169      # libzpaq.cpp:1759-1760
+
+
+def test_method_expansion_and_headers_vs_golden(zlib_, golden):
+    """expand_method + make_config + assembler reproduce the header bytes stored in reference archives."""
+    n = 0
+    for e in golden["method_cases"]:
+        d = gen_input(e)
+        xm = zlib_.expand_method(e["method"], d)
+        h, p, args = zlib_.method_to_header(xm)
+        assert h.hex() == e["header"], (e["kind"], e["n"], e["method"], xm)
+        assert p == b""
+        n += 1
+    assert n >= 60
+
+
+def test_method_expansion_live(zlib_, ref):
+    for kind in ["zeros", "text", "lcg", "records", "pattern"]:
+        for n in [0, 5, 4097, 70000, 1 << 20]:
+            d = corpus.block(kind, n, 4242)
+            for method in ["5", "4", "0", "57", "5,128,0", "5,200,1", "4,100,0", "4,60,1", "8"]:
+                xm = zlib_.expand_method(method, d)
+                h, p, args = zlib_.method_to_header(xm)
+                cfg, rargs = ref.make_config(xm)
+                assert (h, p) == ref.compile(cfg, rargs) and args == rargs, (kind, n, method, xm)
+
+
+def test_unsupported_methods_fail_loudly(zlib_):
+    d = corpus.block("text", 5000, 1)
+    for method in ["1", "2", "3", "5,128,2"]:      # need LZ77 / BWT / E8E9 pre-processing
+        xm = zlib_.expand_method(method, d)
+        with pytest.raises(zlib_.ZpaqError) as ei:
+            zlib_.method_to_header(xm)
+        assert ei.value.code == 8
+
+
+def test_assembler_vs_reference_compiler(zlib_, ref, golden):
+    cfgs = [golden["config_cases"][0]["config"]]
+    for xm in ["x0,1,4,0,3,20", "x1,1,5,0,3,21", "x0,2,12,0,7,21,1c0,0,511i2", "x0,3ci1", "x2,7ci1",
+               "x0,5,4,0,3,20", "x0,6,5,0,7,21,1c0,0,511", "x6,1,6,0,3,26", "x0,0ci1,1,1,1,2awm",
+               "x0,0c1000,0,255c0,1300,255,1500,255i2,13s16,32,255m12t8"]:
+        cfg, args = ref.make_config(xm)
+        assert zlib_.assemble(cfg, args) == ref.compile(cfg, args), xm
+    cfgs.append("""comp 3 8 0 0 2 0 cm 12 20 1 icm 10 hcomp
+      b<>a *c<>a c++ *c=a d=0 do a=*d a+=*c hashd d++ a=d a< 3 while
+      a=c a== 0 ifnot a=r 3 else a= 5 r=a 3 endif do a-- a> 200 until
+      a< 3 ifl b=0 elsel c=0 endif A=B a+= $2+7 Jmp 1 a++ halt
+      pcomp cat ; a> 255 if halt endif out do a++ a== 9 if halt endif forever halt end""")
+    for cfg in cfgs:
+        assert zlib_.assemble(cfg, [1, 2, 3]) == ref.compile(cfg, [1, 2, 3])
+
+
+def test_assembler_golden_all_types(zlib_, golden):
+    e = golden["config_cases"][0]
+    h, p = zlib_.assemble(e["config"])
+    assert h.hex() == e["header"] and p == b""
+
+
+def test_assembler_errors(zlib_):
+    for bad in ["comp 0 0 0 0 0 hcomp foo end", "comp 0 0 0 0 1 0 cm 300 2 hcomp halt end", "comp 0 0",
+                "comp 0 0 0 0 1 1 cm 3 2 hcomp halt end", "comp 0 0 0 0 0 hcomp endif end"]:
+        with pytest.raises(zlib_.ZpaqError):
+            zlib_.assemble(bad)
+
+
+def test_plan_memory_and_roofline_bytes(zlib_, golden):
+    for e in golden["method_cases"]:
+        hdr = bytes.fromhex(e["header"])
+        if hdr[6] == 0:
+            continue
+        p = zlib_.Plan(hdr)
+        assert p.memory == e["memory"]                 # ZPAQL::memory() as findBlock reports it
+        assert p.ncomp == hdr[6]
+        assert p.state_bytes >= e["memory"] - 2 * 2 ** hdr[4] - 2 ** hdr[5] - 400
+    # default -m5 chain at 1 MiB: A = 3626 B per input byte
+    d = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h, _, _ = zlib_.method_to_header(zlib_.expand_method("5", d))
+    p = zlib_.Plan(h)
+    assert p.ncomp == 23 and p.algo_bytes_per_byte == 3626.0 and p.memory == 101699634.0
+
+
+def test_plan_rejects_bad_headers(zlib_, golden):
+    hdr = bytearray(bytes.fromhex(golden["method_cases"][0]["header"]))
+    for mutate in (lambda h: h.__setitem__(7, 77), lambda h: h.__setitem__(0, h[0] ^ 1),
+                   lambda h: h.__setitem__(len(h) - 1, 9)):
+        h = bytearray(hdr)
+        mutate(h)
+        with pytest.raises(zlib_.ZpaqError):
+            zlib_.Plan(bytes(h))
+
+
+def test_stored_blocks_are_host_only_and_bit_exact(zlib_, golden):
+    """Method "0" has no model: pure container plumbing, identical to the reference without a GPU."""
+    e = [x for x in golden["method_cases"] if x["method"] == "0"][0]
+    a = zlib_.compress_block(gen_input(e), "0", e["filename"], e["comment"])
+    assert len(a) == e["len"] and hashlib.sha1(a).hexdigest() == e["sha1"]
+    assert zlib_.decompress(a) == gen_input(e).tobytes()

@@ -1,0 +1,223 @@
+// C ABI (include/zpaq_amd.h): converts internal Failure exceptions into status
+// codes and implements the batched block-level drop-ins on top of the engine.
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "device/engine.hpp"
+#include "device/plan.hpp"
+#include "host/common.hpp"
+#include "host/blocks.hpp"
+#include "host/container.hpp"
+
+namespace zpq {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+}  // namespace zpq
+
+using namespace zpq;
+
+#define ZPQ_TRY try {
+#define ZPQ_CATCH                                                        \
+  }                                                                      \
+  catch (const Failure& f) { set_last_error(f.what()); return f.code; } \
+  catch (const std::bad_alloc&) { set_last_error("Out of memory"); return ZPQ_E_NOMEM; } \
+  catch (const std::exception& ex) { set_last_error(ex.what()); return ZPQ_E_DEVICE; }
+
+extern "C" {
+
+const char* zpq_last_error(void) { return g_last_error.c_str(); }
+const char* zpq_version(void) { return "zpaq_amd 0.1 (ZPAQ level 2, libzpaq 7.15 compatible, gfx950)"; }
+
+int zpq_init(int device) { ZPQ_TRY engine_init(device); return ZPQ_OK; ZPQ_CATCH }
+int zpq_device_count(void) { return engine_device_count(); }
+void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
+int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
+int zpq_set_kernel(int which) { if (which < 0 || which > 2) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
+
+int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out) {
+  ZPQ_TRY
+  if (!out) fail(ZPQ_E_ARG, "null out");
+  *out = plan_from_header(header, hlen);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+void zpq_plan_destroy(zpq_plan* p) { if (p) { engine_plan_release(p); delete p; } }
+int zpq_plan_ncomp(const zpq_plan* p) { return p ? (int)p->hdr().n : 0; }
+double zpq_plan_memory(const zpq_plan* p) { return p ? p->memory : 0; }
+uint64_t zpq_plan_state_bytes(const zpq_plan* p) { return p ? p->hdr().arena_bytes : 0; }
+double zpq_plan_algo_bytes_per_byte(const zpq_plan* p) { return p ? p->algo_bytes : 0; }
+
+int zpq_encode_batch(const zpq_plan* const* plans, const uint8_t* const* in, const uint32_t* in_len,
+                     uint32_t nblocks, uint8_t* const* out, const uint32_t* out_cap, uint32_t* out_len,
+                     int32_t* status) {
+  ZPQ_TRY
+  std::vector<HostBlock> hb(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    if (!plans[b] || plans[b]->hdr().n == 0) fail(ZPQ_E_ARG, "encode_batch needs a modelled plan (n > 0)");
+    hb[b] = HostBlock{plans[b], nullptr, 0, in[b], in_len[b], out[b], out_cap[b]};
+  }
+  std::vector<BlockResult> res;
+  engine_code_host(false, hb, res);
+  int worst = ZPQ_OK;
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    if (out_len) out_len[b] = res[b].out_len;
+    if (status) status[b] = res[b].status;
+    if (res[b].status && !worst) worst = res[b].status;
+  }
+  if (worst) set_last_error("one or more blocks failed; see status[]");
+  return worst;
+  ZPQ_CATCH
+}
+
+int zpq_decode_batch(const zpq_plan* const* plans, const uint8_t* const* in, const uint32_t* in_len,
+                     uint32_t nblocks, uint8_t* const* out, const uint32_t* max_out, uint32_t* out_len,
+                     uint32_t* consumed, int32_t* status) {
+  ZPQ_TRY
+  std::vector<HostBlock> hb(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    if (!plans[b] || plans[b]->hdr().n == 0) fail(ZPQ_E_ARG, "decode_batch needs a modelled plan (n > 0)");
+    hb[b] = HostBlock{plans[b], nullptr, 0, in[b], in_len[b], out[b], max_out[b]};
+  }
+  std::vector<BlockResult> res;
+  engine_code_host(true, hb, res);
+  int worst = ZPQ_OK;
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    if (out_len) out_len[b] = res[b].out_len;
+    if (consumed) consumed[b] = res[b].consumed;
+    if (status) status[b] = res[b].status;
+    if (res[b].status && !worst) worst = res[b].status;
+  }
+  if (worst) set_last_error("one or more blocks failed; see status[]");
+  return worst;
+  ZPQ_CATCH
+}
+
+int zpq_encode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in_off, const uint32_t* in_len,
+                      uint32_t nblocks, void* d_out, const uint64_t* out_off, const uint32_t* out_cap,
+                      zpq_block_result* d_res, void* stream, int timed) {
+  ZPQ_TRY
+  if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
+  engine_code_device(false, plan, d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, (BlockResult*)d_res,
+                     stream, timed != 0);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_decode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in_off, const uint32_t* in_len,
+                      uint32_t nblocks, void* d_out, const uint64_t* out_off, const uint32_t* max_out,
+                      zpq_block_result* d_res, void* stream, int timed) {
+  ZPQ_TRY
+  if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
+  engine_code_device(true, plan, d_in, in_off, in_len, nblocks, d_out, out_off, max_out, (BlockResult*)d_res,
+                     stream, timed != 0);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks) {
+  Timing t = engine_last_timing();
+  if (init_ms) *init_ms = t.init_ms;
+  if (code_ms) *code_ms = t.code_ms;
+  if (blocks) *blocks = t.blocks;
+  return ZPQ_OK;
+}
+
+int zpq_selftest(int32_t out8[8]) { ZPQ_TRY return engine_selftest(out8); ZPQ_CATCH }
+
+// ------------------------------------------------------------ block drop-ins
+int zpq_compress_blocks(const char* method, uint8_t* const* in, const uint32_t* in_len, uint32_t nblocks,
+                        const char* const* filename, const char* const* comment, int dosha1,
+                        uint8_t* const* out, const uint64_t* out_cap, uint64_t* out_len) {
+  ZPQ_TRY
+  std::vector<BlockInput> inputs(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b)
+    inputs[b] = BlockInput{in[b], in_len[b], filename ? filename[b] : nullptr, comment ? comment[b] : nullptr};
+  std::vector<std::vector<U8>> archives;
+  compress_blocks(method, inputs, dosha1 != 0, archives);
+  int rc = ZPQ_OK;
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    if (out_len) out_len[b] = archives[b].size();
+    if (out && out[b] && out_cap && out_cap[b] >= archives[b].size())
+      memcpy(out[b], archives[b].data(), archives[b].size());
+    else { rc = ZPQ_E_OVERFLOW; set_last_error("output buffer too small"); }
+  }
+  return rc;
+  ZPQ_CATCH
+}
+
+int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  ZPQ_TRY
+  U64 total = 0;
+  bool overflow = false;
+  decode_archive(archive, (size_t)n, [&](const U8* p, size_t len) {
+    if (out && total + len <= cap) memcpy(out + total, p, len);
+    else overflow = true;
+    total += len;
+  });
+  if (out_len) *out_len = total;
+  if (overflow) { set_last_error("output buffer too small"); return ZPQ_E_OVERFLOW; }
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+// ------------------------------------------------------------- host pieces
+void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]) {
+  Sha1 s; s.update(in, (size_t)n); memcpy(out20, s.result(), 20);
+}
+
+int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char* out, size_t cap) {
+  ZPQ_TRY
+  const std::string m = expand_method(method ? method : "", data, n);
+  if (m.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "method buffer too small");
+  memcpy(out, m.c_str(), m.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+static int copy_assembled(const Assembled& as, uint8_t* hcomp, size_t hcap, size_t* hlen, uint8_t* pcomp,
+                          size_t pcap, size_t* plen) {
+  if (hlen) *hlen = as.hcomp.size();
+  if (plen) *plen = as.pcomp.size();
+  if (as.hcomp.size() > hcap || as.pcomp.size() > pcap) fail(ZPQ_E_OVERFLOW, "header buffer too small");
+  if (hcomp) memcpy(hcomp, as.hcomp.data(), as.hcomp.size());
+  if (pcomp && !as.pcomp.empty()) memcpy(pcomp, as.pcomp.data(), as.pcomp.size());
+  return ZPQ_OK;
+}
+
+int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t hcap, size_t* hlen,
+                         uint8_t* pcomp, size_t pcap, size_t* plen) {
+  ZPQ_TRY
+  int args[9];
+  const std::string cfg = make_config(xmethod ? xmethod : "", args);
+  if (args9) memcpy(args9, args, sizeof(args));
+  return copy_assembled(assemble(cfg.c_str(), args), hcomp, hcap, hlen, pcomp, pcap, plen);
+  ZPQ_CATCH
+}
+
+int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hcap, size_t* hlen,
+                 uint8_t* pcomp, size_t pcap, size_t* plen) {
+  ZPQ_TRY
+  return copy_assembled(assemble(config, args9), hcomp, hcap, hlen, pcomp, pcap, plen);
+  ZPQ_CATCH
+}
+
+size_t zpq_table(int which, void* out, size_t cap) {
+  try {
+    const Tables& t = tables();
+    const void* src; size_t n;
+    switch (which) {
+      case 0: src = t.squash; n = sizeof(t.squash); break;
+      case 1: src = t.stretch; n = sizeof(t.stretch); break;
+      case 2: src = t.dt; n = sizeof(t.dt); break;
+      case 3: src = t.dt2k; n = sizeof(t.dt2k); break;
+      case 4: src = t.ns; n = sizeof(t.ns); break;
+      default: return 0;
+    }
+    if (n > cap) return 0;
+    memcpy(out, src, n);
+    return n;
+  } catch (...) { return 0; }
+}
+
+}  // extern "C"

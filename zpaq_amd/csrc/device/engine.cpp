@@ -1,0 +1,312 @@
+// Batch engine: owns the device, the HBM arena pool and the launch sequence
+// (init_arena -> code_*).  One process drives one GPU; callers are serialised.
+#include "engine.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "kernels.h"
+
+namespace zpq {
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      int code_ = (e_ == hipErrorOutOfMemory) ? ZPQ_E_NOMEM : ZPQ_E_DEVICE;                   \
+      fail(code_, std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+    }                                                                                         \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = (n + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+    HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Engine {
+  std::mutex mu;
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  DeviceTables* d_tables = nullptr;
+  uint64_t budget = 0;
+  int kernel_choice = 0;
+  DevBuf arena, io_in, io_out, jobs, results;
+  Timing last{};
+};
+
+Engine& eng() {
+  static Engine e;
+  return e;
+}
+
+void require_ready(Engine& e) {
+  if (!e.ready) {
+    // lazy default init: LOCAL_RANK selects the device (one process per GPU)
+    int dev = 0;
+    if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr);
+    engine_init_locked(dev);
+  }
+}
+
+}  // namespace
+
+void engine_init_locked(int device) {
+  Engine& e = eng();
+  if (e.ready && e.device == device) return;
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess || count <= 0)
+    fail(ZPQ_E_DEVICE, "no HIP device available (the modelled path has no CPU fallback)");
+  if (device < 0 || device >= count) device = device % count;
+  HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    fail(ZPQ_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+  if (!e.stream) HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  // constant tables
+  const Tables& t = tables();
+  static DeviceTables host_tb;
+  memcpy(host_tb.stretch, t.stretch, sizeof(host_tb.stretch));
+  memcpy(host_tb.squash, t.squash, sizeof(host_tb.squash));
+  memcpy(host_tb.dt, t.dt, sizeof(host_tb.dt));
+  memcpy(host_tb.dt2k, t.dt2k, sizeof(host_tb.dt2k));
+  memcpy(host_tb.ns, t.ns, sizeof(host_tb.ns));
+  memcpy(host_tb.icm_init, t.icm_init, sizeof(host_tb.icm_init));
+  memcpy(host_tb.isse_init, t.isse_init, sizeof(host_tb.isse_init));
+  memcpy(host_tb.sse_row, t.sse_row, sizeof(host_tb.sse_row));
+  if (!e.d_tables) HIP_CHECK(hipMalloc((void**)&e.d_tables, sizeof(DeviceTables)));
+  HIP_CHECK(hipMemcpy(e.d_tables, &host_tb, sizeof(DeviceTables), hipMemcpyHostToDevice));
+  size_t free_b = 0, total_b = 0;
+  HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  if (!e.budget) e.budget = (uint64_t)(free_b * 0.85);
+  e.device = device;
+  e.ready = true;
+}
+
+void engine_init(int device) {
+  std::lock_guard<std::mutex> g(eng().mu);
+  engine_init_locked(device);
+}
+
+int engine_device_count() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+void engine_shutdown() {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  if (!e.ready) return;
+  (void)hipSetDevice(e.device);
+  (void)hipStreamSynchronize(e.stream);
+  e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release();
+  if (e.d_tables) (void)hipFree(e.d_tables);
+  e.d_tables = nullptr;
+  if (e.stream) (void)hipStreamDestroy(e.stream);
+  e.stream = nullptr;
+  e.ready = false;
+}
+
+void engine_set_budget(uint64_t bytes) { std::lock_guard<std::mutex> g(eng().mu); eng().budget = bytes; }
+void engine_set_kernel(int which) { std::lock_guard<std::mutex> g(eng().mu); eng().kernel_choice = which; }
+Timing engine_last_timing() { std::lock_guard<std::mutex> g(eng().mu); return eng().last; }
+
+static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
+  zpq_plan* p = const_cast<zpq_plan*>(plan);
+  if (p->d_blob && p->d_device == e.device) return (const uint8_t*)p->d_blob;
+  void* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, p->blob.size()));
+  HIP_CHECK(hipMemcpy(d, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+  p->d_blob = d;
+  p->d_device = e.device;
+  return (const uint8_t*)d;
+}
+
+void engine_plan_release(zpq_plan* p) {
+  if (p && p->d_blob) { (void)hipFree(p->d_blob); p->d_blob = nullptr; }
+}
+
+static bool use_wave(const Engine& e, const zpq_plan* plan) {
+  if (e.kernel_choice == 1) return false;
+  if (!plan->hdr().wave_ok) {
+    if (e.kernel_choice == 2) fail(ZPQ_E_UNSUPPORTED, "wave kernel forced but plan has more than 64 components");
+    return false;
+  }
+  return true;
+}
+
+// Launch init + coding kernels for jobs already resident on the device.
+// `order` lists job indices: first the wave-kernel jobs, then the serial ones.
+static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t n_wave,
+                       uint32_t n_serial, uint64_t max_arena, hipStream_t st, bool timed) {
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (timed) for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
+  const uint32_t nb = n_wave + n_serial;
+  // enough 256-thread groups per block to stream the arena at HBM rate
+  uint64_t per = max_arena / (256 * 16 * 8) + 1;
+  uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), 64);
+  if ((uint64_t)chunks * nb > 16384) chunks = (uint32_t)std::max<uint64_t>(1, 16384 / nb);
+  if (timed) HIP_CHECK(hipEventRecord(ev[0], st));
+  HIP_CHECK(launch_init_arena(d_jobs, nb, e.d_tables, chunks, st));
+  if (timed) HIP_CHECK(hipEventRecord(ev[1], st));
+  if (timed) HIP_CHECK(hipEventRecord(ev[2], st));
+  if (n_wave) HIP_CHECK(launch_code_wave(decode, d_jobs, d_res, n_wave, e.d_tables, st));
+  if (n_serial) HIP_CHECK(launch_code_serial(decode, d_jobs + n_wave, d_res + n_wave, n_serial, e.d_tables, st));
+  if (timed) {
+    HIP_CHECK(hipEventRecord(ev[3], st));
+    HIP_CHECK(hipEventSynchronize(ev[3]));
+    float a = 0, b = 0;
+    HIP_CHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&b, ev[2], ev[3]));
+    e.last.init_ms = a;
+    e.last.code_ms = b;
+    e.last.blocks = nb;
+    for (auto& x : ev) (void)hipEventDestroy(x);
+  }
+}
+
+void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  HIP_CHECK(hipSetDevice(e.device));
+  const size_t nb = blocks.size();
+  results.assign(nb, BlockResult{0, 0, 0, 0});
+  size_t pos = 0;
+  e.last = Timing{};
+  while (pos < nb) {
+    // one residency wave: as many blocks as fit the state budget
+    uint64_t need = 0, in_bytes = 0, out_bytes = 0, max_arena = 0;
+    size_t end = pos;
+    while (end < nb) {
+      const HostBlock& hb = blocks[end];
+      uint64_t a = hb.plan->hdr().arena_bytes;
+      if (end > pos && need + a > e.budget) break;
+      need += a;
+      max_arena = std::max(max_arena, a);
+      in_bytes += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
+      out_bytes += ((uint64_t)hb.out_cap + 63) & ~63ull;
+      ++end;
+    }
+    if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: one block's model state exceeds the device budget");
+    const size_t cnt = end - pos;
+    e.arena.ensure(need);
+    e.io_in.ensure(in_bytes + 64);
+    e.io_out.ensure(out_bytes + 64);
+    e.jobs.ensure(cnt * sizeof(BlockJob));
+    e.results.ensure(cnt * sizeof(BlockResult));
+    // order: wave-kernel jobs first
+    std::vector<size_t> order;
+    order.reserve(cnt);
+    for (size_t i = pos; i < end; ++i) if (use_wave(e, blocks[i].plan)) order.push_back(i);
+    const uint32_t n_wave = (uint32_t)order.size();
+    for (size_t i = pos; i < end; ++i) if (!use_wave(e, blocks[i].plan)) order.push_back(i);
+    std::vector<BlockJob> jobs(cnt);
+    std::vector<uint8_t> stage(in_bytes + 64);
+    std::vector<uint64_t> out_off(cnt);
+    uint64_t a_off = 0, i_off = 0, o_off = 0;
+    for (size_t k = 0; k < cnt; ++k) {
+      const HostBlock& hb = blocks[order[k]];
+      BlockJob& j = jobs[k];
+      memset(&j, 0, sizeof(j));
+      j.plan = plan_on_device(e, hb.plan);
+      j.arena = (uint8_t*)e.arena.p + a_off;
+      j.in = (const uint8_t*)e.io_in.p + i_off;
+      j.out = (uint8_t*)e.io_out.p + o_off;
+      j.in_len = hb.in_len + hb.prefix_len;
+      j.out_cap = hb.out_cap;
+      if (hb.prefix_len) memcpy(stage.data() + i_off, hb.prefix, hb.prefix_len);
+      if (hb.in_len) memcpy(stage.data() + i_off + hb.prefix_len, hb.in, hb.in_len);
+      out_off[k] = o_off;
+      a_off += hb.plan->hdr().arena_bytes;
+      i_off += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
+      o_off += ((uint64_t)hb.out_cap + 63) & ~63ull;
+    }
+    HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
+    Timing before = e.last;
+    launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, n_wave, (uint32_t)cnt - n_wave,
+               max_arena, e.stream, true);
+    e.last.init_ms += before.init_ms;
+    e.last.code_ms += before.code_ms;
+    e.last.blocks += before.blocks;
+    std::vector<BlockResult> res(cnt);
+    HIP_CHECK(hipMemcpyAsync(res.data(), e.results.p, cnt * sizeof(BlockResult), hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    for (size_t k = 0; k < cnt; ++k) {
+      const HostBlock& hb = blocks[order[k]];
+      results[order[k]] = res[k];
+      uint32_t got = std::min(res[k].out_len, hb.out_cap);
+      if (got && hb.out)
+        HIP_CHECK(hipMemcpyAsync(hb.out, (const uint8_t*)e.io_out.p + out_off[k], got, hipMemcpyDeviceToHost, e.stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    pos = end;
+  }
+}
+
+void engine_code_device(bool decode, const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
+                        const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
+                        const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed) {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  HIP_CHECK(hipSetDevice(e.device));
+  hipStream_t st = stream ? (hipStream_t)stream : e.stream;
+  const uint64_t a = plan->hdr().arena_bytes;
+  if (a * (uint64_t)nblocks > e.budget)
+    fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
+  e.arena.ensure(a * (uint64_t)nblocks);
+  e.jobs.ensure((size_t)nblocks * sizeof(BlockJob));
+  const uint8_t* dplan = plan_on_device(e, plan);
+  std::vector<BlockJob> jobs(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    BlockJob& j = jobs[b];
+    memset(&j, 0, sizeof(j));
+    j.plan = dplan;
+    j.arena = (uint8_t*)e.arena.p + a * b;
+    j.in = (const uint8_t*)d_in + in_off[b];
+    j.out = (uint8_t*)d_out + out_off[b];
+    j.in_len = in_len[b];
+    j.out_cap = out_cap[b];
+  }
+  HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), (size_t)nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));   // jobs vector goes out of scope below
+  const bool wave = use_wave(e, plan);
+  e.last = Timing{};
+  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, wave ? nblocks : 0, wave ? 0 : nblocks, a, st, timed);
+}
+
+int engine_selftest(int32_t out[8]) {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  HIP_CHECK(hipSetDevice(e.device));
+  int32_t* d = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d, 8 * sizeof(int32_t)));
+  HIP_CHECK(hipMemsetAsync(d, 0, 8 * sizeof(int32_t), e.stream));
+  HIP_CHECK(launch_selftest(d, e.stream));
+  HIP_CHECK(hipMemcpyAsync(out, d, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, e.stream));
+  HIP_CHECK(hipStreamSynchronize(e.stream));
+  (void)hipFree(d);
+  return 0;
+}
+
+}  // namespace zpq

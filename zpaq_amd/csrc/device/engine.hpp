@@ -1,0 +1,45 @@
+#pragma once
+#include <vector>
+
+#include "../host/common.hpp"
+#include "layout.h"
+#include "plan.hpp"
+
+namespace zpq {
+
+struct HostBlock {
+  const zpq_plan* plan;
+  const U8* prefix;   // optional bytes coded before `in` (the PP header), may be null
+  U32 prefix_len;
+  const U8* in;
+  U32 in_len;
+  U8* out;        // host destination (may be null to discard)
+  U32 out_cap;    // encode: capacity; decode: max bytes to decode
+};
+
+struct Timing {
+  float init_ms = 0;   // init_arena_kernel (Predictor::init)
+  float code_ms = 0;   // coding kernel(s)
+  uint32_t blocks = 0;
+};
+
+void engine_init(int device);
+void engine_init_locked(int device);
+int engine_device_count();
+void engine_shutdown();
+void engine_set_budget(uint64_t bytes);
+void engine_set_kernel(int which);
+Timing engine_last_timing();
+void engine_plan_release(zpq_plan* p);
+
+// Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.
+void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);
+
+// Device-resident batch of one plan; results land in the device array d_res.
+void engine_code_device(bool decode, const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
+                        const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
+                        const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed);
+
+int engine_selftest(int32_t out[8]);
+
+}  // namespace zpq

@@ -1,0 +1,198 @@
+// HIP kernels for gfx950 (MI355X).  No CUDA compatibility paths.
+//
+//   init_arena_kernel   : Predictor::init (libzpaq.cpp:1776-1846) for every block
+//                         of a batch, streaming 16-B stores (HBM-write bound).
+//   code_serial_kernel  : generic one-lane coder, any header (fallback/baseline).
+//   code_wave_kernel    : wave-parallel coder, one ZPAQ block per wavefront,
+//                         components spread over lanes (see model_wave.h).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "layout.h"
+#include "model_serial.h"
+#include "model_wave.h"
+
+namespace zpq {
+
+// ------------------------------------------------------------------ init
+__global__ __launch_bounds__(256) void init_arena_kernel(const BlockJob* jobs, const DeviceTables* tb) {
+  const BlockJob job = jobs[blockIdx.y];
+  const PlanHeader* ph = (const PlanHeader*)job.plan;
+  const Segment* segs = (const Segment*)(job.plan + ph->off_seg);
+  const uint32_t nseg = ph->nseg;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+  for (uint32_t s = 0; s < nseg; ++s) {
+    const Segment sg = segs[s];
+    uint4* dst = (uint4*)(job.arena + sg.off);
+    const uint64_t n16 = sg.bytes >> 4;
+    switch (sg.kind) {
+      case F_ZERO:
+      case F_U32: {
+        const uint32_t v = sg.kind == F_ZERO ? 0u : sg.value;
+        const uint4 q = make_uint4(v, v, v, v);
+        for (uint64_t i = tid; i < n16; i += nthreads) dst[i] = q;
+        break;
+      }
+      case F_SSE:
+        for (uint64_t i = tid; i < n16; i += nthreads) {
+          const uint32_t j = (uint32_t)(i & 7) * 4;
+          dst[i] = make_uint4(tb->sse_row[j] | sg.value, tb->sse_row[j + 1] | sg.value,
+                              tb->sse_row[j + 2] | sg.value, tb->sse_row[j + 3] | sg.value);
+        }
+        break;
+      case F_ICM:
+        for (uint64_t i = tid; i < n16; i += nthreads) dst[i] = ((const uint4*)tb->icm_init)[i];
+        break;
+      case F_ISSE:
+        for (uint64_t i = tid; i < n16; i += nthreads) dst[i] = ((const uint4*)tb->isse_init)[i];
+        break;
+      case F_MATCHBUF:
+        for (uint64_t i = tid; i < n16; i += nthreads) dst[i] = make_uint4(i == 0 ? 1u : 0u, 0, 0, 0);
+        break;
+    }
+  }
+}
+
+// ------------------------------------------------------------- serial coder
+struct RangeCoder {
+  uint32_t low, high;
+};
+
+template <bool DEC>
+__global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint32_t nblocks,
+                                   const DeviceTables* tb) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const BlockJob job = jobs[b];
+  SerialCtx s;
+  serial_open(s, job, tb);
+  uint32_t low = 1, high = 0xFFFFFFFFu;
+  uint32_t steps = 0;
+  int status = 0;
+  if (!DEC) {
+    // Encoder::compress / encode (libzpaq.cpp:2402-2447)
+    uint32_t n = 0;   // bytes produced
+    auto put = [&](uint32_t c) { if (n < job.out_cap) job.out[n] = (uint8_t)c; ++n; };
+    auto encode = [&](int y, uint32_t p) {
+      const uint32_t mid = low + (uint32_t)(((uint64_t)(high - low) * p) >> 16);
+      if (y) high = mid; else low = mid + 1;
+      while ((high ^ low) < 0x1000000u) {
+        put(high >> 24);
+        high = high << 8 | 255u;
+        low = low << 8;
+        low += (low == 0);
+      }
+    };
+    for (uint32_t k = 0; k < job.in_len && !status; ++k) {
+      const int c = job.in[k];
+      encode(0, 0);
+      for (int i = 7; i >= 0; --i) {
+        const int pr = serial_predict(s);
+        const int y = (c >> i) & 1;
+        encode(y, (uint32_t)pr * 2 + 1);
+        status = serial_update(s, y);
+        ++steps;
+        if (status) break;
+      }
+    }
+    if (!status) encode(1, 0);
+    if (!status && n > job.out_cap) status = 3;
+    res[b].out_len = n;
+    res[b].consumed = job.in_len;
+  } else {
+    // Decoder::decompress / decode (libzpaq.cpp:2104-2155)
+    uint32_t rp = 0, n = 0, curr = 0;
+    bool eos = false;
+    for (int i = 0; i < 4; ++i) {
+      if (rp >= job.in_len) { status = 6; break; }
+      curr = curr << 8 | job.in[rp++];
+    }
+    while (!status && !eos && n < job.out_cap) {
+      int c = 1;
+      for (int bit = -1; bit < 8; ++bit) {
+        uint32_t p = 0;
+        if (bit >= 0) p = (uint32_t)serial_predict(s) * 2 + 1;
+        if (curr < low || curr > high) { status = 2; break; }
+        const uint32_t mid = low + (uint32_t)(((uint64_t)(high - low) * p) >> 16);
+        int y;
+        if (curr <= mid) { y = 1; high = mid; } else { y = 0; low = mid + 1; }
+        while ((high ^ low) < 0x1000000u) {
+          high = high << 8 | 255u;
+          low = low << 8;
+          low += (low == 0);
+          if (rp >= job.in_len) { status = 6; break; }
+          curr = curr << 8 | job.in[rp++];
+        }
+        if (status) break;
+        if (bit < 0) {
+          if (y) { eos = true; if (curr != 0) status = 2; break; }
+        } else {
+          c += c + y;
+          status = serial_update(s, y);
+          ++steps;
+          if (status) break;
+        }
+      }
+      if (status || eos) break;
+      job.out[n++] = (uint8_t)(c - 256);
+    }
+    res[b].out_len = n;
+    res[b].consumed = eos ? rp : 0;
+  }
+  res[b].status = status;
+  res[b].steps = steps;
+}
+
+// ---------------------------------------------------------------- selftest
+// Checks the cross-lane idioms the wave kernel relies on (DPP reduction,
+// readlane, bpermute shuffles).  out[0]=wave_sum(lane) (2016), out[1]=wave_sum
+// of (lane*lane - 1000) (83640), out[2]=readlane(lane*3, 41) (123),
+// out[3]=sum of __shfl(lane, (lane+5)&63) over lanes (2016), out[4]=wave_sum
+// with only lanes < 19 contributing 7 each (133).
+__global__ void selftest_kernel(int32_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int a = wave_sum(lane);
+  const int b = wave_sum(lane * lane - 1000);
+  const int c = rl(lane * 3, 41);
+  const int d = wave_sum(__shfl(lane, (lane + 5) & 63));
+  int x = 0;
+  if (lane < 19) x = 7;
+  const int e = wave_sum(x);
+  if (lane == 0) { out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = e; }
+}
+
+// ------------------------------------------------------------ launch glue
+static inline hipError_t last() { return hipGetLastError(); }
+
+hipError_t launch_init_arena(const BlockJob* d_jobs, uint32_t nblocks, const DeviceTables* d_tb,
+                             uint32_t chunks, hipStream_t st) {
+  if (!nblocks) return hipSuccess;
+  hipLaunchKernelGGL(init_arena_kernel, dim3(chunks, nblocks), dim3(256), 0, st, d_jobs, d_tb);
+  return last();
+}
+
+hipError_t launch_selftest(int32_t* d_out, hipStream_t st) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, d_out);
+  return last();
+}
+
+hipError_t launch_code_serial(bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t nblocks,
+                              const DeviceTables* d_tb, hipStream_t st) {
+  if (!nblocks) return hipSuccess;
+  // one wavefront per block, one active lane: <<<nblocks, 1>>>
+  if (decode) hipLaunchKernelGGL(code_serial_kernel<true>, dim3(nblocks), dim3(1), 0, st, d_jobs, d_res, nblocks, d_tb);
+  else hipLaunchKernelGGL(code_serial_kernel<false>, dim3(nblocks), dim3(1), 0, st, d_jobs, d_res, nblocks, d_tb);
+  return last();
+}
+
+hipError_t launch_code_wave(bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t nblocks,
+                            const DeviceTables* d_tb, hipStream_t st) {
+  if (!nblocks) return hipSuccess;
+  const uint32_t wg = (nblocks + kWavesPerGroup - 1) / kWavesPerGroup;
+  if (decode) hipLaunchKernelGGL(code_wave_kernel<true>, dim3(wg), dim3(64 * kWavesPerGroup), 0, st, d_jobs, d_res, nblocks, d_tb);
+  else hipLaunchKernelGGL(code_wave_kernel<false>, dim3(wg), dim3(64 * kWavesPerGroup), 0, st, d_jobs, d_res, nblocks, d_tb);
+  return last();
+}
+
+}  // namespace zpq

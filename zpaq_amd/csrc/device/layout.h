@@ -1,0 +1,98 @@
+// Device-visible data layout shared by the host engine and the HIP kernels.
+//
+// One in-flight ZPAQ block owns one contiguous ARENA in HBM:
+//
+//   [ component tables, each 256-B aligned, in COMP order ]   Predictor::init 1776-1846
+//   [ H : U32[2^hh] ][ M : U8[2^hm] ][ R : U32[256] ]         ZPAQL::init 1012-1024
+//   [ BlockRun : per-block scalar state + h[]/p[] + per-component run vars ]
+//
+// The plan (parsed header) is immutable and shared by all blocks coded with the
+// same header; it lives in its own small device buffer.
+#pragma once
+#include <stdint.h>
+
+namespace zpq {
+
+enum CompType : uint32_t { C_NONE = 0, C_CONS, C_CM, C_ICM, C_MATCH, C_AVG, C_MIX2, C_MIX, C_ISSE, C_SSE };
+
+// How to initialise one arena segment (Predictor::init patterns).
+enum FillKind : uint32_t {
+  F_ZERO = 0,
+  F_U32 = 1,       // every dword = value            (CM 0x80000000, MIX 65536/m, MIX2 0x80008000)
+  F_SSE = 2,       // dword j = sse_row[j&31] | value (SSE, value = start count)
+  F_ICM = 3,       // copy icm_init[256]
+  F_ISSE = 4,      // copy isse_init[512]
+  F_MATCHBUF = 5   // zeros, first byte = 1           (MATCH ht(0)=1, libzpaq.cpp:1801)
+};
+
+struct Segment {          // 24 bytes
+  uint64_t off;           // byte offset in arena (256-B aligned)
+  uint64_t bytes;         // multiple of 16
+  uint32_t kind;
+  uint32_t value;
+};
+
+struct CompDesc {         // 64 bytes
+  uint32_t type;
+  uint32_t a1, a2, a3, a4, a5;   // COMP argument bytes cp[1..5]
+  uint32_t limit;         // CM/SSE: cp[]*4 count limit
+  uint32_t mask0;         // t0 index mask (elements): CM 2^s-1, MATCH 2^a1-1, MIX/MIX2 2^s-1, SSE 32*2^s-1
+  uint32_t mask1;         // t1 mask (bytes): ICM/ISSE ht_n-1, MATCH 2^a2-1
+  uint32_t pad0;
+  uint64_t t0;            // arena offset of cm / a16
+  uint64_t t1;            // arena offset of ht
+  uint64_t pad1;
+};
+
+struct PlanHeader {       // followed in the same buffer by CompDesc[n], Segment[nseg], prog[prog_len]
+  uint32_t n;             // components
+  uint32_t hmask;         // 2^hh - 1 (elements)
+  uint32_t mmask;         // 2^hm - 1 (bytes)
+  uint32_t prog_len;      // HCOMP bytes incl. trailing 0
+  uint32_t nseg;
+  uint32_t wave_ok;       // 1 if the wave-parallel kernel supports this chain
+  uint64_t off_H, off_M, off_R, off_run;   // arena offsets
+  uint64_t arena_bytes;   // total, 4 KiB multiple
+  uint32_t off_comp;      // byte offsets inside this buffer
+  uint32_t off_seg;
+  uint32_t off_prog;
+  uint32_t total_bytes;
+  uint64_t dep_mask;      // wave kernel: lanes whose predict needs earlier p[] (ISSE/AVG/MIX2/MIX/SSE)
+  uint64_t mix_mask;      // wave kernel: MIX lanes
+};
+
+// Per-block job descriptor (device array, one per block in the batch).
+struct BlockJob {
+  const uint8_t* plan;    // -> PlanHeader
+  uint8_t* arena;
+  const uint8_t* in;
+  uint8_t* out;
+  uint32_t in_len;
+  uint32_t out_cap;       // encode: capacity; decode: max bytes to decode
+  uint32_t pad[2];
+};
+
+struct BlockResult {      // 16 bytes
+  uint32_t out_len;
+  uint32_t consumed;
+  int32_t status;
+  uint32_t steps;         // coded bits (diagnostic)
+};
+
+// Constant tables as uploaded to the device (one buffer).
+struct DeviceTables {
+  int16_t stretch[32768];
+  uint16_t squash[4096];
+  int32_t dt[1024];
+  int32_t dt2k[256];
+  uint8_t ns[1024];
+  uint32_t icm_init[256];
+  uint32_t isse_init[512];
+  uint32_t sse_row[32];
+};
+
+// Cap on HCOMP instructions per input byte: the reference has no limit (a
+// hostile header can loop forever); a device kernel must not hang.
+static const uint32_t kMaxVmSteps = 1u << 20;
+
+}  // namespace zpq

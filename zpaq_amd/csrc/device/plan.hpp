@@ -1,0 +1,21 @@
+#pragma once
+#include <vector>
+
+#include "../host/common.hpp"
+#include "layout.h"
+
+struct zpq_plan {
+  std::vector<uint8_t> header;     // stored header bytes
+  std::vector<uint8_t> blob;       // PlanHeader + CompDesc[] + Segment[] + prog (host copy)
+  double memory = 0;               // ZPAQL::memory()
+  double algo_bytes = 0;
+  void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
+  int d_device = -1;
+  const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
+  const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }
+};
+
+namespace zpq {
+// Parses a stored block header into a plan; throws Failure(ZPQ_E_HEADER/...).
+zpq_plan* plan_from_header(const U8* header, size_t hlen);
+}

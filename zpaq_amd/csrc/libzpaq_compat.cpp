@@ -1,0 +1,471 @@
+// libzpaq-compatible C++ layer (include/libzpaq.h) over the device engine.
+// Each function names the reference code it stands in for; the hot path
+// (predict/update/encode/decode) is never executed on the host here.
+#include "../../include/libzpaq.h"
+
+#include <stdexcept>
+
+#include "device/plan.hpp"
+#include "host/blocks.hpp"
+#include "host/common.hpp"
+#include "host/container.hpp"
+
+namespace libzpaq {
+
+// Weak default; an application definition of libzpaq::error overrides it
+// (the reference leaves it undefined, libzpaq.h:858).
+__attribute__((weak)) void error(const char* msg) { throw std::runtime_error(msg ? msg : "libzpaq error"); }
+
+namespace {
+// Internal failures surface through error() with the reference's wording where
+// one exists ("Out of memory" matters: zpaq.cpp:123-126 maps it to bad_alloc).
+[[noreturn]] void raise(const zpq::Failure& f) {
+  if (f.code == ZPQ_E_NOMEM) error("Out of memory");
+  error(f.what());
+  throw std::logic_error("libzpaq::error returned");
+}
+template <typename F>
+void guarded(F&& fn) {
+  try { fn(); }
+  catch (const zpq::Failure& f) { raise(f); }
+  catch (const std::bad_alloc&) { error("Out of memory"); throw; }
+}
+
+struct VecWriter : public Writer {
+  std::vector<U8>& v;
+  explicit VecWriter(std::vector<U8>& v_) : v(v_) {}
+  void put(int c) { v.push_back((U8)c); }
+  void write(const char* b, int n) { if (n > 0) v.insert(v.end(), (const U8*)b, (const U8*)b + n); }
+};
+}  // namespace
+
+int toU16(const char* p) { return (p[0] & 255) + 256 * (p[1] & 255); }
+
+int Reader::read(char* buf, int n) {
+  int i = 0, c;
+  while (i < n && (c = get()) >= 0) buf[i++] = (char)c;
+  return i;
+}
+void Writer::write(const char* buf, int n) {
+  for (int i = 0; i < n; ++i) put((U8)buf[i]);
+}
+
+// ---------------------------------------------------------------- SHA1
+// (reference libzpaq.cpp:106-177)
+static void sha1_reset(U32 h[5]) {
+  h[0] = 0x67452301u; h[1] = 0xEFCDAB89u; h[2] = 0x98BADCFEu; h[3] = 0x10325476u; h[4] = 0xC3D2E1F0u;
+}
+SHA1::SHA1() : len_(0) { sha1_reset(h_); }
+void SHA1::put(int c) {
+  buf_[len_ & 63] = (U8)c;
+  if ((++len_ & 63) == 0) zpq::sha1_compress(h_, buf_);
+}
+void SHA1::write(const char* b, int64_t n) {
+  int64_t i = 0;
+  while (i < n && (len_ & 63)) put((U8)b[i++]);
+  for (; i + 64 <= n; i += 64) { zpq::sha1_compress(h_, (const U8*)b + i); len_ += 64; }
+  while (i < n) put((U8)b[i++]);
+}
+const char* SHA1::result() {
+  const U64 bits = len_ * 8;
+  put(0x80);
+  while ((len_ & 63) != 56) put(0);
+  for (int i = 7; i >= 0; --i) put((int)(bits >> (8 * i)) & 255);
+  for (int i = 0; i < 5; ++i) {
+    out_[4 * i] = (char)(h_[i] >> 24); out_[4 * i + 1] = (char)(h_[i] >> 16);
+    out_[4 * i + 2] = (char)(h_[i] >> 8); out_[4 * i + 3] = (char)h_[i];
+  }
+  sha1_reset(h_);
+  len_ = 0;
+  return out_;
+}
+
+// ------------------------------------------------------ one-call functions
+// compressBlock (reference libzpaq.cpp:7543-7731)
+void compressBlock(StringBuffer* in, Writer* out, const char* method, const char* filename,
+                   const char* comment, bool dosha1) {
+  StringBuffer* ins[1] = {in};
+  Writer* outs[1] = {out};
+  const char* fn[1] = {filename};
+  const char* cm[1] = {comment};
+  compressBlocks(ins, outs, 1, method, fn, cm, dosha1);
+}
+
+void compressBlocks(StringBuffer* const* in, Writer* const* out, int n, const char* method,
+                    const char* const* filename, const char* const* comment, bool dosha1) {
+  if (n <= 0) return;
+  std::vector<zpq::BlockInput> inputs((size_t)n);
+  for (int i = 0; i < n; ++i)
+    inputs[i] = zpq::BlockInput{in[i]->data(), (U32)in[i]->size(), filename ? filename[i] : 0, comment ? comment[i] : 0};
+  std::vector<std::vector<U8>> archives;
+  guarded([&] { zpq::compress_blocks(method, inputs, dosha1, archives); });
+  for (int i = 0; i < n; ++i) {
+    size_t pos = 0;
+    while (pos < archives[i].size()) {   // Writer::write takes an int length
+      const size_t k = std::min<size_t>(archives[i].size() - pos, 1u << 30);
+      out[i]->write((const char*)archives[i].data() + pos, (int)k);
+      pos += k;
+    }
+  }
+}
+
+// compress (reference libzpaq.cpp:3008-3031): the stream is cut into blocks of
+// 2^(20+B)-4096 bytes; here up to kBatch blocks are gathered per device batch.
+void compress(Reader* in, Writer* out, const char* method, const char* filename, const char* comment,
+              bool dosha1) {
+  int bs = 4;
+  if (method && method[0] && method[1] >= '0' && method[1] <= '9') {
+    bs = method[1] - '0';
+    if (method[2] >= '0' && method[2] <= '9') bs = bs * 10 + method[2] - '0';
+    if (bs > 11) bs = 11;
+  }
+  const size_t block = ((size_t)0x100000 << bs) - 4096;
+  const size_t kBatchBytes = (size_t)1 << 31;   // host staging bound per batch
+  const size_t kBatch = std::max<size_t>(1, std::min<size_t>(1024, kBatchBytes / block));
+  bool first = true, eof = !in;
+  while (!eof) {
+    std::vector<StringBuffer*> bufs;
+    while (bufs.size() < kBatch) {
+      StringBuffer* sb = new StringBuffer(block);
+      sb->write(0, (int)block);
+      const int got = in->read((char*)sb->data(), (int)block);
+      if (got <= 0) { delete sb; eof = true; break; }
+      sb->resize((size_t)got);
+      bufs.push_back(sb);
+      if ((size_t)got < block) { /* short read: keep going, the next read decides EOF */ }
+    }
+    if (!bufs.empty()) {
+      std::vector<Writer*> outs(bufs.size(), out);
+      std::vector<const char*> fn(bufs.size(), (const char*)0), cm(bufs.size(), (const char*)0);
+      if (first) { fn[0] = filename; cm[0] = comment; first = false; }
+      try { compressBlocks(bufs.data(), outs.data(), (int)bufs.size(), method, fn.data(), cm.data(), dosha1); }
+      catch (...) { for (StringBuffer* b : bufs) delete b; throw; }
+    }
+    for (StringBuffer* b : bufs) delete b;
+  }
+}
+
+// decompress (reference libzpaq.cpp:2378-2389)
+void decompress(Reader* in, Writer* out) {
+  std::vector<U8> all;
+  if (in) {
+    char tmp[1 << 16];
+    int got;
+    while ((got = in->read(tmp, sizeof(tmp))) > 0) all.insert(all.end(), tmp, tmp + got);
+  }
+  guarded([&] {
+    zpq::decode_archive(all.data(), all.size(), [&](const U8* p, size_t len) {
+      size_t pos = 0;
+      while (out && pos < len) {
+        const size_t k = std::min<size_t>(len - pos, 1u << 30);
+        out->write((const char*)p + pos, (int)k);
+        pos += k;
+      }
+    });
+  });
+}
+
+// ------------------------------------------------------------ Decompresser
+// (reference libzpaq.cpp:2247-2374).  A segment's payload is located with the
+// same scan Decoder::skip uses, decoded completely on the device the first time
+// decompress() is called for it, and then served in the requested pieces.
+Decompresser::Decompresser()
+    : in_(0), out_(0), sha1_(0), rpos_(0), plan_(0), dpos_(0), payload_end_(0), seg_decoded_(false),
+      segs_in_block_(0), state_(BLOCK) {}
+Decompresser::~Decompresser() {}
+
+int Decompresser::getc() {
+  if (rpos_ == buf_.size()) {
+    // drop consumed bytes, refill (the read-ahead the reference's Decoder::get does)
+    buf_.clear();
+    rpos_ = 0;
+    if (!in_) return -1;
+    buf_.resize(1 << 16);
+    const int got = in_->read((char*)buf_.data(), (int)buf_.size());
+    buf_.resize(got > 0 ? (size_t)got : 0);
+    if (buf_.empty()) return -1;
+  }
+  return buf_[rpos_++];
+}
+
+bool Decompresser::findBlock(double* memptr) {
+  U32 h1 = 0x3D49B113u, h2 = 0x29EB7F93u, h3 = 0x2614BE13u, h4 = 0x3828EB13u;
+  int c;
+  while ((c = getc()) != -1) {
+    h1 = h1 * 12 + (U32)c; h2 = h2 * 20 + (U32)c; h3 = h3 * 28 + (U32)c; h4 = h4 * 44 + (U32)c;
+    if (h1 == 0xB16B88F1u && h2 == 0xFF5376F1u && h3 == 0x72AC5BF1u && h4 == 0x2F909AF1u) break;
+  }
+  if (c == -1) return false;
+  const int level = getc();
+  if (level != 1 && level != 2) error("unsupported ZPAQ level");
+  if (getc() != 1) error("unsupported ZPAQL type");
+  header_.clear();
+  const int lo = getc(), hi = getc();
+  if (lo < 0 || hi < 0) error("unexpected end of file");
+  header_.push_back((U8)lo); header_.push_back((U8)hi);
+  const int hsize = lo + 256 * hi;
+  for (int i = 0; i < hsize; ++i) {
+    const int b = getc();
+    if (b < 0) error("unexpected end of file");
+    header_.push_back((U8)b);
+  }
+  if (hsize < 6) error("header too short");
+  if (level == 1 && header_[6] == 0) error("ZPAQ level 1 requires at least 1 component");
+  if (memptr) {
+    if (header_[6]) {
+      guarded([&] {
+        zpq_plan* p = zpq::plan_from_header(header_.data(), header_.size());
+        *memptr = p->memory;
+        delete p;
+      });
+    } else *memptr = 0;
+  }
+  segs_in_block_ = 0;
+  state_ = FILENAME;
+  return true;
+}
+
+void Decompresser::hcomp(Writer* out2) {
+  for (size_t i = 0; i < header_.size(); ++i) out2->put(header_[i]);
+}
+bool Decompresser::pcomp(Writer*) { return false; }
+
+bool Decompresser::findFilename(Writer* filename) {
+  const int c = getc();
+  if (c == 1) {
+    for (;;) {
+      const int b = getc();
+      if (b == -1) error("unexpected EOF");
+      if (b == 0) { state_ = COMMENT; return true; }
+      if (filename) filename->put(b);
+    }
+  } else if (c == 255) { state_ = BLOCK; return false; }
+  error("missing segment or end of block");
+  return false;
+}
+
+void Decompresser::readComment(Writer* comment) {
+  state_ = DATA;
+  for (;;) {
+    const int b = getc();
+    if (b == -1) error("unexpected EOF");
+    if (b == 0) break;
+    if (comment) comment->put(b);
+  }
+  if (getc() != 0) error("missing reserved byte");
+  seg_decoded_ = false;
+  decoded_.clear();
+  dpos_ = 0;
+}
+
+// Gathers this segment's payload from the input (up to and including the zero
+// terminator) and decodes it on the device.
+void Decompresser::decode_segment() {
+  std::vector<U8> payload;
+  const bool modeled = header_[6] != 0;
+  if (modeled) {
+    if (++segs_in_block_ > 1) error("multi-segment modelled blocks are outside this build's scope");
+    U32 curr = 0;
+    int c = 0;
+    while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); payload.push_back((U8)c); curr = (U32)c; }
+    while (curr) { c = getc(); if (c < 0) error("unexpected end of file"); payload.push_back((U8)c); curr = curr << 8 | (U32)c; }
+    // a flush byte of 00 puts a fifth zero in front of the marker (Decoder::skip 2165)
+    while ((c = getc()) == 0) payload.push_back(0);
+    if (c >= 0) --rpos_;
+    guarded([&] { decoded_ = zpq::decode_payload(header_, payload.data(), payload.size(), 0); });
+  } else {
+    for (;;) {
+      U32 len = 0;
+      for (int i = 0; i < 4; ++i) { const int c = getc(); if (c < 0) error("unexpected end of file"); len = len << 8 | (U32)c; }
+      if (!len) break;
+      for (U32 i = 0; i < len; ++i) { const int c = getc(); if (c < 0) error("unexpected end of file"); decoded_.push_back((U8)c); }
+    }
+  }
+  if (decoded_.empty()) error("Unexpected EOS");
+  if (decoded_[0] == 1) error("PCOMP post-processing is outside this build's hot-path scope");
+  if (decoded_[0] != 0) error("unknown post processing type");
+  dpos_ = 1;
+  seg_decoded_ = true;
+}
+
+bool Decompresser::decompress(int n) {
+  if (state_ != DATA) error("decompression after skipped segment");
+  if (!seg_decoded_) decode_segment();
+  size_t avail = decoded_.size() - dpos_;
+  size_t take = (n < 0 || (size_t)n > avail) ? avail : (size_t)n;
+  if (take) {
+    if (out_) out_->write((const char*)decoded_.data() + dpos_, (int)take);
+    if (sha1_) sha1_->write((const char*)decoded_.data() + dpos_, (int64_t)take);
+    dpos_ += take;
+  }
+  // the reference returns false exactly when the EOS symbol is decoded (2333-2340):
+  // i.e. when more bytes were asked for than the segment still held
+  if (n < 0 || (size_t)n > take) { state_ = SEGEND; return false; }
+  return true;
+}
+
+void Decompresser::readSegmentEnd(char* sha1string) {
+  int c = 0;
+  if (state_ == DATA) {
+    if (!seg_decoded_) {
+      // skip without decoding (Decoder::skip 2158-2181)
+      if (header_[6]) {
+        U32 curr = 0;
+        while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); curr = (U32)c; }
+        while (curr && (c = getc()) >= 0) curr = curr << 8 | (U32)c;
+        ++segs_in_block_;
+      } else {
+        for (;;) {
+          U32 len = 0;
+          for (int i = 0; i < 4; ++i) { c = getc(); if (c < 0) error("skipped to EOF"); len = len << 8 | (U32)c; }
+          if (!len) break;
+          for (U32 i = 0; i < len; ++i) if (getc() < 0) error("skipped to EOF");
+        }
+      }
+    }
+    while ((c = getc()) == 0) {}
+  } else {
+    while ((c = getc()) == 0) {}   // a flush byte of 00 leaves extra zeros before the marker
+  }
+  state_ = FILENAME;
+  if (c == 254) { if (sha1string) sha1string[0] = 0; }
+  else if (c == 253) {
+    if (sha1string) sha1string[0] = 1;
+    for (int i = 1; i <= 20; ++i) { const int b = getc(); if (sha1string) sha1string[i] = (char)b; }
+  } else error("missing end of segment marker");
+}
+
+// -------------------------------------------------------------- Compressor
+// (reference libzpaq.cpp:2776-3004).  Bytes are gathered per segment and coded
+// on the device when the segment ends.
+Compressor::Compressor() : out_(0), in_(0), segs_(0), state_(INIT) { memset(sha1result_, 0, 20); }
+Compressor::~Compressor() {}
+
+void Compressor::writeTag() {
+  for (int i = 0; i < 13; ++i) out_->put(zpq::kBlockTag[i]);
+}
+
+void Compressor::startBlock(int) {
+  error("built-in min/mid/max models are not bundled; pass their header bytes or a config to startBlock()");
+}
+
+void Compressor::startBlock(const char* hcomp) {
+  const size_t hsize = (size_t)toU16(hcomp);
+  header_.assign((const U8*)hcomp, (const U8*)hcomp + hsize + 2);
+  pcomp_.clear();
+  guarded([&] { delete zpq::plan_from_header(header_.data(), header_.size()); });   // validate
+  out_->put('z'); out_->put('P'); out_->put('Q');
+  out_->put(1 + (header_[6] == 0));
+  out_->put(1);
+  for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
+  segs_ = 0;
+  state_ = BLOCK1;
+}
+
+void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
+  zpq::Assembled as;
+  guarded([&] { as = zpq::assemble(config, args); });
+  if (pcomp_cmd) for (char ch : as.pcomp_cmd) pcomp_cmd->put((U8)ch);
+  header_ = as.hcomp;
+  pcomp_ = as.pcomp;
+  out_->put('z'); out_->put('P'); out_->put('Q');
+  out_->put(1 + (header_[6] == 0));
+  out_->put(1);
+  for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
+  segs_ = 0;
+  state_ = BLOCK1;
+}
+
+void Compressor::hcomp(Writer* out2) { for (size_t i = 0; i < header_.size(); ++i) out2->put(header_[i]); }
+bool Compressor::pcomp(Writer* out2) {
+  if (pcomp_.empty()) return false;
+  for (size_t i = 0; i < pcomp_.size(); ++i) out2->put(pcomp_[i]);
+  return true;
+}
+
+void Compressor::startSegment(const char* filename, const char* comment) {
+  out_->put(1);
+  while (filename && *filename) out_->put(*filename++);
+  out_->put(0);
+  while (comment && *comment) out_->put(*comment++);
+  out_->put(0);
+  out_->put(0);
+  if (state_ == BLOCK1) state_ = SEG1;
+  if (state_ == BLOCK2) state_ = SEG2;
+  pending_.clear();
+}
+
+void Compressor::postProcess(const char* pcomp, int len) {
+  if (state_ == SEG2) return;
+  std::vector<U8> code;
+  if (!pcomp) { if (pcomp_.size() > 2) code.assign(pcomp_.begin() + 2, pcomp_.end()); }
+  else {
+    if (len == 0) { len = toU16(pcomp); pcomp += 2; }
+    code.assign((const U8*)pcomp, (const U8*)pcomp + len);
+  }
+  if (!code.empty()) {
+    pending_.push_back(1);
+    pending_.push_back((U8)(code.size() & 255));
+    pending_.push_back((U8)(code.size() >> 8));
+    pending_.insert(pending_.end(), code.begin(), code.end());
+  } else pending_.push_back(0);
+  state_ = SEG2;
+}
+
+bool Compressor::compress(int n) {
+  if (state_ == SEG1) postProcess();
+  char buf[1 << 14];
+  while (n) {
+    int want = (int)sizeof(buf);
+    if (n >= 0 && n < want) want = n;
+    const int got = in_->read(buf, want);
+    if (got < 0 || got > want) error("invalid read size");
+    if (got <= 0) return false;
+    if (n >= 0) n -= got;
+    pending_.insert(pending_.end(), (const U8*)buf, (const U8*)buf + got);
+  }
+  return true;
+}
+
+void Compressor::flush_segment() {
+  if (state_ == SEG1) postProcess();
+  if (header_[6] == 0) {
+    std::vector<U8> framed;
+    zpq::write_stored_payload(framed, 0, 0, pending_.data(), pending_.size());
+    if (!framed.empty()) out_->write((const char*)framed.data(), (int)framed.size());
+  } else {
+    if (++segs_ > 1) error("multi-segment modelled blocks are outside this build's scope");
+    std::vector<U8> coded;
+    guarded([&] { coded = zpq::encode_payload(header_, 0, 0, pending_.data(), pending_.size()); });
+    size_t pos = 0;
+    while (pos < coded.size()) {
+      const size_t k = std::min<size_t>(coded.size() - pos, 1u << 30);
+      out_->write((const char*)coded.data() + pos, (int)k);
+      pos += k;
+    }
+  }
+  pending_.clear();
+  for (int i = 0; i < 4; ++i) out_->put(0);
+}
+
+void Compressor::endSegment(const char* sha1string) {
+  flush_segment();
+  if (sha1string) { out_->put(253); for (int i = 0; i < 20; ++i) out_->put(sha1string[i]); }
+  else out_->put(254);
+  state_ = BLOCK2;
+}
+
+char* Compressor::endSegmentChecksum(int64_t*, bool) {
+  // verify mode (setVerify) needs the PCOMP interpreter on the host: not in scope
+  flush_segment();
+  out_->put(254);
+  state_ = BLOCK2;
+  return 0;
+}
+
+void Compressor::endBlock() {
+  out_->put(255);
+  state_ = INIT;
+}
+
+}  // namespace libzpaq
