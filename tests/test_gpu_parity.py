@@ -16,7 +16,7 @@ KERNELS = [2, 1]   # wave-parallel, generic one-lane
 
 
 def test_cross_lane_selftest(gpu):
-    assert gpu.selftest()[:5] == [2016, 83640, 123, 2016, 133]
+    assert gpu.selftest()[:5] == [2016, 21344, 123, 2016, 133]
 
 
 def test_native_library_is_the_one_running(gpu):

@@ -147,7 +147,7 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
 // ---------------------------------------------------------------- selftest
 // Checks the cross-lane idioms the wave kernel relies on (DPP reduction,
 // readlane, bpermute shuffles).  out[0]=wave_sum(lane) (2016), out[1]=wave_sum
-// of (lane*lane - 1000) (83640), out[2]=readlane(lane*3, 41) (123),
+// of (lane*lane - 1000) (21344), out[2]=readlane(lane*3, 41) (123),
 // out[3]=sum of __shfl(lane, (lane+5)&63) over lanes (2016), out[4]=wave_sum
 // with only lanes < 19 contributing 7 each (133).
 __global__ void selftest_kernel(int32_t* out) {
