@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the ZPAQ context-mixing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--blocks B --block-bytes S --kind text --method 5]
+
+A "step" = one pass of the hot path (Predictor init + predict/update/encode of
+every bit) over one batch of B synthetic blocks per GPU, inputs already resident
+in HBM.  Default workload = BASELINE.json configs[2]: method "5" over 1024 x
+1 MiB "enwik-style" Zipf text blocks on one MI355X.  N > 1 (launched by
+torch.distributed.run, one rank per GPU): blocks are independent, so each rank
+codes its own B blocks with no data-path collective (weak scaling); ranks only
+barrier and max-reduce the time.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the coding kernel against HBM
+(achieved = algorithmic model-state bytes per launch / kernel time measured with
+hipEvents on the launch stream); `cpu_baseline` times the reference libzpaq
+(oracle/_ref, kind "reference") or, if that was not built, our C oracle (kind
+"port") on a bounded sample of the same blocks on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _gen_block(args):
+    from zpaq_amd import corpus
+    kind, nbytes, seed = args
+    return corpus.block(kind, nbytes, seed)
+
+
+def make_corpus(kind, nblocks, block_bytes, first):
+    """[nblocks, block_bytes] uint8, block b = corpus.block(kind, block_bytes, 12345 + first + b)."""
+    from zpaq_amd import corpus
+    jobs = [(kind, block_bytes, corpus.BASE_SEED + first + b) for b in range(nblocks)]
+    out = np.empty((nblocks, block_bytes), np.uint8)
+    nproc = min(len(jobs), os.cpu_count() or 1, 64)
+    if nproc > 1 and nblocks * block_bytes >= (8 << 20):
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            for b, blk in enumerate(pool.imap(_gen_block, jobs, chunksize=max(1, len(jobs) // (nproc * 4)))):
+                out[b] = blk
+    else:
+        for b, j in enumerate(jobs):
+            out[b] = _gen_block(j)
+    return out
+
+
+def cpu_baseline(blocks, method, budget_s):
+    """Reference libzpaq on this box's host cores over a bounded sample of the same blocks."""
+    from oracle.oracle_py import Oracle, Ref, have_ref, parse_block
+    cores = os.cpu_count() or 1
+    nb, bs = blocks.shape
+    if have_ref():
+        ref = Ref()
+        # calibrate on one block, then size the sample for ~budget_s of wall time on all cores
+        t1, _ = ref.compress_blocks_mt(blocks[:1], method, 1)
+        per_core = max(t1, 1e-3)
+        sample = int(max(1, min(nb, (budget_s / per_core) * cores * 0.8)))
+        threads = min(cores, sample)
+        wall, lens = ref.compress_blocks_mt(blocks[:sample], method, threads)
+        return {"value": sample * bs / 1e6 / wall, "unit": "MB/s", "cores": threads, "kind": "reference",
+                "sample": f"{sample} x {bs} B blocks of the same corpus, libzpaq::compressBlock(\"{method}\") "
+                          f"(JIT build, -O3) from a {threads}-thread work queue; 1 thread: {bs / 1e6 / t1:.3f} MB/s",
+                "single_thread_MBps": bs / 1e6 / t1}, lens
+    # fallback: our scalar C port, single thread, a slice of one block
+    import zpaq_amd as z
+    orc = Oracle()
+    k = min(bs, 200000)
+    h, _, _ = z.method_to_header(z.expand_method(method, blocks[0][:k]))
+    t0 = time.time()
+    orc.encode(h, b"\0" + blocks[0][:k].tobytes())
+    wall = time.time() - t0
+    return {"value": k / 1e6 / wall, "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": f"first {k} B of block 0 through oracle/zpaq_oracle.c (scalar, 1 thread)"}, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU")
+    ap.add_argument("--block-bytes", type=int, default=1 << 20)
+    ap.add_argument("--kind", default="text")
+    ap.add_argument("--method", default="5")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--verify-blocks", type=int, default=4, help="blocks round-tripped through the device decoder")
+    ap.add_argument("--kernel", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import zpaq_amd as z
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    z.init(local)
+    z.set_kernel(a.kernel)
+
+    nb, bs = a.blocks, a.block_bytes
+    blocks = make_corpus(a.kind, nb, bs, first=rank * nb)
+
+    # one plan per distinct header; the headline text corpus has exactly one
+    headers = {}
+    for b in range(nb):
+        h, p, _ = z.method_to_header(z.expand_method(a.method, blocks[b]))
+        assert p == b""
+        headers.setdefault(h, []).append(b)
+    groups = [(z.Plan(h), idx) for h, idx in headers.items()]
+    algo_bytes = sum(pl.algo_bytes_per_byte * len(idx) * (bs + 1) for pl, idx in groups)
+    state_bytes = sum(pl.state_bytes * len(idx) for pl, idx in groups)
+
+    # inputs resident in HBM before the timed region: row b = PP byte 0 | block b
+    stride_in = (bs + 1 + 255) // 256 * 256
+    cap = bs + bs // 4 + 4096
+    stride_out = (cap + 255) // 256 * 256
+    host_in = np.zeros((nb, stride_in), np.uint8)
+    host_in[:, 1:bs + 1] = blocks
+    d_in = torch.from_numpy(host_in).to(dev)
+    d_out = torch.empty((nb, stride_out), dtype=torch.uint8, device=dev)
+    d_res = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
+    L = z.lib()
+
+    def launch(plan, idx, decode=False, src=None, src_len=None, dst=None, dst_cap=None, res=None):
+        n = len(idx)
+        io = (C.c_uint64 * n)(*[int(i) * (stride_out if decode else stride_in) for i in idx])
+        il = (C.c_uint32 * n)(*([bs + 1] * n if src_len is None else src_len))
+        oo = (C.c_uint64 * n)(*[int(i) * (stride_in if decode else stride_out) for i in idx])
+        oc = (C.c_uint32 * n)(*([cap] * n if dst_cap is None else dst_cap))
+        r = res if res is not None else d_res
+        res_ptr = r.data_ptr() + 16 * int(idx[0]) if res is None else r.data_ptr()
+        fn = L.zpq_decode_device if decode else L.zpq_encode_device
+        rc = fn(plan._h, C.c_void_p((src if src is not None else d_in).data_ptr()), io, il, n,
+                C.c_void_p((dst if dst is not None else d_out).data_ptr()), oo, oc, C.c_void_p(res_ptr), None, 1)
+        if rc:
+            raise RuntimeError(L.zpq_last_error().decode())
+        return z.last_timing()
+
+    def step():
+        init_ms = code_ms = 0.0
+        for plan, idx in groups:
+            # blocks of one plan are contiguous runs in practice; launch per contiguous run
+            run = [idx[0]]
+            for i in idx[1:] + [None]:
+                if i is not None and i == run[-1] + 1:
+                    run.append(i)
+                    continue
+                t = launch(plan, run)
+                init_ms += t[0]
+                code_ms += t[1]
+                run = [i]
+        return init_ms, code_ms
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    init_ms = code_ms = 0.0
+    for _ in range(a.steps):
+        i_ms, c_ms = step()
+        init_ms += i_ms
+        code_ms += c_ms
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = d_res.cpu().numpy()
+    out_len, status = res[:, 0].astype(np.int64), res[:, 2]
+    ok = bool((status == 0).all())
+    coded_total = int(out_len.sum())
+
+    # product-path self check: round-trip a few blocks through the device decoder
+    verified = 0
+    nv = min(a.verify_blocks, nb)
+    if ok and nv:
+        for plan, idx in groups:
+            vi = [i for i in idx if i < nv]
+            if not vi or vi != list(range(vi[0], vi[0] + len(vi))):
+                continue
+            coded = d_out[vi[0]:vi[0] + len(vi)].clone()
+            lens = [int(out_len[i]) for i in vi]
+            for k, ln in enumerate(lens):           # append the 4-zero terminator the container adds
+                coded[k, ln:ln + 4] = 0
+            back = torch.empty((len(vi), stride_in), dtype=torch.uint8, device=dev)
+            r2 = torch.zeros((len(vi), 4), dtype=torch.int32, device=dev)
+            n = len(vi)
+            io = (C.c_uint64 * n)(*[k * stride_out for k in range(n)])
+            il = (C.c_uint32 * n)(*[ln + 4 for ln in lens])
+            oo = (C.c_uint64 * n)(*[k * stride_in for k in range(n)])
+            oc = (C.c_uint32 * n)(*[bs + 8] * n)
+            rc = L.zpq_decode_device(plan._h, C.c_void_p(coded.data_ptr()), io, il, n, C.c_void_p(back.data_ptr()),
+                                     oo, oc, C.c_void_p(r2.data_ptr()), None, 0)
+            torch.cuda.synchronize()
+            if rc:
+                raise RuntimeError(L.zpq_last_error().decode())
+            r2h = r2.cpu().numpy()
+            for k, i in enumerate(vi):
+                good = r2h[k, 2] == 0 and r2h[k, 0] == bs + 1 and bool((back[k, :bs + 1] == d_in[i, :bs + 1]).all())
+                verified += int(good)
+                ok = ok and good
+
+    total_bytes = float(nb) * bs * world * a.steps
+    value = total_bytes / 1e6 / elapsed
+    code_s = code_ms / 1e3 / max(a.steps, 1)          # coding-kernel time per step (this rank)
+    achieved = algo_bytes / 1e9 / code_s if code_s > 0 else 0.0
+    line = {
+        "metric": "compress MB/s + bit-identical ratio, -m5 over 1024x1 MiB blocks",
+        "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": f"method \"{a.method}\" x {nb} blocks x {bs} B '{a.kind}' per GPU "
+                               f"(BASELINE configs[2] when 1024 x 1 MiB text)",
+                   "blocks_per_gpu": nb, "block_bytes": bs, "corpus": a.kind, "method": a.method,
+                   "plans": len(groups), "ncomp": [g[0].ncomp for g in groups], "parallelism": f"blocks/{world}gpu",
+                   "state_GiB_per_gpu": state_bytes / 2 ** 30},
+        "ratio": coded_total / (float(nb) * bs) if nb else None,
+        "all_status_ok": ok, "roundtrip_verified_blocks": verified,
+        "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "code_wave_kernel<encode>" if a.kernel != 1 else "code_serial_kernel<encode>",
+                     "algo_bytes_per_launch": algo_bytes},
+    }
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        base, ref_lens = cpu_baseline(blocks, a.method, a.cpu_seconds)
+        line["cpu_baseline"] = base
+        if ref_lens is not None:
+            # archive length = prologue + coded + 4 + 21 + 1; prologue is identical, so lengths must agree
+            from oracle.oracle_py import Ref, parse_block
+            k = len(ref_lens)
+            ref = Ref()
+            a0 = ref.compress_block(blocks[0], a.method)
+            overhead = parse_block(a0)["payload_start"] + 4 + 21 + 1
+            same = all(int(ref_lens[i]) == int(out_len[i]) + overhead for i in range(k))
+            ps = parse_block(a0)["payload_start"]
+            ours0 = d_out[0, :int(out_len[0])].cpu().numpy().tobytes()
+            same = same and a0[ps:ps + len(ours0)] == ours0
+            line["cpu_baseline"]["bit_identical_vs_reference"] = bool(same)
+            line["cpu_baseline"]["compared_blocks"] = k
+        line["vs_cpu"] = value / base["value"] if base["value"] else None
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

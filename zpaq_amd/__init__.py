@@ -39,7 +39,8 @@ class ZpaqError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIBNAME)
+    # ZPAQ_AMD_LIB selects an alternative in-tree build (e.g. the cycle-profiling variant)
+    return os.path.join(_HERE, os.environ.get("ZPAQ_AMD_LIB", _LIBNAME))
 
 
 _lib = None

@@ -420,11 +420,22 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
   uint32_t steps = 0;
   int status = 0;
 
+#ifdef ZPQ_PROF
+  unsigned long long prof[5] = {0, 0, 0, 0, 0};   // phase1, phase2, update, vm, total
+  const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#define PROF_BEGIN unsigned long long pt_ = __builtin_readcyclecounter();
+#define PROF_END(k) prof[k] += __builtin_readcyclecounter() - pt_;
+#else
+#define PROF_BEGIN
+#define PROF_END(k)
+#endif
   auto bit_step_post = [&](int y) -> int {   // update + c8/hmap4 bookkeeping (libzpaq.cpp:2055-2065)
-    wave_update(m, s, y);
+    { PROF_BEGIN wave_update(m, s, y); PROF_END(2) }
     m.c8 += m.c8 + y;
     if (m.c8 >= 256) {
+      PROF_BEGIN
       const int e = wvm_run(vm, (uint32_t)(m.c8 - 256));
+      PROF_END(3)
       if (e) return e;
       m.hmap4 = 1;
       m.c8 = 1;
@@ -437,8 +448,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
     return 0;
   };
   auto predict = [&]() -> uint32_t {
-    wave_predict_phase1(m, s);
-    wave_predict_phase2(m, s);
+    { PROF_BEGIN wave_predict_phase1(m, s); PROF_END(0) }
+    { PROF_BEGIN wave_predict_phase2(m, s); PROF_END(1) }
     return uni((uint32_t)L.squash[rl(s.p, m.n - 1) + 2048]);
   };
 
@@ -510,6 +521,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
     if (lane == 0) { res[b].out_len = n; res[b].consumed = eos ? rp : 0; }
   }
   if (lane == 0) { res[b].status = status; res[b].steps = steps; }
+#ifdef ZPQ_PROF
+  if (lane == 0 && b == 0) {
+    prof[4] = __builtin_readcyclecounter() - prof_t0;
+    printf("[zpq prof] block 0: steps=%u cycles/bit: phase1=%.0f phase2=%.0f update=%.0f vm=%.0f total=%.0f\n", steps,
+           (double)prof[0] / steps, (double)prof[1] / steps, (double)prof[2] / steps, (double)prof[3] / steps,
+           (double)prof[4] / steps);
+  }
+#endif
 }
 
 }  // namespace zpq
