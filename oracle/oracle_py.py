@@ -65,7 +65,7 @@ class Ref:
         L.ref_block_memory.argtypes = [_u8p, C.c_size_t]
         L.ref_compress_blocks_mt.restype = C.c_double
         L.ref_compress_blocks_mt.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_char_p, C.c_int,
-                                             C.POINTER(C.c_longlong), _u8p, C.c_size_t]
+                                             C.POINTER(C.c_longlong), _u8p, C.c_size_t, C.c_double]
 
     def _err(self):
         return RuntimeError(self.lib.ref_last_error().decode("latin1"))
@@ -149,13 +149,14 @@ class Ref:
         a = _bytes_arr(archive)
         return float(self.lib.ref_block_memory(_ptr(a), a.size))
 
-    def compress_blocks_mt(self, blocks: np.ndarray, method, nthreads: int):
-        """blocks [nblocks, block_bytes] uint8 -> (wall seconds, archive sizes)."""
+    def compress_blocks_mt(self, blocks: np.ndarray, method, nthreads: int, deadline_s: float = 0.0):
+        """blocks [nblocks, block_bytes] uint8 -> (wall seconds, archive sizes; -2 = not started
+        because deadline_s had passed)."""
         blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
         nb, bs = blocks.shape
         lens = (C.c_longlong * nb)()
         s = self.lib.ref_compress_blocks_mt(_ptr(blocks), bs, nb, self._s(method), int(nthreads),
-                                            lens, None, 0)
+                                            lens, None, 0, float(deadline_s))
         if s < 0:
             raise self._err()
         return s, list(lens)

@@ -190,15 +190,20 @@ double ref_block_memory(const unsigned char* archive, size_t n) {
 // work queue, like zpaq.cpp:1918-1965 does.  Returns wall seconds; out_len[b]
 // gets each archive's size.  Outputs themselves are discarded unless out!=0
 // (then block b is written at out + b*out_stride).
+// deadline_s > 0: no new block is started after that many seconds (blocks not
+// started keep out_len[b] = -2), so the call is bounded by deadline + one block.
 double ref_compress_blocks_mt(const unsigned char* in, size_t block_bytes, int nblocks,
                               const char* method, int nthreads, long long* out_len,
-                              unsigned char* out, size_t out_stride) {
+                              unsigned char* out, size_t out_stride, double deadline_s) {
   std::atomic<int> next(0);
   std::atomic<int> failed(0);
   auto t0 = std::chrono::steady_clock::now();
+  if (out_len) for (int b = 0; b < nblocks; ++b) out_len[b] = -2;
   auto work = [&]() {
     std::vector<unsigned char> tmp;
     for (;;) {
+      if (deadline_s > 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) break;
       int b = next.fetch_add(1);
       if (b >= nblocks) break;
       unsigned char* dst; size_t cap;
