@@ -52,8 +52,9 @@ void zpq_shutdown(void);
 /* Cap on device bytes the engine may hold for model state (default: 85% of
  * free HBM at init).  Batches needing more are run in several residency waves. */
 int zpq_set_state_budget(uint64_t bytes);
-/* Select the coding kernel: 0 = auto (wave-parallel when the plan allows it),
- * 1 = force the one-lane generic kernel, 2 = force wave-parallel. */
+/* Select the coding kernel: 0 = auto (best available for each plan),
+ * 1 = generic one-lane kernel, 2 = generic wave-parallel kernel, 3 = per-header
+ * specialised kernel (fails with ZPQ_E_UNSUPPORTED when it cannot be built). */
 int zpq_set_kernel(int which);
 
 /* ---- model plan: a parsed block header + device arena layout ---- */
@@ -71,6 +72,21 @@ uint64_t zpq_plan_state_bytes(const zpq_plan*);
 /* ALGORITHMIC model-state bytes moved per coded input byte,
  * excluding init and I/O: the roofline numerator. */
 double zpq_plan_algo_bytes_per_byte(const zpq_plan*);
+
+/* Per-header kernel specialisation (the GPU analogue of the reference's x86
+ * JIT, libzpaq.cpp:3824-4583 / 3231-3811): HIP source generated for this
+ * header, instantiating device/spec_kernel.h.  zpq_plan_spec_source returns the
+ * text and its cache key (40 hex chars + NUL) so that a build step can
+ * precompile it to <cache dir>/<key>.hsaco; at run time the engine loads that
+ * file or falls back to hipRTC.  Needs no GPU. */
+int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
+/* Which kernel will code this plan on the current device: 3 specialised,
+ * 2 generic wave, 1 generic one-lane.  note (optional) receives where the
+ * specialised kernel came from ("cache:<key>" / "hiprtc") or why it is not used. */
+int zpq_plan_kernel_kind(zpq_plan*, char* note, size_t cap);
+/* Directories used by the specialisation cache / hipRTC include path. */
+const char* zpq_spec_cache_dir(void);
+const char* zpq_spec_include_dir(void);
 
 /* ---- the hot path: batches of independent blocks ---- */
 /* Encoder::compress over in[b][0..in_len[b]) then EOS, for every block

@@ -12,7 +12,8 @@ from zpaq_amd import corpus
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [2, 1]   # wave-parallel, generic one-lane
+KERNELS = [3, 2, 1]   # per-header specialised, generic wave-parallel, generic one-lane
+SIZE_LIMIT = {3: 262144, 2: 20000, 1: 2000}   # the generic kernels are fallbacks: keep their cases short
 
 
 def test_cross_lane_selftest(gpu):
@@ -29,9 +30,8 @@ def test_encode_matches_oracle_and_golden(gpu, oracle, golden, kernel):
     """zpq_encode_batch over every small golden case: coded stream == oracle == reference archive slice."""
     gpu.set_kernel(kernel)
     try:
-        entries = [e for e in golden["method_cases"] if e["n"] <= 65536 and bytes.fromhex(e["header"])[6]]
-        if kernel == 1:
-            entries = [e for e in entries if e["n"] <= 20000]
+        entries = [e for e in golden["method_cases"]
+                   if e["n"] <= min(65536, SIZE_LIMIT[kernel]) and bytes.fromhex(e["header"])[6]]
         plans, inputs = [], []
         cache = {}
         for e in entries:
@@ -57,7 +57,7 @@ def test_compress_blocks_bit_identical_archives(gpu, golden, kernel):
     """Batched compressBlock: whole archives (tag .. 255) hash-identical to the reference's."""
     gpu.set_kernel(kernel)
     try:
-        lim = 262144 if kernel == 2 else 20000
+        lim = SIZE_LIMIT[kernel]
         by_method = {}
         for e in golden["method_cases"]:
             if e["n"] <= lim:
@@ -93,6 +93,8 @@ def test_all_nine_component_types(gpu, oracle, golden, kernel):
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_legacy_min_mid_max_models(gpu, golden, kernel, idx):
     """BASELINE.json names mid.cfg / max.cfg: the built-in chains, encode + decode, from reference archives."""
+    if kernel == 1 and idx != 1:
+        pytest.skip("one-lane fallback kernel: one legacy model is enough")
     gpu.set_kernel(kernel)
     try:
         e = golden["level_cases"][idx]
@@ -118,6 +120,25 @@ def test_decode_reference_archives(gpu, golden, kernel):
         assert gpu.decompress(stream) == want
     finally:
         gpu.set_kernel(0)
+
+
+def test_specialised_kernel_is_the_one_running(gpu, golden):
+    """Standard chains come from the in-tree code-object cache; data-dependent ones through hipRTC."""
+    import ctypes as C
+    L = gpu.lib()
+    note = C.create_string_buffer(4096)
+    d = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h, _, _ = gpu.method_to_header(gpu.expand_method("5", d))
+    plan = gpu.Plan(h)
+    assert L.zpq_plan_kernel_kind(plan._h, note, 4096) == 3, note.value
+    assert note.value.startswith(b"cache:"), note.value
+    d = corpus.block("records", 30000, 77)          # period detection -> a chain nobody prebuilt
+    h2, _, _ = gpu.method_to_header(gpu.expand_method("5", d))
+    assert h2 != h
+    plan2 = gpu.Plan(h2)
+    kind = L.zpq_plan_kernel_kind(plan2._h, note, 4096)
+    assert kind == 3, note.value
+    assert note.value.startswith(b"hiprtc") or note.value.startswith(b"cache:")
 
 
 def test_decoder_status_codes(gpu, golden):

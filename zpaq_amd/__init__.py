@@ -118,7 +118,7 @@ def shutdown():
 
 
 def set_kernel(which: int):
-    """0 auto, 1 generic one-lane kernel, 2 wave-parallel kernel."""
+    """0 auto, 1 generic one-lane kernel, 2 generic wave-parallel kernel, 3 per-header specialised kernel."""
     _check(lib().zpq_set_kernel(int(which)))
 
 

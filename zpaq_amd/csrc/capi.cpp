@@ -6,6 +6,7 @@
 
 #include "device/engine.hpp"
 #include "device/plan.hpp"
+#include "device/spec_loader.hpp"
 #include "host/common.hpp"
 #include "host/blocks.hpp"
 #include "host/container.hpp"
@@ -33,7 +34,7 @@ int zpq_init(int device) { ZPQ_TRY engine_init(device); return ZPQ_OK; ZPQ_CATCH
 int zpq_device_count(void) { return engine_device_count(); }
 void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
 int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
-int zpq_set_kernel(int which) { if (which < 0 || which > 2) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
+int zpq_set_kernel(int which) { if (which < 0 || which > 3) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
 
 int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out) {
   ZPQ_TRY
@@ -47,6 +48,32 @@ int zpq_plan_ncomp(const zpq_plan* p) { return p ? (int)p->hdr().n : 0; }
 double zpq_plan_memory(const zpq_plan* p) { return p ? p->memory : 0; }
 uint64_t zpq_plan_state_bytes(const zpq_plan* p) { return p ? p->hdr().arena_bytes : 0; }
 double zpq_plan_algo_bytes_per_byte(const zpq_plan* p) { return p ? p->algo_bytes : 0; }
+
+int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, char key41[41]) {
+  ZPQ_TRY
+  if (!p) fail(ZPQ_E_ARG, "null plan");
+  std::string source, key, why;
+  if (!spec_source_and_key(*p, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (len) *len = source.size();
+  if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
+  if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
+  memcpy(src, source.c_str(), source.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) {
+  try {
+    std::string n;
+    const int k = engine_plan_kernel_kind(p, n);
+    if (note && cap) { strncpy(note, n.c_str(), cap - 1); note[cap - 1] = 0; }
+    return k;
+  } catch (const Failure& f) { set_last_error(f.what()); return -f.code; }
+  catch (const std::exception& ex) { set_last_error(ex.what()); return -ZPQ_E_DEVICE; }
+}
+
+const char* zpq_spec_cache_dir(void) { static std::string s; s = spec_cache_dir(); return s.c_str(); }
+const char* zpq_spec_include_dir(void) { static std::string s; s = spec_include_dir(); return s.c_str(); }
 
 int zpq_encode_batch(const zpq_plan* const* plans, const uint8_t* const* in, const uint32_t* in_len,
                      uint32_t nblocks, uint8_t* const* out, const uint32_t* out_cap, uint32_t* out_len,

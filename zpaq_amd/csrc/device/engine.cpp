@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "kernels.h"
+#include "spec_loader.hpp"
 
 namespace zpq {
 
@@ -47,6 +48,7 @@ struct Engine {
   int kernel_choice = 0;
   DevBuf arena, io_in, io_out, jobs, results;
   Timing last{};
+  int last_kind = 0;
 };
 
 Engine& eng() {
@@ -141,24 +143,52 @@ static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
 
 void engine_plan_release(zpq_plan* p) {
   if (p && p->d_blob) { (void)hipFree(p->d_blob); p->d_blob = nullptr; }
+  spec_kernel_release(p);
 }
 
-static bool use_wave(const Engine& e, const zpq_plan* plan) {
-  if (e.kernel_choice == 1) return false;
+// Which kernel codes a plan: 3 = per-header specialised kernel, 2 = generic
+// wave kernel, 1 = generic one-lane kernel.  kernel_choice 0 picks the best
+// available; 1/2/3 force one (3 fails loudly if specialisation is unavailable).
+static int kernel_kind(Engine& e, const zpq_plan* plan) {
+  zpq_plan* p = const_cast<zpq_plan*>(plan);
+  const int want = e.kernel_choice;
+  if (want == 1) return 1;
   if (!plan->hdr().wave_ok) {
-    if (e.kernel_choice == 2) fail(ZPQ_E_UNSUPPORTED, "wave kernel forced but plan has more than 64 components");
-    return false;
+    if (want >= 2) fail(ZPQ_E_UNSUPPORTED, "wave kernels need n <= 64 components");
+    return 1;
   }
-  return true;
+  if (want == 2) return 2;
+  if (spec_kernel_for(p)) return 3;
+  if (want == 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
+  return 2;
 }
 
-// Launch init + coding kernels for jobs already resident on the device.
-// `order` lists job indices: first the wave-kernel jobs, then the serial ones.
-static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t n_wave,
-                       uint32_t n_serial, uint64_t max_arena, hipStream_t st, bool timed) {
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note) {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  HIP_CHECK(hipSetDevice(e.device));
+  const int k = kernel_kind(e, p);
+  note = p->spec_note;
+  return k;
+}
+
+struct LaunchGroup { int kind; SpecKernel* spec; uint32_t first, count; };
+
+static hipError_t launch_spec(SpecKernel* k, bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t n,
+                              const DeviceTables* d_tb, hipStream_t st) {
+  void* args[4] = {(void*)&d_jobs, (void*)&d_res, (void*)&n, (void*)&d_tb};
+  const uint32_t wg = (n + 3) / 4;
+  return hipModuleLaunchKernel(decode ? k->decode : k->encode, wg, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+}
+
+// Launch init + coding kernels for jobs already resident on the device, grouped
+// so that each group is one launch.
+static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res,
+                       const std::vector<LaunchGroup>& groups, uint32_t nb, uint64_t max_arena, hipStream_t st,
+                       bool timed) {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (timed) for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
-  const uint32_t nb = n_wave + n_serial;
   // enough 256-thread groups per block to stream the arena at HBM rate
   uint64_t per = max_arena / (256 * 16 * 8) + 1;
   uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), 64);
@@ -167,8 +197,11 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
   HIP_CHECK(launch_init_arena(d_jobs, nb, e.d_tables, chunks, st));
   if (timed) HIP_CHECK(hipEventRecord(ev[1], st));
   if (timed) HIP_CHECK(hipEventRecord(ev[2], st));
-  if (n_wave) HIP_CHECK(launch_code_wave(decode, d_jobs, d_res, n_wave, e.d_tables, st));
-  if (n_serial) HIP_CHECK(launch_code_serial(decode, d_jobs + n_wave, d_res + n_wave, n_serial, e.d_tables, st));
+  for (const LaunchGroup& g : groups) {
+    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
+    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
+    else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
+  }
   if (timed) {
     HIP_CHECK(hipEventRecord(ev[3], st));
     HIP_CHECK(hipEventSynchronize(ev[3]));
@@ -212,12 +245,25 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     e.io_out.ensure(out_bytes + 64);
     e.jobs.ensure(cnt * sizeof(BlockJob));
     e.results.ensure(cnt * sizeof(BlockResult));
-    // order: wave-kernel jobs first
+    // order jobs so that every (kernel kind, plan) group is one contiguous launch
     std::vector<size_t> order;
     order.reserve(cnt);
-    for (size_t i = pos; i < end; ++i) if (use_wave(e, blocks[i].plan)) order.push_back(i);
-    const uint32_t n_wave = (uint32_t)order.size();
-    for (size_t i = pos; i < end; ++i) if (!use_wave(e, blocks[i].plan)) order.push_back(i);
+    for (size_t i = pos; i < end; ++i) order.push_back(i);
+    std::vector<int> kind_of(nb, 0);
+    for (size_t i = pos; i < end; ++i) kind_of[i] = kernel_kind(e, blocks[i].plan);
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+      if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
+      if (kind_of[x] == 3) return blocks[x].plan < blocks[y].plan;
+      return false;
+    });
+    std::vector<LaunchGroup> groups;
+    for (size_t k = 0; k < cnt; ++k) {
+      const zpq_plan* pl = blocks[order[k]].plan;
+      const int kd = kind_of[order[k]];
+      SpecKernel* sk = kd == 3 ? (SpecKernel*)pl->spec : nullptr;
+      if (!groups.empty() && groups.back().kind == kd && groups.back().spec == sk) ++groups.back().count;
+      else groups.push_back(LaunchGroup{kd, sk, (uint32_t)k, 1});
+    }
     std::vector<BlockJob> jobs(cnt);
     std::vector<uint8_t> stage(in_bytes + 64);
     std::vector<uint64_t> out_off(cnt);
@@ -242,8 +288,8 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
     HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
     Timing before = e.last;
-    launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, n_wave, (uint32_t)cnt - n_wave,
-               max_arena, e.stream, true);
+    launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
+               e.stream, true);
     e.last.init_ms += before.init_ms;
     e.last.code_ms += before.code_ms;
     e.last.blocks += before.blocks;
@@ -289,9 +335,11 @@ void engine_code_device(bool decode, const zpq_plan* plan, const void* d_in, con
   }
   HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), (size_t)nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));   // jobs vector goes out of scope below
-  const bool wave = use_wave(e, plan);
+  const int kd = kernel_kind(e, plan);
+  std::vector<LaunchGroup> groups(1, LaunchGroup{kd, kd == 3 ? (SpecKernel*)plan->spec : nullptr, 0, nblocks});
   e.last = Timing{};
-  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, wave ? nblocks : 0, wave ? 0 : nblocks, a, st, timed);
+  e.last_kind = kd;
+  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, a, st, timed);
 }
 
 int engine_selftest(int32_t out[8]) {

@@ -9,7 +9,9 @@
 // The plan (parsed header) is immutable and shared by all blocks coded with the
 // same header; it lives in its own small device buffer.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace zpq {
 
@@ -90,6 +92,11 @@ struct DeviceTables {
   uint32_t isse_init[512];
   uint32_t sse_row[32];
 };
+
+// LDS plan of the specialised kernel (spec_kernel.h), known to the host code
+// generator: shared constant tables, then one region per wave (block).
+static const int kSpecTablesBytes = 32768 + 2688 + 4096 + 512 + 1024;                       // 41088
+static const int kSpecWaveLdsBytes = (((163840 - 256) - kSpecTablesBytes) / 4) & ~15;        // 30624
 
 // Cap on HCOMP instructions per input byte: the reference has no limit (a
 // hostile header can loop forever); a device kernel must not hang.

@@ -1,4 +1,5 @@
 #pragma once
+#include <string>
 #include <vector>
 
 #include "../host/common.hpp"
@@ -11,6 +12,9 @@ struct zpq_plan {
   double algo_bytes = 0;
   void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
   int d_device = -1;
+  void* spec = nullptr;            // SpecKernel* (device/spec_loader.hpp)
+  int spec_state = 0;              // 0 not tried, 1 loaded, -1 unavailable
+  std::string spec_note;           // where the kernel came from / why it is unavailable
   const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
   const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }
 };

@@ -1,0 +1,150 @@
+// Loads (or JIT-compiles) the per-header specialised kernels.
+#include "spec_loader.hpp"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <vector>
+
+#include "../host/codegen.hpp"
+
+namespace zpq {
+
+namespace {
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr((const void*)&spec_kernel_for, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    if (k != std::string::npos) return p.substr(0, k);
+  }
+  return ".";
+}
+
+bool read_file(const std::string& path, std::string& out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  out = ss.str();
+  return true;
+}
+
+std::string hex20(const U8* d) {
+  char hex[41];
+  for (int i = 0; i < 20; ++i) snprintf(hex + 2 * i, 3, "%02x", d[i]);
+  return std::string(hex, 40);
+}
+
+}  // namespace
+
+std::string spec_include_dir() {
+  if (const char* e = getenv("ZPAQ_AMD_DEVICE_INCLUDE")) return e;
+  return lib_dir() + "/csrc/device";
+}
+std::string spec_cache_dir() {
+  if (const char* e = getenv("ZPAQ_AMD_SPEC_CACHE")) return e;
+  return lib_dir() + "/spec_cache";
+}
+
+bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_spec_source(plan, source, why_not)) return false;
+  std::string h1, h2;
+  const std::string inc = spec_include_dir();
+  if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2)) {
+    why_not = "kernel template headers not found under " + inc;
+    return false;
+  }
+  Sha1 s;
+  s.update(source.data(), source.size());
+  s.update(h1.data(), h1.size());
+  s.update(h2.data(), h2.size());
+  key = hex20(s.result());
+  return true;
+}
+
+static bool compile_hiprtc(const std::string& source, std::vector<char>& code, std::string& log) {
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "zpq_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    log = "hiprtcCreateProgram failed";
+    return false;
+  }
+  const std::string inc = "-I" + spec_include_dir();
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), "-Wno-unused-label"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  size_t ls = 0;
+  if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+    log.resize(ls);
+    hiprtcGetProgramLog(prog, &log[0]);
+  }
+  if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); return false; }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code.resize(cs);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return true;
+}
+
+SpecKernel* spec_kernel_for(zpq_plan* plan) {
+  if (plan->spec_state > 0) return (SpecKernel*)plan->spec;
+  if (plan->spec_state < 0) return nullptr;
+  plan->spec_state = -1;
+  if (getenv("ZPAQ_AMD_NO_SPEC")) { plan->spec_note = "disabled by ZPAQ_AMD_NO_SPEC"; return nullptr; }
+  std::string source, key, why;
+  if (!spec_source_and_key(*plan, source, key, why)) { plan->spec_note = why; return nullptr; }
+  std::vector<char> code;
+  std::string origin;
+  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
+  std::string blob;
+  if (read_file(path, blob) && !blob.empty()) {
+    code.assign(blob.begin(), blob.end());
+    origin = "cache:" + key;
+  } else {
+    std::string log;
+    if (!compile_hiprtc(source, code, log)) {
+      plan->spec_note = "hipRTC compile failed: " + log.substr(0, 2000);
+      return nullptr;
+    }
+    origin = "hiprtc";
+    ::mkdir(spec_cache_dir().c_str(), 0755);
+    std::ofstream f(path + ".tmp", std::ios::binary);
+    if (f) {
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      ::rename((path + ".tmp").c_str(), path.c_str());
+    }
+  }
+  SpecKernel* k = new SpecKernel;
+  if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&k->encode, k->module, "zpq_spec_encode") != hipSuccess ||
+      hipModuleGetFunction(&k->decode, k->module, "zpq_spec_decode") != hipSuccess) {
+    plan->spec_note = "hipModuleLoadData failed for " + origin;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    return nullptr;
+  }
+  k->origin = origin;
+  plan->spec = k;
+  plan->spec_state = 1;
+  plan->spec_note = origin;
+  return k;
+}
+
+void spec_kernel_release(zpq_plan* plan) {
+  if (plan && plan->spec) {
+    SpecKernel* k = (SpecKernel*)plan->spec;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    plan->spec = nullptr;
+    plan->spec_state = 0;
+  }
+}
+
+}  // namespace zpq

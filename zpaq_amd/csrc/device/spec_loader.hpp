@@ -1,0 +1,30 @@
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+
+#include "plan.hpp"
+
+namespace zpq {
+
+struct SpecKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t encode = nullptr;
+  hipFunction_t decode = nullptr;
+  std::string origin;   // "cache:<file>" or "hiprtc"
+};
+
+// The specialised kernel of `plan` for the current device, or nullptr when it
+// is not available (then plan->spec_note says why and the generic kernels run).
+// Looks in the in-tree cache (zpaq_amd/spec_cache/<key>.hsaco, filled by
+// zpaq_amd/prebuild.py at build time), else compiles with hipRTC and stores the
+// code object back into the cache directory when that is writable.
+SpecKernel* spec_kernel_for(zpq_plan* plan);
+void spec_kernel_release(zpq_plan* plan);
+
+// Source text + cache key (with the template-header digest) for prebuilding.
+bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
+std::string spec_include_dir();
+std::string spec_cache_dir();
+
+}  // namespace zpq

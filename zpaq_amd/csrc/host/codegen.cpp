@@ -1,0 +1,224 @@
+// Per-header kernel specialisation: header -> HIP source for gfx950.
+//
+// The reference speeds its CPU path up by JIT-compiling predict/update and the
+// HCOMP program to x86 per block header (libzpaq.cpp:3824-4583, 3231-3811).  The
+// MI355X analogue: emit a tiny translation unit that (a) pins the COMP list as
+// constexpr data for the hand-written kernel template in device/spec_kernel.h
+// and (b) translates the HCOMP bytecode to straight-line C++
+// with gotos.  The text is compiled ahead of time for the standard method
+// chains (zpaq_amd/prebuild.py -> zpaq_amd/spec_cache/*.hsaco) or at run time
+// through hipRTC (device/spec_loader.cpp).
+#include "codegen.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <sstream>
+
+namespace zpq {
+
+namespace {
+
+struct Insn { int pc, len, op; };
+
+// operand expression (read)
+std::string src_expr(int k, int imm) {
+  switch (k) {
+    case 0: return "a";
+    case 1: return "b";
+    case 2: return "c";
+    case 3: return "d";
+    case 4: return "(unsigned)M[b & MMASK]";
+    case 5: return "(unsigned)M[c & MMASK]";
+    case 6: return "H[d & HMASK]";
+    default: return std::to_string(imm) + "u";
+  }
+}
+// assignment to operand g of expression e
+std::string dst_stmt(int g, const std::string& e) {
+  switch (g) {
+    case 0: return "a = " + e + ";";
+    case 1: return "b = " + e + ";";
+    case 2: return "c = " + e + ";";
+    case 3: return "d = " + e + ";";
+    case 4: return "M[b & MMASK] = (unsigned char)(" + e + ");";
+    case 5: return "M[c & MMASK] = (unsigned char)(" + e + ");";
+    default: return "H[d & HMASK] = " + e + ";";
+  }
+}
+
+// Translates the HCOMP program; returns false if it cannot be compiled
+// statically (then the generic interpreter kernel is used instead).
+bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
+  std::map<int, Insn> insns;
+  std::vector<int> work(1, 0);
+  std::set<int> bad;    // pcs where execution is an error
+  auto decode_len = [&](int pc) -> int {
+    const int op = prog[pc];
+    if (op == 255) return 3;
+    return (op & 7) == 7 ? 2 : 1;
+  };
+  while (!work.empty()) {
+    const int pc = work.back();
+    work.pop_back();
+    if (insns.count(pc) || bad.count(pc)) continue;
+    if (pc < 0 || pc >= len) { bad.insert(pc); continue; }
+    const int op = prog[pc];
+    const int l = decode_len(pc);
+    if (pc + l > len) { bad.insert(pc); continue; }
+    insns[pc] = Insn{pc, l, op};
+    if (insns.size() > 20000) return false;
+    const int imm = l >= 2 ? prog[pc + 1] : 0;
+    if (op == 56) continue;                                            // HALT
+    if (op == 63) { work.push_back(pc + 2 + (int)(int8_t)imm); continue; }   // JMP
+    if (op == 39 || op == 47) work.push_back(pc + 2 + (int)(int8_t)imm);      // JT / JF
+    if (op == 255) { work.push_back(prog[pc + 1] + 256 * prog[pc + 2]); continue; }
+    work.push_back(pc + l);
+  }
+  out << "  template <class MP, class HP, class RP>\n"
+         "  static __device__ __forceinline__ int hcomp(unsigned input, unsigned& rb, unsigned& rc, unsigned& rd,\n"
+         "                                              unsigned& rf, MP M, HP H, RP R) {\n"
+         "    unsigned a = input, b = rb, c = rc, d = rd, f = rf;\n"
+         "    unsigned budget = " << kMaxVmSteps << "u;\n"
+         "    (void)R; (void)budget;\n"
+         "    goto L0;\n";
+  auto label = [&](int pc) -> std::string {
+    if (insns.count(pc)) return "L" + std::to_string(pc);
+    return "Lerr";
+  };
+  for (auto it = insns.begin(); it != insns.end(); ++it) {
+    const Insn& in = it->second;
+    const int pc = in.pc, op = in.op, g = op >> 3, k = op & 7;
+    const int imm = in.len >= 2 ? prog[pc + 1] : 0;
+    const int next = pc + in.len;
+    std::string st;
+    bool falls = true;
+    auto jump = [&](int target, const std::string& cond) {
+      std::string s = cond.empty() ? "" : "if (" + cond + ") ";
+      if (target <= pc) s += "{ if (--budget == 0u) goto Lerr; goto " + label(target) + "; }";
+      else s += "goto " + label(target) + ";";
+      return s;
+    };
+    if (op < 64) {
+      if (g == 7) {
+        if (op == 56) { st = "goto Lhalt;"; falls = false; }
+        else if (op == 57) st = ";";
+        else if (op == 59) st = "a = (a + (unsigned)M[b & MMASK] + 512u) * 773u;";
+        else if (op == 60) st = "H[d & HMASK] = (H[d & HMASK] + a + 512u) * 773u;";
+        else if (op == 63) { st = jump(pc + 2 + (int)(int8_t)imm, ""); falls = false; }
+        else { st = "goto Lerr;"; falls = false; }
+      } else if (k == 7) {
+        if (g < 4) st = dst_stmt(g, "R[" + std::to_string(imm) + "]");
+        else if (g == 4) st = jump(pc + 2 + (int)(int8_t)imm, "f");
+        else if (g == 5) st = jump(pc + 2 + (int)(int8_t)imm, "!f");
+        else st = "R[" + std::to_string(imm) + "] = a;";
+      } else if (op == 0 || k > 4) { st = "goto Lerr;"; falls = false; }
+      else if (k == 0) {
+        if (g == 4 || g == 5) {
+          const std::string m = g == 4 ? "M[b & MMASK]" : "M[c & MMASK]";
+          st = "{ const unsigned x = " + m + "; " + m + " = (unsigned char)a; a = (a & 0xFFFFFF00u) | x; }";
+        } else st = "{ const unsigned x = " + src_expr(g, 0) + "; " + dst_stmt(g, "a") + " a = x; }";
+      } else if (k == 1) st = dst_stmt(g, src_expr(g, 0) + " + 1u");
+      else if (k == 2) st = dst_stmt(g, src_expr(g, 0) + " - 1u");
+      else if (k == 3) st = dst_stmt(g, "~" + src_expr(g, 0));
+      else st = dst_stmt(g, "0u");
+    } else if (op < 120) {
+      st = dst_stmt(g - 8, src_expr(k, imm));
+    } else if (op < 128) { st = "goto Lerr;"; falls = false; }
+    else if (op < 240) {
+      const std::string v = src_expr(k, imm);
+      switch (g - 16) {
+        case 0: st = "a += " + v + ";"; break;
+        case 1: st = "a -= " + v + ";"; break;
+        case 2: st = "a *= " + v + ";"; break;
+        case 3: st = "{ const unsigned x = " + v + "; a = x ? a / x : 0u; }"; break;
+        case 4: st = "{ const unsigned x = " + v + "; a = x ? a % x : 0u; }"; break;
+        case 5: st = "a &= " + v + ";"; break;
+        case 6: st = "a &= ~(" + v + ");"; break;
+        case 7: st = "a |= " + v + ";"; break;
+        case 8: st = "a ^= " + v + ";"; break;
+        case 9: st = "a <<= ((" + v + ") & 31u);"; break;
+        case 10: st = "a >>= ((" + v + ") & 31u);"; break;
+        case 11: st = "f = zpq::sp_uni(a == (" + v + "));"; break;
+        case 12: st = "f = zpq::sp_uni(a < (" + v + "));"; break;
+        default: st = "f = zpq::sp_uni(a > (" + v + "));"; break;
+      }
+    } else if (op == 255) { st = jump(prog[pc + 1] + 256 * prog[pc + 2], ""); falls = false; }
+    else { st = "goto Lerr;"; falls = false; }
+    out << "    L" << pc << ": " << st;
+    if (falls) {
+      auto nx = std::next(it);
+      if (nx == insns.end() || nx->first != next) out << " goto " << label(next) << ";";
+    }
+    out << "\n";
+  }
+  out << "    Lhalt: rb = b; rc = c; rd = d; rf = f; return 0;\n"
+         "    Lerr: return 5;\n"
+         "  }\n";
+  return true;
+}
+
+}  // namespace
+
+bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string& why_not) {
+  const PlanHeader& ph = plan.hdr();
+  const int n = (int)ph.n;
+  if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
+  const CompDesc* comp = plan.comps();
+  // LDS plan for the wave's region: H first, then ICM/ISSE side tables while they fit
+  int lds_used = 0, h_lds = -1;
+  const int h_bytes = (int)(4u * (ph.hmask + 1));
+  if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
+  std::ostringstream o;
+  o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
+       "#include \"spec_kernel.h\"\n"
+       "namespace zpq_gen {\n"
+       "struct Chain {\n";
+  int nmix = 0, nsse = 0;
+  std::ostringstream comps;
+  for (int i = 0; i < n; ++i) {
+    const CompDesc& c = comp[i];
+    int lds = -1, slot = -1;
+    if (c.type == C_ICM || c.type == C_ISSE) {
+      const int bytes = c.type == C_ICM ? 1024 : 2048;
+      if (lds_used + bytes <= kSpecWaveLdsBytes) { lds = lds_used; lds_used += bytes; }
+    }
+    if (c.type == C_MIX) slot = nmix++;
+    if (c.type == C_SSE) slot = nsse++;
+    if (c.type == C_MIX && (c.a3 > 64 || c.a2 + c.a3 > 64)) { why_not = "MIX wider than a wavefront"; return false; }
+    comps << "    {" << c.type << "u," << c.a1 << "u," << c.a2 << "u," << c.a3 << "u," << c.a4 << "u," << c.a5 << "u, "
+          << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, " << lds << ","
+          << slot << "},\n";
+  }
+  o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ";\n"
+    << "  static constexpr unsigned HMASK = " << ph.hmask << "u, MMASK = " << ph.mmask << "u;\n"
+    << "  static constexpr int H_LDS = " << h_lds << ";\n"
+    << "  static constexpr unsigned long long OFF_H = " << ph.off_H << "ull, OFF_M = " << ph.off_M
+    << "ull, OFF_R = " << ph.off_R << "ull;\n"
+    << "  static constexpr zpq::CompK comp[N] = {\n" << comps.str() << "  };\n";
+  const U8* prog = plan.blob.data() + ph.off_prog;
+  if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
+  o << "};\n"
+       "}  // namespace zpq_gen\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void zpq_spec_encode(const zpq::BlockJob* jobs, "
+       "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
+       "  zpq::spec_kernel_body<zpq_gen::Chain, false>(jobs, res, nblocks, tb);\n}\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void zpq_spec_decode(const zpq::BlockJob* jobs, "
+       "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
+       "  zpq::spec_kernel_body<zpq_gen::Chain, true>(jobs, res, nblocks, tb);\n}\n";
+  source = o.str();
+  return true;
+}
+
+std::string spec_cache_key(const std::string& source) {
+  // key = SHA-1 of the generated text and of the kernel template it instantiates
+  Sha1 s;
+  s.update(source.data(), source.size());
+  const U8* d = s.result();
+  char hex[41];
+  for (int i = 0; i < 20; ++i) snprintf(hex + 2 * i, 3, "%02x", d[i]);
+  return std::string(hex, 40);
+}
+
+}  // namespace zpq

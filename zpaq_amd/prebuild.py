@@ -1,0 +1,123 @@
+"""Ahead-of-time compilation of the per-header specialised kernels.
+
+    python -m zpaq_amd.prebuild            (called by __graft_entry__.build())
+
+For every standard block header -- the chains compressBlock generates for
+methods "4" and "5" (.. "9") at each block-size exponent, with and without the
+text hint, plus the headers recorded in tests/golden/golden.json (legacy
+min/mid/max models, the all-nine-types config) -- ask the library for the
+generated HIP source (zpq_plan_spec_source) and compile it with
+`hipcc --genco --offload-arch=gfx950` into zpaq_amd/spec_cache/<key>.hsaco.
+hipcc cross-compiles without a GPU.  Headers not covered here (e.g. level-5
+chains with data-dependent periodic models) are compiled at run time by hipRTC
+and added to the same cache.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def standard_headers():
+    import zpaq_amd as z
+    hs = {}
+    for level in ("4", "5"):
+        for arg0 in range(0, 7):
+            for hint in ("", ",128,1"):        # plain / text
+                # expand against a dummy buffer of the right size class: only n matters for arg0
+                n = max(1, (1 << (20 + arg0)) - 4096)
+                dummy = bytes(1)            # period detection sees no period in a 1-byte buffer
+                xm = z.expand_method(level + hint, dummy)
+                # expand_method derives arg0 from the buffer length: patch it in
+                xm = "x" + str(arg0) + xm[xm.index(","):]
+                try:
+                    h, p, _ = z.method_to_header(xm)
+                except z.ZpaqError:
+                    continue
+                hs[h] = f"method {level}{hint} arg0={arg0}"
+    gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
+    if os.path.exists(gpath):
+        g = json.load(open(gpath))
+        for sect in ("method_cases", "config_cases", "level_cases"):
+            for e in g[sect]:
+                h = bytes.fromhex(e["header"])
+                if h[6]:
+                    hs.setdefault(h, f"golden {sect}")
+    return hs
+
+
+def source_and_key(header):
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_spec_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    p = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    rc = L.zpq_plan_spec_source(p._h, buf, len(buf), C.byref(ln), key)
+    if rc != 0:
+        return None, L.zpq_last_error().decode()
+    return buf.value.decode(), key.value.decode()
+
+
+def compile_one(args):
+    src, key, cache, inc = args
+    out = os.path.join(cache, key + ".hsaco")
+    if os.path.exists(out) and os.path.getsize(out) > 0:
+        return key, "cached"
+    tmp = os.path.join(cache, key + ".hip")
+    with open(tmp, "w") as fh:
+        fh.write(src)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-I", inc, "--genco", tmp,
+           "-o", out + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    os.remove(tmp)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {key}:\n{r.stdout[-3000:]}")
+    os.replace(out + ".tmp", out)
+    return key, "built"
+
+
+def main(verbose=True):
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_spec_cache_dir.restype = C.c_char_p
+    L.zpq_spec_include_dir.restype = C.c_char_p
+    cache = L.zpq_spec_cache_dir().decode()
+    inc = L.zpq_spec_include_dir().decode()
+    os.makedirs(cache, exist_ok=True)
+    jobs, skipped = [], 0
+    seen = set()
+    for h, why in standard_headers().items():
+        src, key = source_and_key(h)
+        if src is None:
+            skipped += 1
+            continue
+        if key in seen:
+            continue
+        seen.add(key)
+        jobs.append((src, key, cache, inc))
+    # drop stale code objects of older template versions
+    for fn in os.listdir(cache):
+        if fn.endswith(".hsaco") and fn[:-6] not in seen and not os.environ.get("ZPAQ_AMD_KEEP_CACHE"):
+            os.remove(os.path.join(cache, fn))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(compile_one, jobs))
+    if verbose:
+        print(f"spec_cache: {sum(1 for _, s in res if s == 'built')} built, "
+              f"{sum(1 for _, s in res if s == 'cached')} up to date, {skipped} not specialisable -> {cache}")
+    return res
+
+
+if __name__ == "__main__":
+    main()
