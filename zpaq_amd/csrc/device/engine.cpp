@@ -47,6 +47,7 @@ struct Engine {
   uint64_t budget = 0;
   int kernel_choice = 0;
   DevBuf arena, io_in, io_out, jobs, results;
+  std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
   int last_kind = 0;
 };
@@ -197,11 +198,35 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
   HIP_CHECK(launch_init_arena(d_jobs, nb, e.d_tables, chunks, st));
   if (timed) HIP_CHECK(hipEventRecord(ev[1], st));
   if (timed) HIP_CHECK(hipEventRecord(ev[2], st));
-  for (const LaunchGroup& g : groups) {
-    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
-    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
-    else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, st));
+  // Groups (one per kernel kind / plan) are independent: fan them out over side streams so a
+  // batch mixing several chains does not serialise one launch after the other.
+  const size_t nside = groups.size() > 1 ? std::min<size_t>(groups.size() - 1, 7) : 0;
+  while (e.side.size() < nside) {
+    hipStream_t s2;
+    HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    e.side.push_back(s2);
   }
+  hipEvent_t fork = nullptr;
+  if (nside) {
+    HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(fork, st));
+  }
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const LaunchGroup& g = groups[gi];
+    hipStream_t gs = (nside && gi % (nside + 1)) ? e.side[gi % (nside + 1) - 1] : st;
+    if (gs != st && gi <= nside) HIP_CHECK(hipStreamWaitEvent(gs, fork, 0));
+    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
+    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
+    else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
+  }
+  for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
+    hipEvent_t done;
+    HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(done, e.side[k]));
+    HIP_CHECK(hipStreamWaitEvent(st, done, 0));
+    HIP_CHECK(hipEventDestroy(done));
+  }
+  if (fork) HIP_CHECK(hipEventDestroy(fork));
   if (timed) {
     HIP_CHECK(hipEventRecord(ev[3], st));
     HIP_CHECK(hipEventSynchronize(ev[3]));

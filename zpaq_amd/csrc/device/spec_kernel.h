@@ -126,6 +126,20 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
 }
 
+// May a MIX / SSE row be fetched one bit early?  Only when consecutive bits of a byte always
+// select different rows (then the early copy cannot miss the previous bit's update).
+constexpr bool mix_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u; }
+constexpr bool sse_pf(const CompK& c) { return c.mask0 >= 32u * 256u - 1u; }
+
+// lanes (components) of a given type, as a compile-time bit mask
+template <class Chain>
+constexpr unsigned long long type_mask(unsigned t) {
+  unsigned long long m = 0;
+  for (int i = 0; i < Chain::N; ++i)
+    if (Chain::comp[i].type == t) m |= 1ull << i;
+  return m;
+}
+
 // ---------------------------------------------------------------------------
 template <class Chain, bool DEC>
 __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResult* res, unsigned nblocks,
@@ -156,8 +170,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
 
   // ---- per-lane component constants (selected from the constexpr chain) ----
   unsigned type = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 0, sizebits = 0;
-  g_u8* t0 = nullptr;
-  g_u8* t1 = nullptr;
+  g_u8* t0 = arena;      // idle lanes keep a valid address: some loads are issued by every lane
+  g_u8* t1 = arena;
   int ldsoff = -1;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -196,8 +210,22 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     else return (g_u32*)(arena + Chain::OFF_H);
   }();
 
+  // ---- lane classes (compile-time masks over the chain) ----
+  constexpr unsigned long long M_CM = type_mask<Chain>(C_CM), M_ICM = type_mask<Chain>(C_ICM),
+                               M_ISSE = type_mask<Chain>(C_ISSE), M_MATCH = type_mask<Chain>(C_MATCH),
+                               M_MIX2 = type_mask<Chain>(C_MIX2);
+  const bool is_cm = (M_CM >> lane) & 1, is_icm = (M_ICM >> lane) & 1, is_isse = (M_ISSE >> lane) & 1;
+  const bool is_match = (M_MATCH >> lane) & 1, is_mix2 = (M_MIX2 >> lane) & 1;
+  const bool has_row = is_icm || is_isse;
+  const bool gl = is_cm || is_mix2;           // lanes with one global table word per bit
+  // may the next bit's word be fetched one bit early?  Only if consecutive bits can never
+  // address the same element (else the early copy could miss this bit's update)
+  const bool pf_lane = is_cm ? mask0 >= 511u : (is_mix2 && a5 == 255u && mask0 >= 255u);
+  // a table with a single element never leaves its register (e.g. the final "mix2 0")
+  const bool resident = gl && mask0 == 0u;
+
   // ---- per-lane mutable state ----
-  unsigned cxt = 0, ra = 0, rb = 0, rc = 0, rlimit = 0;   // Component::cxt,a,b,c,limit
+  unsigned cxt = 0;            // CM/MIX2: element index; ICM/ISSE: bit history (Component::cxt)
   unsigned h = 0;
   int p = 0;
   static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
@@ -209,53 +237,71 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   unsigned v0 = 0, v1 = 0;
   unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0;   // cached 16-byte bit-history row
   unsigned rowoff = 0xFFFFFFFFu;   // offset of the cached row in ht, or none
+  unsigned touch_a = 0, touch_b = 0;   // keep-alive for the second-nibble line prefetch
+  // MATCH, register resident (Component a=len, b=offset, limit=pos): the byte being built is c8
+  // itself and the predicted byte is fetched once per byte
+  unsigned ra = 0, rb = 0, rc = 0, rlimit = 0, mpred = 0, mdd = 0;
+  // rows selected this bit (wave-uniform element indices) and their words, lane-parallel
   int mixw[NMIX];              // lane t holds weight t of each MIX row
-  unsigned mixrow[NMIX];       // element index of the selected row (uniform)
+  unsigned mixrow[NMIX];
   unsigned ssev[NSSE];         // lane t (<32) holds entry t of each SSE row
-  unsigned ssecx[NSSE];        // element index of the trained SSE entry (uniform)
+  unsigned ssecx[NSSE];        // element index of the trained SSE entry
+  // one-bit-ahead candidates (next bit = 0 / next bit = 1)
+  unsigned gwc0 = 0, gwc1 = 0;
+  int mixc0[NMIX], mixc1[NMIX];
+  unsigned ssec0[NSSE], ssec1[NSSE];
 #pragma unroll
-  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; }
+  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
 #pragma unroll
-  for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; }
+  for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; ssec0[k] = 0; ssec1[k] = 0; }
+  unsigned rw = 0;             // the element of a resident (single-entry) table
+  if (resident) rw = is_cm ? *(const g_u32*)t0 : (unsigned)*(const g_u16*)t0;
+  bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
+  int ylast = 0;
 
   int c8 = 1, hmap4 = 1;
   unsigned low = 1, high = 0xFFFFFFFFu;
   unsigned steps = 0;
   int status = 0;
 
-  const bool is_icm = type == C_ICM, is_isse = type == C_ISSE;
-  const bool has_row = is_icm || is_isse;
+#ifdef ZPQ_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // predict, update, hcomp, total, rows, loads, chain
+  const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#define SP_PROF_BEGIN const unsigned long long pt_ = __builtin_readcyclecounter();
+#define SP_PROF_END(k) prof[k] += __builtin_readcyclecounter() - pt_;
+#else
+#define SP_PROF_BEGIN
+#define SP_PROF_END(k)
+#endif
+
+  // element index / load of the per-bit global word of a CM or MIX2 lane
+  auto g_index = [&](int c8x, int hm4x) __attribute__((always_inline)) -> unsigned {
+    return is_cm ? ((h ^ (unsigned)hm4x) & mask0) : ((h + (unsigned)(c8x & (int)a5)) & mask0);
+  };
+  auto g_load = [&](unsigned idx) __attribute__((always_inline)) -> unsigned {
+    // one dword load for both kinds: CM words are dwords, MIX2 weights are halves of a dword
+    const unsigned off = is_cm ? idx * 4u : idx * 2u;
+    const unsigned w = *(const g_u32*)(t0 + (off & ~3u));
+    return is_cm ? w : ((w >> ((off & 2u) * 8u)) & 0xffffu);
+  };
 
   // ---------------------------------------------------------------- predict
   auto predict = [&]() __attribute__((always_inline)) -> unsigned {
     const bool nib = (c8 == 1) || ((c8 & 0xf0) == 16);
     const int slot = hmap4 & 15;
-    // (A) issue this bit's global loads: addresses depend only on (h, c8, hmap4)
-    if (type == C_CM) {
-      cxt = (h ^ (unsigned)hmap4) & mask0;
-      v0 = ((const g_u32*)t0)[cxt];
-    } else if (type == C_MIX2) {
-      cxt = (h + (unsigned)(c8 & (int)a5)) & mask0;
-      v0 = ((const g_u16*)t0)[cxt];
-    }
-    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(ic)::value;
-      constexpr CompK c = Chain::comp[i];
-      if constexpr (c.type == C_MIX) {
-        const unsigned hi = sp_rlu(h, i);
-        const unsigned r = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
-        mixrow[c.slot] = r;
-        if (lane < (int)c.a3) mixw[c.slot] = ((const g_i32*)(arena + c.t0))[r + lane];
-      } else if constexpr (c.type == C_SSE) {
-        const unsigned hi = sp_rlu(h, i);
-        const unsigned cx0 = ((hi + (unsigned)c8) * 32u) & c.mask0;
-        ssecx[c.slot] = cx0;
-        if (lane < 32) ssev[c.slot] = ((const g_u32*)(arena + c.t0))[cx0 + lane];
-      }
-    });
-    // (B) ICM / ISSE: bit-history row in registers, side table in LDS
+    const bool more = c8 < 128;               // another bit of this byte follows
+    const int c8a = c8 * 2, c8b = c8 * 2 + 1;
+    const int hm4a = (c8a >= 16 && c8a < 32) ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+    const int hm4b = (c8b >= 16 && c8b < 32) ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                             : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+    // (B) ICM / ISSE: bit-history row in registers, probed once per nibble
+#ifdef ZPQ_PROF
+    const unsigned long long pb0 = __builtin_readcyclecounter();
+#endif
+    unsigned q0 = 0, q1 = 0;
     if (has_row) {
       if (nib) {
+        asm volatile("" ::"v"(touch_a), "v"(touch_b));
         if (rowoff != 0xFFFFFFFFu) *(g_u128*)(t1 + rowoff) = make_uint4(row0, row1, row2, row3);   // write back
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> sizebits) & 255u;
@@ -274,33 +320,119 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
         row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
         row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
+      } else if (c8 >= 8 && c8 < 16) {
+        // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
+        const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
+        touch_a = *(const g_u32*)(t1 + ((cxa * 16u) & (mask1 - 15u)));
+        touch_b = *(const g_u32*)(t1 + ((cxb * 16u) & (mask1 - 15u)));
       }
       cxt = row_get(row0, row1, row2, row3, slot);                         // bit history
-      // ICM: one word at [bh]; ISSE: two words at [2*bh], [2*bh+1]
+      // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]
       const unsigned e0 = is_icm ? cxt : 2u * cxt, e1 = is_icm ? cxt : 2u * cxt + 1u;
       if (ldsoff >= 0) {
         const lds_u32* q = (const lds_u32*)(wl + ldsoff);
-        v0 = q[e0];
-        v1 = q[e1];
+        q0 = q[e0];
+        q1 = q[e1];
       } else {
         const g_u32* q = (const g_u32*)t0;
-        v0 = q[e0];
-        v1 = q[e1];
+        q0 = q[e0];
+        q1 = q[e1];
       }
-      if (is_icm) p = sp_stretch(T, v0 >> 8);
-    } else if (type == C_MATCH) {
-      if (ra == 0) p = 0;
-      else {
-        rc = (t1[(rlimit - rb) & mask1] >> (7 - cxt)) & 1u;
-        const int dd = T.dt2k[ra];
-        p = sp_stretch(T, (unsigned)((rc ? -dd : dd) & 32767));
-      }
-    } else if (type == C_CM) {
-      p = sp_stretch(T, v0 >> 17);
     }
-    // (C) dependent components, in index order, unrolled with literal lanes
+#ifdef ZPQ_PROF
+    const unsigned long long pb1 = __builtin_readcyclecounter();
+    prof[4] += pb1 - pb0;
+#endif
+    // (A) global words of this bit.  Addresses depend only on (h, c8, hmap4), so a word can be
+    //     fetched one bit early for both values of the coming bit.  This bit's words come from the
+    //     candidates fetched during the previous bit (registers, no wait on anything issued in
+    //     this step) -- or are loaded now at the start of a byte / where early fetch is illegal.
+    //     Then the next bit's candidates are issued, unconditionally and for every lane (idle
+    //     lanes read a harmless in-table word) so that the instruction stream -- and with it
+    //     the compiler's vmcnt bookkeeping -- is the same on every path.
+    unsigned gw = 0;
+    if (gl) cxt = g_index(c8, hmap4);
+    if (pf_valid) {
+      gw = ylast ? gwc1 : gwc0;
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        if constexpr (c.type == C_MIX && mix_pf(c)) mixw[c.slot] = ylast ? mixc1[c.slot] : mixc0[c.slot];
+        if constexpr (c.type == C_SSE && sse_pf(c)) ssev[c.slot] = ylast ? ssec1[c.slot] : ssec0[c.slot];
+      });
+      if (gl && !pf_lane && !resident) gw = g_load(cxt);
+    } else {
+      gw = g_load(gl ? cxt : 0u);
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+        if constexpr (c.type == C_MIX && mix_pf(c)) {
+          const unsigned r = ((sp_rlu(h, i) + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
+          mixw[c.slot] = ((const g_i32*)(arena + c.t0))[r + (unsigned)min(lane, (int)c.a3 - 1)];
+        }
+        if constexpr (c.type == C_SSE && sse_pf(c)) {
+          const unsigned cx0 = ((sp_rlu(h, i) + (unsigned)c8) * 32u) & c.mask0;
+          ssev[c.slot] = ((const g_u32*)(arena + c.t0))[cx0 + (unsigned)(lane & 31)];
+        }
+      });
+    }
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_MIX) {
+        const unsigned hi = sp_rlu(h, i);
+        const g_i32* tab = (const g_i32*)(arena + c.t0);
+        const unsigned ln = (unsigned)min(lane, (int)c.a3 - 1);
+        mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
+        if constexpr (mix_pf(c)) {
+          mixc0[c.slot] = tab[((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3 + ln];
+          mixc1[c.slot] = tab[((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3 + ln];
+        } else {
+          mixw[c.slot] = tab[mixrow[c.slot] + ln];
+        }
+      } else if constexpr (c.type == C_SSE) {
+        const unsigned hi = sp_rlu(h, i);
+        const g_u32* tab = (const g_u32*)(arena + c.t0);
+        const unsigned ln = (unsigned)(lane & 31);
+        ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
+        if constexpr (sse_pf(c)) {
+          ssec0[c.slot] = tab[(((hi + (unsigned)c8a) * 32u) & c.mask0) + ln];
+          ssec1[c.slot] = tab[(((hi + (unsigned)c8b) * 32u) & c.mask0) + ln];
+        } else {
+          ssev[c.slot] = tab[ssecx[c.slot] + ln];
+        }
+      }
+    });
+    {
+      const unsigned ia = (gl && pf_lane) ? g_index(c8a, hm4a) : 0u, ib = (gl && pf_lane) ? g_index(c8b, hm4b) : 0u;
+      gwc0 = g_load(ia);
+      gwc1 = g_load(ib);
+    }
+    if (resident) gw = rw;
+#ifdef ZPQ_PROF
+    const unsigned long long pb2 = __builtin_readcyclecounter();
+    prof[5] += pb2 - pb1;
+#endif
+    // (C) MATCH: pure register work (predicted byte and 2048/len were fetched at the byte boundary)
+    unsigned msx = 0;
+    if (is_match && ra != 0) {
+      rc = (mpred >> (7 - (31 - __builtin_clz((unsigned)c8)))) & 1u;
+      msx = (rc ? 0u - mdd : mdd) & 32767u;
+    }
+    // (D) one stretch lookup for every context-only component
+    const unsigned sx = is_icm ? (q0 >> 8) : (is_cm ? (gw >> 17) : msx);
+    const int st = sp_stretch(T, sx & 32767u);
+    if (is_icm || is_cm || (is_match && ra != 0)) p = st;
+    else if (is_match) p = 0;
+    v0 = has_row ? q0 : gw;
+    v1 = q1;
+    // (E) dependent components, in index order, unrolled with literal lanes
     Dep<Chain, 0>::predict(T, lane, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, cxt);
-    return sp_uni((unsigned)sp_squash(T, sp_rl(p, N - 1)));
+    pf_valid = more;
+    const unsigned prr = sp_uni((unsigned)sp_squash(T, sp_rl(p, N - 1)));
+#ifdef ZPQ_PROF
+    prof[6] += __builtin_readcyclecounter() - pb2;
+#endif
+    return prr;
   };
 
   // ----------------------------------------------------------------- update
@@ -308,29 +440,46 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int slot = hmap4 & 15;
     const int pj = __shfl(p, (int)(a2 & 63));     // ISSE j / MIX2 j
     const int pk = __shfl(p, (int)(a3 & 63));     // MIX2 k
-    if (type == C_CM) {
-      const unsigned count = v0 & 0x3ffu;
-      const int err = y * 32767 - (int)(v0 >> 17);
-      const unsigned prod = (unsigned)err * (unsigned)T.dt[count];
-      ((g_u32*)t0)[cxt] = v0 + (prod & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
-    } else if (is_icm) {
-      row_set(row0, row1, row2, row3, slot, T.ns[cxt * 4 + y]);
-      const unsigned nv = v0 + (unsigned)((int)((unsigned)(y * 32767) - (v0 >> 8)) >> 2);
-      if (ldsoff >= 0) ((lds_u32*)(wl + ldsoff))[cxt] = nv; else ((g_u32*)t0)[cxt] = nv;
-    } else if (is_isse) {
-      const int err = y * 32767 - sp_squash(T, p);
-      const unsigned nw0 = (unsigned)sp_clamp512k((int)v0 + ((err * pj + (1 << 12)) >> 13));
-      const unsigned nw1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-      if (ldsoff >= 0) { lds_u32* q = (lds_u32*)(wl + ldsoff) + 2 * cxt; q[0] = nw0; q[1] = nw1; }
-      else { g_u32* q = (g_u32*)t0 + 2 * cxt; q[0] = nw0; q[1] = nw1; }
-      row_set(row0, row1, row2, row3, slot, T.ns[cxt * 4 + y]);
-    } else if (type == C_MATCH) {
-      g_u8* buf = t1;
-      const unsigned mask = mask1;
+    // every lane's LDS lookups, issued together
+    const int sq = sp_squash(T, sp_clamp2k(p));
+    const unsigned nsv = T.ns[(cxt & 255u) * 4u + (unsigned)y];
+    const unsigned count = v0 & 0x3ffu;
+    const unsigned dtv = (unsigned)T.dt[count];
+    const int yq = y * 32767;
+    if (is_cm) {
+      const int err = yq - (int)(v0 >> 17);
+      const unsigned nv = v0 + (((unsigned)err * dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+      ((g_u32*)t0)[cxt] = nv;
+      rw = nv;
+    } else if (has_row) {
+      row_set(row0, row1, row2, row3, slot, nsv);
+      const int err = yq - sq;
+      // ICM: one word; ISSE: two weights
+      const unsigned n0 = is_icm ? v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2)
+                                 : (unsigned)sp_clamp512k((int)v0 + ((err * pj + (1 << 12)) >> 13));
+      const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
+      const unsigned e0 = is_icm ? cxt : 2u * cxt;
+      if (ldsoff >= 0) {
+        lds_u32* q = (lds_u32*)(wl + ldsoff);
+        q[e0] = n0;
+        if (is_isse) q[e0 + 1] = n1;
+      } else {
+        g_u32* q = (g_u32*)t0;
+        q[e0] = n0;
+        if (is_isse) q[e0 + 1] = n1;
+      }
+    } else if (is_mix2) {
+      const int err = ((yq - sq) * (int)a4) >> 5;
+      int w = (int)v0 + ((err * (pj - pk) + (1 << 12)) >> 13);
+      w = min(max(w, 0), 65535);
+      ((g_u16*)t0)[cxt] = (unsigned short)w;
+      rw = (unsigned)w;
+    } else if (is_match) {
       if ((int)rc != y) ra = 0;
-      buf[rlimit & mask] = (unsigned char)(buf[rlimit & mask] * 2 + y);
-      if (++cxt == 8) {
-        cxt = 0;
+      if (c8 >= 128) {                                     // this bit completes the byte
+        g_u8* buf = t1;
+        const unsigned mask = mask1;
+        buf[rlimit & mask] = (unsigned char)(c8 * 2 + y);
         rlimit = (rlimit + 1) & mask;
         g_u32* e = (g_u32*)t0 + (h & mask0);
         if (ra == 0) {
@@ -339,21 +488,20 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
             while (ra < 255 && buf[(rlimit - ra - 1) & mask] == buf[(rlimit - ra - rb - 1) & mask]) ++ra;
         } else ra += ra < 255;
         *e = rlimit;
+        if (ra != 0) { mpred = buf[(rlimit - rb) & mask]; mdd = T.dt2k[ra]; }
       }
-    } else if (type == C_MIX2) {
-      const int err = ((y * 32767 - sp_squash(T, p)) * (int)a4) >> 5;
-      int w = (int)v0 + ((err * (pj - pk) + (1 << 12)) >> 13);
-      w = min(max(w, 0), 65535);
-      ((g_u16*)t0)[cxt] = (unsigned short)w;
     }
     Dep<Chain, 0>::update(T, arena, lane, y, p, mixw, mixrow, ssev, ssecx);
+    ylast = y;
   };
 
   auto after_bit = [&](int y) __attribute__((always_inline)) -> int {   // c8 / hmap4 bookkeeping (libzpaq.cpp:2055-2065)
-    update(y);
+    { SP_PROF_BEGIN update(y); SP_PROF_END(1) }
     c8 += c8 + y;
     if (c8 >= 256) {
+      SP_PROF_BEGIN
       const int e = Chain::hcomp((unsigned)(c8 - 256), vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+      SP_PROF_END(2)
       if (e) return e;
       hmap4 = 1;
       c8 = 1;
@@ -383,7 +531,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       const int ch = (int)sp_uni(in_ptr[k]);
       encode(0, 0);
       for (int i = 7; i >= 0; --i) {
-        const unsigned pr = predict();
+        unsigned pr;
+        { SP_PROF_BEGIN pr = predict(); SP_PROF_END(0) }
         const int y = (ch >> i) & 1;
         encode(y, pr * 2 + 1);
         status = after_bit(y);
@@ -434,6 +583,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     if (lane == 0) { res[b].out_len = n; res[b].consumed = eos ? rp : 0; }
   }
   if (lane == 0) { res[b].status = status; res[b].steps = steps; }
+#ifdef ZPQ_PROF
+  if (lane == 0 && b == 0) {
+    prof[3] = __builtin_readcyclecounter() - prof_t0;
+    printf("[zpq spec prof] block 0: steps=%u cycles/bit: predict=%.0f (rows=%.0f loads=%.0f chain=%.0f) update=%.0f hcomp=%.0f total=%.0f\n",
+           steps, (double)prof[0] / steps, (double)prof[4] / steps, (double)prof[5] / steps, (double)prof[6] / steps,
+           (double)prof[1] / steps, (double)prof[2] / steps, (double)prof[3] / steps);
+  }
+#endif
 }
 
 // ---- compile-time walk over the dependent components -------------------------

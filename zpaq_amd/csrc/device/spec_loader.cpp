@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <vector>
@@ -65,6 +66,7 @@ bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string&
   s.update(source.data(), source.size());
   s.update(h1.data(), h1.size());
   s.update(h2.data(), h2.size());
+  if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));   // e.g. -DZPQ_PROF
   key = hex20(s.result());
   return true;
 }
@@ -76,8 +78,13 @@ static bool compile_hiprtc(const std::string& source, std::vector<char>& code, s
     return false;
   }
   const std::string inc = "-I" + spec_include_dir();
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), "-Wno-unused-label"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  // -simplifycfg-sink-common=false: store sinking across the kernel's big if/else ladders
+  // otherwise forces register state into scratch (see prebuild.py, same flags)
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), "-Wno-unused-label",
+                                   "-mllvm", "-simplifycfg-sink-common=false"};
+  const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS");
+  if (defs && defs[0]) opts.push_back(defs);   // a single extra option, e.g. -DZPQ_PROF
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
     log.resize(ls);

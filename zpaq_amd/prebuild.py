@@ -78,8 +78,11 @@ def compile_one(args):
     tmp = os.path.join(cache, key + ".hip")
     with open(tmp, "w") as fh:
         fh.write(src)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-I", inc, "--genco", tmp,
-           "-o", out + ".tmp"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label",
+           "-mllvm", "-simplifycfg-sink-common=false",     # keeps the kernel's register state out of scratch
+           "-I", inc, "--genco", tmp, "-o", out + ".tmp"]
+    if os.environ.get("ZPAQ_AMD_SPEC_DEFS"):
+        cmd.insert(1, os.environ["ZPAQ_AMD_SPEC_DEFS"])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     os.remove(tmp)
     if r.returncode != 0:
