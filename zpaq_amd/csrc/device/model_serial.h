@@ -193,7 +193,7 @@ __device__ inline int serial_predict(SerialCtx& s) {
         p[i] = (p[c.a1] * (int)c.a3 + p[c.a2] * (256 - (int)c.a3)) >> 8;
         break;
       case C_MIX2: {
-        const uint16_t* a16 = (const uint16_t*)(s.arena + c.t0);
+        const uint32_t* a16 = (const uint32_t*)(s.arena + c.t0);
         r.cxt = (s.h[i] + (uint32_t)(c8 & (int)c.a5)) & c.mask0;
         int w = a16[r.cxt];
         p[i] = (w * p[c.a2] + (65536 - w) * p[c.a3]) >> 16;
@@ -276,12 +276,12 @@ __device__ inline int serial_update(SerialCtx& s, int y) {
         break;
       }
       case C_MIX2: {
-        uint16_t* a16 = (uint16_t*)(s.arena + c.t0);
+        uint32_t* a16 = (uint32_t*)(s.arena + c.t0);
         int err = ((y * 32767 - (int)tb->squash[p[i] + 2048]) * (int)c.a4) >> 5;
         int w = a16[r.cxt];
         w += (err * (p[c.a2] - p[c.a3]) + (1 << 12)) >> 13;
         w = w < 0 ? 0 : (w > 65535 ? 65535 : w);
-        a16[r.cxt] = (uint16_t)w;
+        a16[r.cxt] = (uint32_t)w;
         break;
       }
       case C_MIX: {

@@ -224,7 +224,7 @@ __device__ inline void wave_predict_phase1(const WaveModel& m, Lane& s) {
     }
     case C_MIX2: {
       s.cxt = (s.h + (uint32_t)(c8 & (int)s.a5)) & s.mask0;
-      s.w0 = ((const uint16_t*)s.t0)[s.cxt];
+      s.w0 = (int)((const uint32_t*)s.t0)[s.cxt];
       break;
     }
     case C_MIX: {
@@ -337,7 +337,7 @@ __device__ inline void wave_update(const WaveModel& m, Lane& s, int y) {
       int w = s.w0;
       w += (err * (pj - pk) + (1 << 12)) >> 13;
       w = w < 0 ? 0 : (w > 65535 ? 65535 : w);
-      ((uint16_t*)s.t0)[s.cxt] = (uint16_t)w;
+      ((uint32_t*)s.t0)[s.cxt] = (uint32_t)w;
       break;
     }
     default: break;

@@ -89,7 +89,9 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         if (cp[3] >= i) fail(ZPQ_E_HEADER, "MIX2 k >= i");
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "MIX2 j >= i");
         c.mask0 = (1u << cp[1]) - 1;
-        c.t0 = seg(align_up(2ull << cp[1], 16), F_U32, 0x80008000u);
+        // device layout: one dword per weight (the reference packs U16) so that CM and MIX2
+        // words are fetched, prefetched and written back by the same dword instructions
+        c.t0 = seg(align_up(4ull << cp[1], 16), F_U32, 32768u);
         mem += 2 * size; algo += 32;
         dep_mask |= 1ull << (i & 63);
         break;

@@ -169,21 +169,32 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   lds_u8* const wl = (lds_u8*)&wave_lds[wave][0];
 
   // ---- per-lane component constants (selected from the constexpr chain) ----
-  unsigned type = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 0, sizebits = 0;
-  g_u8* t0 = arena;      // idle lanes keep a valid address: some loads are issued by every lane
-  g_u8* t1 = arena;
+  // Tables are addressed as arena + 32-bit offset (the arena of a specialised plan is < 4 GiB),
+  // so every global access is "uniform base + VGPR offset" and needs no 64-bit address math.
+  // Lanes without a table of some kind point at a private 64-byte dummy slot instead: loads and
+  // stores can then be issued by ALL lanes with no exec-mask juggling (divergent branches were a
+  // quarter of the instruction stream), and land harmlessly.
+  const unsigned dummy = (unsigned)Chain::OFF_RUN + (unsigned)lane * 64u;
+  const unsigned dummy_lds = (unsigned)(kSpecWaveLds - 512) + (unsigned)lane * 8u;
+  unsigned type = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63, sizebits = 0;
+  unsigned off0 = dummy, off1 = dummy;
   int ldsoff = -1;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if (lane == i) {
       const CompK c = Chain::comp[i];
       type = c.type; a2 = c.a2; a3 = c.a3; a4 = c.a4; a5 = c.a5;
-      limit = c.limit; mask0 = c.mask0; mask1 = c.mask1; sizebits = c.a1 + 2;
-      t0 = arena + c.t0;
-      t1 = arena + c.t1;
+      limit = c.limit; mask0 = c.mask0; sizebits = c.a1 + 2;
+      off0 = (unsigned)c.t0;
+      if (c.type == C_ICM || c.type == C_ISSE || c.type == C_MATCH) { off1 = (unsigned)c.t1; mask1 = c.mask1; }
       ldsoff = c.lds;
     }
   }
+  auto G32 = [&](unsigned off) __attribute__((always_inline)) -> g_u32& { return *(g_u32*)(arena + off); };
+  auto G8 = [&](unsigned off) __attribute__((always_inline)) -> g_u8& { return *(g_u8*)(arena + off); };
+  auto G128 = [&](unsigned off) __attribute__((always_inline)) -> g_u128& { return *(g_u128*)(arena + off); };
+  auto L32 = [&](unsigned off) __attribute__((always_inline)) -> lds_u32& { return *(lds_u32*)(wl + off); };
+
   // side tables -> LDS (the arena copies were initialised by init_arena_kernel)
   if (live) {
     static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
@@ -197,6 +208,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     });
     if constexpr (Chain::H_LDS >= 0)
       for (unsigned k = lane; k <= Chain::HMASK; k += 64) ((lds_u32*)(wl + Chain::H_LDS))[k] = 0;
+    L32(dummy_lds) = 0;
+    L32(dummy_lds + 4) = 0;
   }
   __syncthreads();
   if (!live) return;
@@ -223,9 +236,16 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   const bool pf_lane = is_cm ? mask0 >= 511u : (is_mix2 && a5 == 255u && mask0 >= 255u);
   // a table with a single element never leaves its register (e.g. the final "mix2 0")
   const bool resident = gl && mask0 == 0u;
+  const unsigned goff = gl ? off0 : dummy;                  // base of the per-bit global word
+  const unsigned gmask = gl ? mask0 : 0u;                   // idle lanes always address element 0 of their dummy
+  const unsigned rmask = has_row ? mask1 : 63u;             // idle lanes probe inside their 64-byte dummy
+  const unsigned roff = has_row ? off1 : dummy;             // base of the bit-history hash table
+  const unsigned ldsq = (has_row && ldsoff >= 0) ? (unsigned)ldsoff : dummy_lds;   // side table in LDS
+  const bool side_global = has_row && ldsoff < 0;           // side table left in the arena (LDS full)
 
   // ---- per-lane mutable state ----
-  unsigned cxt = 0;            // CM/MIX2: element index; ICM/ISSE: bit history (Component::cxt)
+  unsigned bh = 0;             // ICM/ISSE: bit history of this bit (Component::cxt)
+  unsigned gidx = 0;           // CM/MIX2: element index of this bit
   unsigned h = 0;
   int p = 0;
   static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
@@ -235,8 +255,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   // table words read in predict and reused by update:
   //   CM: v0 = cm word | ICM: v0 = side-table word | ISSE: v0,v1 = weights | MIX2: v0 = weight
   unsigned v0 = 0, v1 = 0;
-  unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0;   // cached 16-byte bit-history row
-  unsigned rowoff = 0xFFFFFFFFu;   // offset of the cached row in ht, or none
+  // cached 16-byte bit-history row.  The tables start out all zero, so writing the initial
+  // (zero) row back to offset 0 at the first probe changes nothing.
+  unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0;
+  unsigned rowoff = 0;
   unsigned touch_a = 0, touch_b = 0;   // keep-alive for the second-nibble line prefetch
   // MATCH, register resident (Component a=len, b=offset, limit=pos): the byte being built is c8
   // itself and the predicted byte is fetched once per byte
@@ -254,8 +276,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; ssec0[k] = 0; ssec1[k] = 0; }
-  unsigned rw = 0;             // the element of a resident (single-entry) table
-  if (resident) rw = is_cm ? *(const g_u32*)t0 : (unsigned)*(const g_u16*)t0;
+  unsigned rw = G32(goff);     // the element of a resident (single-entry) table
   bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
   int ylast = 0;
 
@@ -274,15 +295,9 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
 #define SP_PROF_END(k)
 #endif
 
-  // element index / load of the per-bit global word of a CM or MIX2 lane
+  // element index of the per-bit global word (CM: h ^ hmap4, MIX2: h + (c8 & mask)); idle lanes get 0
   auto g_index = [&](int c8x, int hm4x) __attribute__((always_inline)) -> unsigned {
-    return is_cm ? ((h ^ (unsigned)hm4x) & mask0) : ((h + (unsigned)(c8x & (int)a5)) & mask0);
-  };
-  auto g_load = [&](unsigned idx) __attribute__((always_inline)) -> unsigned {
-    // one dword load for both kinds: CM words are dwords, MIX2 weights are halves of a dword
-    const unsigned off = is_cm ? idx * 4u : idx * 2u;
-    const unsigned w = *(const g_u32*)(t0 + (off & ~3u));
-    return is_cm ? w : ((w >> ((off & 2u) * 8u)) & 0xffffu);
+    return (is_cm ? (h ^ (unsigned)hm4x) : (h + (unsigned)(c8x & (int)a5))) & gmask;
   };
 
   // ---------------------------------------------------------------- predict
@@ -294,50 +309,45 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int hm4a = (c8a >= 16 && c8a < 32) ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
     const int hm4b = (c8b >= 16 && c8b < 32) ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
                                              : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
-    // (B) ICM / ISSE: bit-history row in registers, probed once per nibble
 #ifdef ZPQ_PROF
     const unsigned long long pb0 = __builtin_readcyclecounter();
 #endif
-    unsigned q0 = 0, q1 = 0;
-    if (has_row) {
-      if (nib) {
-        asm volatile("" ::"v"(touch_a), "v"(touch_b));
-        if (rowoff != 0xFFFFFFFFu) *(g_u128*)(t1 + rowoff) = make_uint4(row0, row1, row2, row3);   // write back
-        const unsigned cx = h + 16u * (unsigned)c8;
-        const unsigned chk = (cx >> sizebits) & 255u;
-        const unsigned h0 = (cx * 16u) & (mask1 - 15u);
-        const uint4 r0 = *(const g_u128*)(t1 + h0);
-        const uint4 r1 = *(const g_u128*)(t1 + (h0 ^ 16u));
-        const uint4 r2 = *(const g_u128*)(t1 + (h0 ^ 32u));
-        // Predictor::find (libzpaq.cpp:2072-2088)
-        const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
-        const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
-        const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
-        const bool hit = m0 || m1 || m2;
-        const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
-        rowoff = h0 ^ (unsigned)(pick << 4);
-        row0 = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
-        row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
-        row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
-        row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
-      } else if (c8 >= 8 && c8 < 16) {
-        // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
-        const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
-        touch_a = *(const g_u32*)(t1 + ((cxa * 16u) & (mask1 - 15u)));
-        touch_b = *(const g_u32*)(t1 + ((cxb * 16u) & (mask1 - 15u)));
-      }
-      cxt = row_get(row0, row1, row2, row3, slot);                         // bit history
-      // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]
-      const unsigned e0 = is_icm ? cxt : 2u * cxt, e1 = is_icm ? cxt : 2u * cxt + 1u;
-      if (ldsoff >= 0) {
-        const lds_u32* q = (const lds_u32*)(wl + ldsoff);
-        q0 = q[e0];
-        q1 = q[e1];
-      } else {
-        const g_u32* q = (const g_u32*)t0;
-        q0 = q[e0];
-        q1 = q[e1];
-      }
+    // (B) ICM / ISSE: bit-history row in registers, probed once per nibble (all lanes take part;
+    //     lanes without a row work on their dummy slot)
+    if (nib) {
+      asm volatile("" ::"v"(touch_a), "v"(touch_b));
+      G128(roff + rowoff) = make_uint4(row0, row1, row2, row3);             // write the old row back
+      const unsigned cx = h + 16u * (unsigned)c8;
+      const unsigned chk = (cx >> sizebits) & 255u;
+      const unsigned h0 = (cx * 16u) & (rmask - 15u);
+      const uint4 r0 = G128(roff + h0);
+      const uint4 r1 = G128(roff + (h0 ^ 16u));
+      const uint4 r2 = G128(roff + (h0 ^ 32u));
+      // Predictor::find (libzpaq.cpp:2072-2088)
+      const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+      const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+      const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
+      const bool hit = m0 || m1 || m2;
+      const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
+      rowoff = h0 ^ (unsigned)(pick << 4);
+      row0 = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
+      row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
+      row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
+      row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
+    } else if (c8 >= 8 && c8 < 16) {
+      // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
+      const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
+      touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
+      touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+    }
+    bh = row_get(row0, row1, row2, row3, slot);                              // bit history
+    // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]; idle lanes: their dummy
+    const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
+    const unsigned el = side_global ? 0u : e0;             // LDS view: a lane whose table is global uses its dummy
+    unsigned q0 = L32(ldsq + 4u * el);
+    unsigned q1 = L32(ldsq + 4u * el + (is_icm ? 0u : 4u));
+    if constexpr (Chain::ANY_GLOBAL_SIDE) {
+      if (side_global) { q0 = G32(off0 + 4u * e0); q1 = G32(off0 + 4u * e0 + (is_icm ? 0u : 4u)); }
     }
 #ifdef ZPQ_PROF
     const unsigned long long pb1 = __builtin_readcyclecounter();
@@ -347,11 +357,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     //     fetched one bit early for both values of the coming bit.  This bit's words come from the
     //     candidates fetched during the previous bit (registers, no wait on anything issued in
     //     this step) -- or are loaded now at the start of a byte / where early fetch is illegal.
-    //     Then the next bit's candidates are issued, unconditionally and for every lane (idle
-    //     lanes read a harmless in-table word) so that the instruction stream -- and with it
-    //     the compiler's vmcnt bookkeeping -- is the same on every path.
-    unsigned gw = 0;
-    if (gl) cxt = g_index(c8, hmap4);
+    //     Then the next bit's candidates are issued, unconditionally and by every lane, so that
+    //     the instruction stream -- and with it the compiler's vmcnt bookkeeping -- is the same
+    //     on every path.
+    unsigned gw;
+    gidx = g_index(c8, hmap4);
     if (pf_valid) {
       gw = ylast ? gwc1 : gwc0;
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
@@ -359,19 +369,21 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         if constexpr (c.type == C_MIX && mix_pf(c)) mixw[c.slot] = ylast ? mixc1[c.slot] : mixc0[c.slot];
         if constexpr (c.type == C_SSE && sse_pf(c)) ssev[c.slot] = ylast ? ssec1[c.slot] : ssec0[c.slot];
       });
-      if (gl && !pf_lane && !resident) gw = g_load(cxt);
+      if constexpr (Chain::ANY_NONPF_GL) {
+        if (gl && !pf_lane && !resident) gw = G32(goff + 4u * gidx);
+      }
     } else {
-      gw = g_load(gl ? cxt : 0u);
+      gw = G32(goff + 4u * gidx);
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) {
           const unsigned r = ((sp_rlu(h, i) + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
-          mixw[c.slot] = ((const g_i32*)(arena + c.t0))[r + (unsigned)min(lane, (int)c.a3 - 1)];
+          mixw[c.slot] = (int)G32((unsigned)c.t0 + 4u * (r + (unsigned)min(lane, (int)c.a3 - 1)));
         }
         if constexpr (c.type == C_SSE && sse_pf(c)) {
           const unsigned cx0 = ((sp_rlu(h, i) + (unsigned)c8) * 32u) & c.mask0;
-          ssev[c.slot] = ((const g_u32*)(arena + c.t0))[cx0 + (unsigned)(lane & 31)];
+          ssev[c.slot] = G32((unsigned)c.t0 + 4u * (cx0 + (unsigned)(lane & 31)));
         }
       });
     }
@@ -380,53 +392,48 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         const unsigned hi = sp_rlu(h, i);
-        const g_i32* tab = (const g_i32*)(arena + c.t0);
         const unsigned ln = (unsigned)min(lane, (int)c.a3 - 1);
         mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
         if constexpr (mix_pf(c)) {
-          mixc0[c.slot] = tab[((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3 + ln];
-          mixc1[c.slot] = tab[((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3 + ln];
+          mixc0[c.slot] = (int)G32((unsigned)c.t0 + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3 + ln));
+          mixc1[c.slot] = (int)G32((unsigned)c.t0 + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3 + ln));
         } else {
-          mixw[c.slot] = tab[mixrow[c.slot] + ln];
+          mixw[c.slot] = (int)G32((unsigned)c.t0 + 4u * (mixrow[c.slot] + ln));
         }
       } else if constexpr (c.type == C_SSE) {
         const unsigned hi = sp_rlu(h, i);
-        const g_u32* tab = (const g_u32*)(arena + c.t0);
         const unsigned ln = (unsigned)(lane & 31);
         ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
         if constexpr (sse_pf(c)) {
-          ssec0[c.slot] = tab[(((hi + (unsigned)c8a) * 32u) & c.mask0) + ln];
-          ssec1[c.slot] = tab[(((hi + (unsigned)c8b) * 32u) & c.mask0) + ln];
+          ssec0[c.slot] = G32((unsigned)c.t0 + 4u * ((((hi + (unsigned)c8a) * 32u) & c.mask0) + ln));
+          ssec1[c.slot] = G32((unsigned)c.t0 + 4u * ((((hi + (unsigned)c8b) * 32u) & c.mask0) + ln));
         } else {
-          ssev[c.slot] = tab[ssecx[c.slot] + ln];
+          ssev[c.slot] = G32((unsigned)c.t0 + 4u * (ssecx[c.slot] + ln));
         }
       }
     });
     {
-      const unsigned ia = (gl && pf_lane) ? g_index(c8a, hm4a) : 0u, ib = (gl && pf_lane) ? g_index(c8b, hm4b) : 0u;
-      gwc0 = g_load(ia);
-      gwc1 = g_load(ib);
+      const unsigned ia = pf_lane ? g_index(c8a, hm4a) : 0u, ib = pf_lane ? g_index(c8b, hm4b) : 0u;
+      gwc0 = G32(goff + 4u * ia);
+      gwc1 = G32(goff + 4u * ib);
     }
-    if (resident) gw = rw;
+    gw = resident ? rw : gw;
 #ifdef ZPQ_PROF
     const unsigned long long pb2 = __builtin_readcyclecounter();
     prof[5] += pb2 - pb1;
 #endif
     // (C) MATCH: pure register work (predicted byte and 2048/len were fetched at the byte boundary)
-    unsigned msx = 0;
-    if (is_match && ra != 0) {
-      rc = (mpred >> (7 - (31 - __builtin_clz((unsigned)c8)))) & 1u;
-      msx = (rc ? 0u - mdd : mdd) & 32767u;
-    }
+    const bool m_on = is_match && ra != 0;
+    rc = m_on ? ((mpred >> (7 - (31 - __builtin_clz((unsigned)c8)))) & 1u) : rc;
+    const unsigned msx = (rc ? 0u - mdd : mdd) & 32767u;
     // (D) one stretch lookup for every context-only component
     const unsigned sx = is_icm ? (q0 >> 8) : (is_cm ? (gw >> 17) : msx);
     const int st = sp_stretch(T, sx & 32767u);
-    if (is_icm || is_cm || (is_match && ra != 0)) p = st;
-    else if (is_match) p = 0;
+    p = (is_icm || is_cm || m_on) ? st : (is_match ? 0 : p);
     v0 = has_row ? q0 : gw;
     v1 = q1;
     // (E) dependent components, in index order, unrolled with literal lanes
-    Dep<Chain, 0>::predict(T, lane, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, cxt);
+    Dep<Chain, 0>::predict(T, lane, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx);
     pf_valid = more;
     const unsigned prr = sp_uni((unsigned)sp_squash(T, sp_rl(p, N - 1)));
 #ifdef ZPQ_PROF
@@ -442,56 +449,47 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int pk = __shfl(p, (int)(a3 & 63));     // MIX2 k
     // every lane's LDS lookups, issued together
     const int sq = sp_squash(T, sp_clamp2k(p));
-    const unsigned nsv = T.ns[(cxt & 255u) * 4u + (unsigned)y];
+    const unsigned nsv = T.ns[(bh & 255u) * 4u + (unsigned)y];
     const unsigned count = v0 & 0x3ffu;
     const unsigned dtv = (unsigned)T.dt[count];
     const int yq = y * 32767;
-    if (is_cm) {
-      const int err = yq - (int)(v0 >> 17);
-      const unsigned nv = v0 + (((unsigned)err * dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
-      ((g_u32*)t0)[cxt] = nv;
-      rw = nv;
-    } else if (has_row) {
-      row_set(row0, row1, row2, row3, slot, nsv);
-      const int err = yq - sq;
-      // ICM: one word; ISSE: two weights
-      const unsigned n0 = is_icm ? v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2)
-                                 : (unsigned)sp_clamp512k((int)v0 + ((err * pj + (1 << 12)) >> 13));
-      const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-      const unsigned e0 = is_icm ? cxt : 2u * cxt;
-      if (ldsoff >= 0) {
-        lds_u32* q = (lds_u32*)(wl + ldsoff);
-        q[e0] = n0;
-        if (is_isse) q[e0 + 1] = n1;
-      } else {
-        g_u32* q = (g_u32*)t0;
-        q[e0] = n0;
-        if (is_isse) q[e0 + 1] = n1;
-      }
-    } else if (is_mix2) {
-      const int err = ((yq - sq) * (int)a4) >> 5;
-      int w = (int)v0 + ((err * (pj - pk) + (1 << 12)) >> 13);
-      w = min(max(w, 0), 65535);
-      ((g_u16*)t0)[cxt] = (unsigned short)w;
-      rw = (unsigned)w;
-    } else if (is_match) {
-      if ((int)rc != y) ra = 0;
-      if (c8 >= 128) {                                     // this bit completes the byte
-        g_u8* buf = t1;
-        const unsigned mask = mask1;
-        buf[rlimit & mask] = (unsigned char)(c8 * 2 + y);
-        rlimit = (rlimit + 1) & mask;
-        g_u32* e = (g_u32*)t0 + (h & mask0);
-        if (ra == 0) {
-          rb = rlimit - *e;
-          if (rb & mask)
-            while (ra < 255 && buf[(rlimit - ra - 1) & mask] == buf[(rlimit - ra - rb - 1) & mask]) ++ra;
-        } else ra += ra < 255;
-        *e = rlimit;
-        if (ra != 0) { mpred = buf[(rlimit - rb) & mask]; mdd = T.dt2k[ra]; }
-      }
+    const int err = yq - sq;
+    // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
+    row_set(row0, row1, row2, row3, slot, nsv);
+    const unsigned n0 = is_icm ? v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2)
+                               : (unsigned)sp_clamp512k((int)v0 + ((err * pj + (1 << 12)) >> 13));
+    const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
+    const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
+    const unsigned el = side_global ? 0u : e0;
+    L32(ldsq + 4u * el) = n0;
+    L32((is_isse && !side_global) ? ldsq + 4u * el + 4u : dummy_lds + 4u) = n1;
+    if constexpr (Chain::ANY_GLOBAL_SIDE) {
+      if (side_global) { G32(off0 + 4u * e0) = n0; if (is_isse) G32(off0 + 4u * e0 + 4u) = n1; }
     }
-    Dep<Chain, 0>::update(T, arena, lane, y, p, mixw, mixrow, ssev, ssecx);
+    // per-bit global word: CM (Predictor::train) or MIX2 weight; idle lanes write their dummy
+    const int errcm = yq - (int)(v0 >> 17);
+    const unsigned cm_new = v0 + (((unsigned)errcm * dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+    const int err2 = (err * (int)a4) >> 5;
+    const int w2 = min(max((int)v0 + ((err2 * (pj - pk) + (1 << 12)) >> 13), 0), 65535);
+    const unsigned gnew = is_cm ? cm_new : (unsigned)w2;
+    G32(goff + 4u * gidx) = gnew;
+    rw = gnew;
+    // MATCH (Predictor::update0 case MATCH, libzpaq.cpp:1985-2008)
+    ra = (is_match && (int)rc != y) ? 0u : ra;
+    if (c8 >= 128 && is_match) {                           // this bit completes the byte
+      const unsigned mask = mask1;
+      G8(off1 + (rlimit & mask)) = (unsigned char)(c8 * 2 + y);
+      rlimit = (rlimit + 1) & mask;
+      const unsigned eo = off0 + 4u * (h & mask0);
+      if (ra == 0) {
+        rb = rlimit - G32(eo);
+        if (rb & mask)
+          while (ra < 255 && G8(off1 + ((rlimit - ra - 1) & mask)) == G8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+      } else ra += ra < 255;
+      G32(eo) = rlimit;
+      if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
+    }
+    Dep<Chain, 0>::update(T, arena, lane, dummy, y, p, mixw, mixrow, ssev, ssecx);
     ylast = y;
   };
 
@@ -598,8 +596,7 @@ template <class Chain, int I>
 struct Dep {
   template <int NM, int NS>
   static __device__ __forceinline__ void predict(const SpecTables& T, int lane, int c8, int& p, int w0, int w1,
-                                                 int (&mixw)[NM], unsigned (&ssev)[NS], unsigned (&ssecx)[NS],
-                                                 unsigned& cxt) {
+                                                 int (&mixw)[NM], unsigned (&ssev)[NS], unsigned (&ssecx)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_ISSE) {
@@ -631,12 +628,12 @@ struct Dep {
         p = lane == I ? val : p;
         ssecx[c.slot] += (unsigned)(pq + (wt >> 5));        // element trained in update
       }
-      Dep<Chain, I + 1>::predict(T, lane, c8, p, w0, w1, mixw, ssev, ssecx, cxt);
+      Dep<Chain, I + 1>::predict(T, lane, c8, p, w0, w1, mixw, ssev, ssecx);
     }
   }
 
   template <int NM, int NS>
-  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, int y, int p,
+  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int p,
                                                 int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&ssev)[NS],
                                                 unsigned (&ssecx)[NS]) {
     if constexpr (I < Chain::N) {
@@ -645,10 +642,9 @@ struct Dep {
         const int err = ((y * 32767 - sp_squash(T, sp_rl(p, I))) * (int)c.a4) >> 4;
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
-        if (lane < (int)c.a3) {
-          const int w = sp_clamp512k(mixw[c.slot] + ((err * pin + (1 << 12)) >> 13));
-          ((g_i32*)(arena + c.t0))[mixrow[c.slot] + lane] = w;
-        }
+        const int w = sp_clamp512k(mixw[c.slot] + ((err * pin + (1 << 12)) >> 13));
+        const unsigned wo = lane < (int)c.a3 ? (unsigned)c.t0 + 4u * (mixrow[c.slot] + (unsigned)lane) : dummy;
+        *(g_i32*)(arena + wo) = w;
       } else if constexpr (c.type == C_SSE) {
         // Predictor::train on cm[cxt]; the word is still in lane (cxt & 31) of the row registers
         const unsigned e = ssecx[c.slot];
@@ -657,9 +653,9 @@ struct Dep {
         const int err = y * 32767 - (int)(v >> 17);
         const unsigned prod = (unsigned)err * (unsigned)T.dt[count];
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
-        if (lane == 0) ((g_u32*)(arena + c.t0))[e & c.mask0] = nv;
+        *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
       }
-      Dep<Chain, I + 1>::update(T, arena, lane, y, p, mixw, mixrow, ssev, ssecx);
+      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, p, mixw, mixrow, ssev, ssecx);
     }
   }
 };

@@ -165,6 +165,7 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
+  if (ph.arena_bytes >= (1ull << 32)) { why_not = "model state of 4 GiB or more per block"; return false; }
   const CompDesc* comp = plan.comps();
   // LDS plan for the wave's region: H first, then ICM/ISSE side tables while they fit
   int lds_used = 0, h_lds = -1;
@@ -176,14 +177,18 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
        "namespace zpq_gen {\n"
        "struct Chain {\n";
   int nmix = 0, nsse = 0;
+  bool any_global_side = false, any_nonpf_gl = false;
   std::ostringstream comps;
   for (int i = 0; i < n; ++i) {
     const CompDesc& c = comp[i];
     int lds = -1, slot = -1;
     if (c.type == C_ICM || c.type == C_ISSE) {
       const int bytes = c.type == C_ICM ? 1024 : 2048;
-      if (lds_used + bytes <= kSpecWaveLdsBytes) { lds = lds_used; lds_used += bytes; }
+      if (lds_used + bytes <= kSpecWaveLdsBytes - 512) { lds = lds_used; lds_used += bytes; }   // last 512 B: dummy slots
+      else any_global_side = true;
     }
+    if (c.type == C_CM && c.mask0 < 511u && c.mask0 != 0u) any_nonpf_gl = true;
+    if (c.type == C_MIX2 && !(c.a5 == 255u && c.mask0 >= 255u) && c.mask0 != 0u) any_nonpf_gl = true;
     if (c.type == C_MIX) slot = nmix++;
     if (c.type == C_SSE) slot = nsse++;
     if (c.type == C_MIX && (c.a3 > 64 || c.a2 + c.a3 > 64)) { why_not = "MIX wider than a wavefront"; return false; }
@@ -194,6 +199,9 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
   o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ";\n"
     << "  static constexpr unsigned HMASK = " << ph.hmask << "u, MMASK = " << ph.mmask << "u;\n"
     << "  static constexpr int H_LDS = " << h_lds << ";\n"
+    << "  static constexpr bool ANY_GLOBAL_SIDE = " << (any_global_side ? "true" : "false")
+    << ", ANY_NONPF_GL = " << (any_nonpf_gl ? "true" : "false") << ";\n"
+    << "  static constexpr unsigned long long OFF_RUN = " << ph.off_run << "ull;\n"
     << "  static constexpr unsigned long long OFF_H = " << ph.off_H << "ull, OFF_M = " << ph.off_M
     << "ull, OFF_R = " << ph.off_R << "ull;\n"
     << "  static constexpr zpq::CompK comp[N] = {\n" << comps.str() << "  };\n";
