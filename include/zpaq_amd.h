@@ -140,7 +140,7 @@ int zpq_decode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
 /* Runs a tiny kernel exercising the cross-lane idioms (DPP reduction, readlane,
- * bpermute); out8[0..4] must equal {2016, 21344, 123, 2016, 133}. */
+ * bpermute); out8[0..5] must equal {2016, 21344, 123, 2016, 133, 13671}. */
 int zpq_selftest(int32_t out8[8]);
 
 /* ---- block-level drop-ins (host side + hot path) ---- */

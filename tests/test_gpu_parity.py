@@ -17,7 +17,7 @@ SIZE_LIMIT = {3: 262144, 2: 20000, 1: 2000}   # the generic kernels are fallback
 
 
 def test_cross_lane_selftest(gpu):
-    assert gpu.selftest()[:5] == [2016, 21344, 123, 2016, 133]
+    assert gpu.selftest()[:6] == [2016, 21344, 123, 2016, 133, 13671]
 
 
 def test_native_library_is_the_one_running(gpu):

@@ -149,7 +149,7 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
 // readlane, bpermute shuffles).  out[0]=wave_sum(lane) (2016), out[1]=wave_sum
 // of (lane*lane - 1000) (21344), out[2]=readlane(lane*3, 41) (123),
 // out[3]=sum of __shfl(lane, (lane+5)&63) over lanes (2016), out[4]=wave_sum
-// with only lanes < 19 contributing 7 each (133).
+// with only lanes < 19 contributing 7 each (133), out[5]=sum of wave_shr:1 of lane*7 (13671).
 __global__ void selftest_kernel(int32_t* out) {
   const int lane = threadIdx.x & 63;
   const int a = wave_sum(lane);
@@ -159,7 +159,9 @@ __global__ void selftest_kernel(int32_t* out) {
   int x = 0;
   if (lane < 19) x = 7;
   const int e = wave_sum(x);
-  if (lane == 0) { out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = e; }
+  // wave_shr:1 (used by the specialised kernel's ISSE fast path): lane i reads lane i-1, lane 0 reads 0
+  const int f = wave_sum(__builtin_amdgcn_update_dpp(0, lane * 7, 0x138, 0xF, 0xF, false));
+  if (lane == 0) { out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = e; out[5] = f; }
 }
 
 // ------------------------------------------------------------ launch glue

@@ -131,6 +131,36 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr bool mix_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u; }
 constexpr bool sse_pf(const CompK& c) { return c.mask0 >= 32u * 256u - 1u; }
 
+// 24-bit multiply-add (v_mad_i32_i24): exact whenever both factors fit in 24 signed bits, and the
+// low 32 bits of the product wrap exactly like a 32-bit multiply
+__device__ __forceinline__ int sp_mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+// value of the lane to the left (lane 0 receives 0): DPP wave_shr:1
+__device__ __forceinline__ int sp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+
+// ISSE fast path: every ISSE takes its input from the lane on its left, and that lane is a
+// context-only component or another ISSE.  Then all ISSE chains of the model are resolved together
+// by DEPTH rounds of (shift right one lane, multiply-add, clamp) instead of one round per component.
+template <class Chain>
+constexpr bool isse_left_fed() {
+  for (int i = 0; i < Chain::N; ++i) {
+    if (Chain::comp[i].type != C_ISSE) continue;
+    if (i == 0 || Chain::comp[i].a2 != (unsigned)(i - 1)) return false;
+    const unsigned t = Chain::comp[i - 1].type;
+    if (!(t == C_CONS || t == C_CM || t == C_ICM || t == C_MATCH || t == C_ISSE)) return false;
+  }
+  return true;
+}
+template <class Chain>
+constexpr int isse_depth() {
+  int best = 0, run = 0;
+  for (int i = 0; i < Chain::N; ++i) {
+    run = Chain::comp[i].type == C_ISSE ? run + 1 : 0;
+    if (run > best) best = run;
+  }
+  return best;
+}
+
 // lanes (components) of a given type, as a compile-time bit mask
 template <class Chain>
 constexpr unsigned long long type_mask(unsigned t) {
@@ -223,6 +253,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     else return (g_u32*)(arena + Chain::OFF_H);
   }();
 
+  constexpr bool kIsseFast = isse_left_fed<Chain>();
+  constexpr int kIsseDepth = isse_depth<Chain>();
   // ---- lane classes (compile-time masks over the chain) ----
   constexpr unsigned long long M_CM = type_mask<Chain>(C_CM), M_ICM = type_mask<Chain>(C_ICM),
                                M_ISSE = type_mask<Chain>(C_ISSE), M_MATCH = type_mask<Chain>(C_MATCH),
@@ -432,8 +464,20 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     p = (is_icm || is_cm || m_on) ? st : (is_match ? 0 : p);
     v0 = has_row ? q0 : gw;
     v1 = q1;
-    // (E) dependent components, in index order, unrolled with literal lanes
-    Dep<Chain, 0>::predict(T, lane, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx);
+    // (E) dependent components.  ISSE chains first, all at once, when every ISSE is fed by its left
+    //     neighbour; then the rest in index order, unrolled with literal lanes.  `lane_o` is the lane
+    //     id made opaque so that the "lane == I" merges are two cheap VALU ops per step instead of
+    //     loop-invariant SGPR masks that spill.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    if constexpr (kIsseFast) {
+#pragma unroll
+      for (int it = 0; it < kIsseDepth; ++it) {
+        const int val = sp_clamp2k(sp_mad24((int)v0, sp_shr1(p), (int)v1 * 64) >> 16);
+        p = is_isse ? val : p;
+      }
+    }
+    Dep<Chain, 0>::predict(T, lane_o, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx);
     pf_valid = more;
     const unsigned prr = sp_uni((unsigned)sp_squash(T, sp_rl(p, N - 1)));
 #ifdef ZPQ_PROF
@@ -445,8 +489,22 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   // ----------------------------------------------------------------- update
   auto update = [&](int y) __attribute__((always_inline)) {
     const int slot = hmap4 & 15;
-    const int pj = __shfl(p, (int)(a2 & 63));     // ISSE j / MIX2 j
-    const int pk = __shfl(p, (int)(a3 & 63));     // MIX2 k
+    // inputs that live in other lanes: ISSE needs p[j]; MIX2 needs p[j] - p[k]
+    int pj, pdiff = 0;
+    if constexpr (kIsseFast) pj = sp_shr1(p);
+    else pj = __shfl(p, (int)(a2 & 63));
+    {
+      int lane_u = lane;
+      asm volatile("" : "+v"(lane_u));
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+        if constexpr (c.type == C_MIX2) {
+          const int d = sp_rl(p, (int)c.a2) - sp_rl(p, (int)c.a3);
+          pdiff = lane_u == i ? d : pdiff;
+        }
+      });
+    }
     // every lane's LDS lookups, issued together
     const int sq = sp_squash(T, sp_clamp2k(p));
     const unsigned nsv = T.ns[(bh & 255u) * 4u + (unsigned)y];
@@ -457,7 +515,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
     row_set(row0, row1, row2, row3, slot, nsv);
     const unsigned n0 = is_icm ? v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2)
-                               : (unsigned)sp_clamp512k((int)v0 + ((err * pj + (1 << 12)) >> 13));
+                               : (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13));
     const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
     const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
     const unsigned el = side_global ? 0u : e0;
@@ -468,9 +526,9 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     }
     // per-bit global word: CM (Predictor::train) or MIX2 weight; idle lanes write their dummy
     const int errcm = yq - (int)(v0 >> 17);
-    const unsigned cm_new = v0 + (((unsigned)errcm * dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
-    const int err2 = (err * (int)a4) >> 5;
-    const int w2 = min(max((int)v0 + ((err2 * (pj - pk) + (1 << 12)) >> 13), 0), 65535);
+    const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+    const int err2 = __mul24(err, (int)a4) >> 5;
+    const int w2 = min(max((int)v0 + ((err2 * pdiff + (1 << 12)) >> 13), 0), 65535);
     const unsigned gnew = is_cm ? cm_new : (unsigned)w2;
     G32(goff + 4u * gidx) = gnew;
     rw = gnew;
@@ -600,9 +658,11 @@ struct Dep {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_ISSE) {
-        const int pj = sp_rl(p, (int)c.a2);
-        const int val = sp_clamp2k((w0 * pj + w1 * 64) >> 16);
-        p = lane == I ? val : p;
+        if constexpr (!isse_left_fed<Chain>()) {
+          const int pj = sp_rl(p, (int)c.a2);
+          const int val = sp_clamp2k(sp_mad24(w0, pj, w1 * 64) >> 16);
+          p = lane == I ? val : p;
+        }
       } else if constexpr (c.type == C_AVG) {
         const int pj = sp_rl(p, (int)c.a1), pk = sp_rl(p, (int)c.a2);
         const int val = (pj * (int)c.a3 + pk * (256 - (int)c.a3)) >> 8;
@@ -615,7 +675,7 @@ struct Dep {
         // inputs p[j..j+m-1] sit in lanes j..j+m-1; weight t sits in lane t
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
-        const int x = lane < (int)c.a3 ? (mixw[c.slot] >> 8) * pin : 0;
+        const int x = lane < (int)c.a3 ? __mul24(mixw[c.slot] >> 8, pin) : 0;
         const int val = sp_clamp2k(sp_wave_sum(x) >> 8);
         p = lane == I ? val : p;
       } else if constexpr (c.type == C_SSE) {
@@ -642,7 +702,7 @@ struct Dep {
         const int err = ((y * 32767 - sp_squash(T, sp_rl(p, I))) * (int)c.a4) >> 4;
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
-        const int w = sp_clamp512k(mixw[c.slot] + ((err * pin + (1 << 12)) >> 13));
+        const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, pin, 1 << 12) >> 13));
         const unsigned wo = lane < (int)c.a3 ? (unsigned)c.t0 + 4u * (mixrow[c.slot] + (unsigned)lane) : dummy;
         *(g_i32*)(arena + wo) = w;
       } else if constexpr (c.type == C_SSE) {
