@@ -114,7 +114,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU")
     ap.add_argument("--block-bytes", type=int, default=1 << 20)
     ap.add_argument("--kind", default="text")
@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
     ap.add_argument("--verify-bytes", type=int, default=32768)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--distribute", action="store_true",
+                    help="N>1: rank 0 generates the whole corpus and scatters it over RCCL; coded blocks are gathered back "
+                         "(timed separately as dist_ms; the hot path itself has no collective)")
     a = ap.parse_args()
 
     import torch
@@ -142,7 +145,18 @@ def main():
     z.set_kernel(a.kernel)
 
     nb, bs = a.blocks, a.block_bytes
-    blocks = make_corpus(a.kind, nb, bs, first=rank * nb)
+    dist_ms = {}
+    if a.distribute and world > 1:
+        from zpaq_amd import dist as zd
+        full = make_corpus(a.kind, nb * world, bs, first=0) if rank == 0 else None
+        zd.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        mine = zd.scatter_blocks(full, nb * world, bs)
+        torch.cuda.synchronize(); zd.barrier()
+        dist_ms["scatter"] = (time.perf_counter() - t0) * 1e3
+        blocks = mine.cpu().numpy()
+        del full
+    else:
+        blocks = make_corpus(a.kind, nb, bs, first=rank * nb)
 
     # one plan per distinct header; the headline text corpus has exactly one
     headers = {}
@@ -221,6 +235,16 @@ def main():
 
     res = d_res.cpu().numpy()
     out_len, status = res[:, 0].astype(np.int64), res[:, 2]
+    if a.distribute and world > 1:
+        from zpaq_amd import dist as zd
+        host_out = d_out.cpu().numpy()
+        mine_coded = [host_out[i, :int(out_len[i])].tobytes() for i in range(nb)]
+        zd.barrier(); t0 = time.perf_counter()
+        allc = zd.gather_archives(mine_coded)
+        zd.barrier()
+        dist_ms["gather"] = (time.perf_counter() - t0) * 1e3
+        if rank == 0:
+            assert len(allc) == nb * world
     ok = bool((status == 0).all())
     coded_total = int(out_len.sum())
 
@@ -255,6 +279,19 @@ def main():
                 verified += int(good)
                 ok = ok and good
 
+    # which kernel coded the blocks (3 = per-header specialised, 2 = generic wave, 1 = generic one-lane)
+    note = C.create_string_buffer(512)
+    kinds = sorted({int(L.zpq_plan_kernel_kind(pl._h, note, 512)) for pl, _ in groups})
+    kname = {3: "zpq_spec_" + "encode", 2: "code_wave_kernel<encode>", 1: "code_serial_kernel<encode>"}.get(kinds[-1], "?")
+    # HBM traffic per launch from the committed rocprofv3 PMC passes, when this exact workload was profiled
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"method {a.method} x {nb} x {bs} {a.kind}"
+        if key in tj and tj[key]["kernel"] == kname:
+            traffic = tj[key]["traffic_bytes"]
+    except Exception:
+        pass
     total_bytes = float(nb) * bs * world * a.steps
     value = total_bytes / 1e6 / elapsed
     code_s = code_ms / 1e3 / max(a.steps, 1)          # coding-kernel time per step (this rank)
@@ -272,10 +309,11 @@ def main():
         "ratio": coded_total / (float(nb) * bs) if nb else None,
         "all_status_ok": ok, "roundtrip_verified_blocks": verified,
         "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
+        "dist_ms": dist_ms or None,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "code_wave_kernel<encode>" if a.kernel != 1 else "code_serial_kernel<encode>",
-                     "algo_bytes_per_launch": algo_bytes},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": kname, "kernel_origin": note.value.decode(errors="replace"),
+                     "algo_bytes_per_launch": algo_bytes, "kernel_s_per_launch": code_s},
     }
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         base, ref_lens = cpu_baseline(blocks, a.method, a.cpu_seconds)

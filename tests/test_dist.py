@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the N > 1 path of the framework -- block sharding, scatter of the
+corpus, gather of variable-length archives in block order, max-over-ranks timing.  The coder is
+replaced by a stand-in (zlib) because there is no GPU here; what is tested is exactly what runs
+between ranks on the 8-GPU node."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def test_shard_range_covers_everything():
+    from zpaq_amd.dist import shard_range
+    for nb in (0, 1, 7, 8, 1024, 8191):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(nb, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == nb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, zlib, time
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["ZROOT"])
+    from zpaq_amd import corpus, dist as zd
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    NB, BS = 7, 3000                       # odd count: ranks get different numbers of blocks
+    blocks = corpus.corpus("text", NB, BS) if rank == 0 else None
+    mine = zd.scatter_blocks(blocks, NB, BS)
+    b, e = zd.shard_range(NB, rank, world)
+    assert mine.shape == (e - b, BS)
+    ref = corpus.corpus("text", NB, BS)[b:e]
+    assert (mine.numpy() == ref).all(), "scatter delivered the wrong slice"
+    archives = [zlib.compress(row.tobytes()) + bytes([rank]) * (i + 1) for i, row in enumerate(mine.numpy())]
+    zd.barrier()
+    t = zd.max_over_ranks(0.5 + rank)
+    assert abs(t - (world - 0.5)) < 1e-9
+    got = zd.gather_archives(archives)
+    if rank == 0:
+        assert len(got) == NB
+        full = corpus.corpus("text", NB, BS)
+        k = 0
+        for r in range(world):
+            rb, re = zd.shard_range(NB, r, world)
+            for i in range(re - rb):
+                a = got[k]
+                tail = i + 1
+                assert a[-tail:] == bytes([r]) * tail
+                assert zlib.decompress(a[:-tail]) == full[k].tobytes(), "archives out of block order"
+                k += 1
+        print("RANK0_OK")
+    else:
+        assert got is None
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_scatter_gather_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ZROOT=ROOT, GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
+    assert "RANK0_OK" in outs[0]
