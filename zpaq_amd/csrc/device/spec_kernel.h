@@ -547,21 +547,54 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       G32(eo) = rlimit;
       if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
     }
-    Dep<Chain, 0>::update(T, arena, lane, dummy, y, p, mixw, mixrow, ssev, ssecx);
+    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx);
     ylast = y;
+  };
+
+  // The ENCODER knows the byte before it codes it, so it runs HCOMP one byte ahead: at the start of
+  // byte k it already computes the contexts of byte k+1 and touches the lines byte k+1 will probe
+  // first (hash rows of the first nibble, bit-0 MIX/SSE rows, CM line), which hides the only HBM
+  // round trip left exposed per byte.  The decoder cannot (the byte is its output).
+  unsigned h_next = 0, ka0 = 0, ka1 = 0, ka2 = 0;
+  auto run_ahead = [&](int ch) __attribute__((always_inline)) -> int {
+    asm volatile("" ::"v"(ka0), "v"(ka1), "v"(ka2));
+    SP_PROF_BEGIN
+    const int e = Chain::hcomp((unsigned)ch, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    SP_PROF_END(2)
+    if (e) return e;
+    h_next = vm_H[(unsigned)lane & Chain::HMASK];
+    const unsigned cx = h_next + 16u;
+    ka0 = G32(roff + ((cx * 16u) & (rmask - 15u)));
+    ka1 = G32(goff + 4u * ((is_cm ? (h_next ^ 1u) : (h_next + (1u & a5))) & gmask));
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_MIX) {
+        const unsigned r = ((sp_rlu(h_next, i) + (1u & c.a5)) & c.mask0) * c.a3;
+        ka2 ^= G32((unsigned)c.t0 + 4u * (r + (unsigned)min(lane, (int)c.a3 - 1)));
+      } else if constexpr (c.type == C_SSE) {
+        const unsigned cx0 = ((sp_rlu(h_next, i) + 1u) * 32u) & c.mask0;
+        ka2 ^= G32((unsigned)c.t0 + 4u * (cx0 + (unsigned)(lane & 31)));
+      }
+    });
+    return 0;
   };
 
   auto after_bit = [&](int y) __attribute__((always_inline)) -> int {   // c8 / hmap4 bookkeeping (libzpaq.cpp:2055-2065)
     { SP_PROF_BEGIN update(y); SP_PROF_END(1) }
     c8 += c8 + y;
     if (c8 >= 256) {
-      SP_PROF_BEGIN
-      const int e = Chain::hcomp((unsigned)(c8 - 256), vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
-      SP_PROF_END(2)
-      if (e) return e;
+      if constexpr (DEC) {
+        SP_PROF_BEGIN
+        const int e = Chain::hcomp((unsigned)(c8 - 256), vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+        SP_PROF_END(2)
+        if (e) return e;
+        h = vm_H[(unsigned)lane & Chain::HMASK];
+      } else {
+        h = h_next;            // computed by run_ahead() when this byte started
+      }
       hmap4 = 1;
       c8 = 1;
-      h = vm_H[(unsigned)lane & Chain::HMASK];
     } else if (c8 >= 16 && c8 < 32) {
       hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
     } else {
@@ -585,6 +618,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     };
     for (unsigned k = 0; k < job.in_len && !status; ++k) {
       const int ch = (int)sp_uni(in_ptr[k]);
+      status = run_ahead(ch);
+      if (status) break;
       encode(0, 0);
       for (int i = 7; i >= 0; --i) {
         unsigned pr;
@@ -693,13 +728,13 @@ struct Dep {
   }
 
   template <int NM, int NS>
-  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int p,
+  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int sq, int p,
                                                 int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&ssev)[NS],
                                                 unsigned (&ssecx)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_MIX) {
-        const int err = ((y * 32767 - sp_squash(T, sp_rl(p, I))) * (int)c.a4) >> 4;
+        const int err = ((y * 32767 - sp_rl(sq, I)) * (int)c.a4) >> 4;   // sq = squash(p) of every lane, computed once
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
         const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, pin, 1 << 12) >> 13));
@@ -715,7 +750,7 @@ struct Dep {
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
         *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
       }
-      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, p, mixw, mixrow, ssev, ssecx);
+      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx);
     }
   }
 };
