@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
     ap.add_argument("--verify-bytes", type=int, default=32768)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
+                    help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
     ap.add_argument("--distribute", action="store_true",
                     help="N>1: rank 0 generates the whole corpus and scatters it over RCCL; coded blocks are gathered back "
                          "(timed separately as dist_ms; the hot path itself has no collective)")
@@ -235,6 +237,50 @@ def main():
 
     res = d_res.cpu().numpy()
     out_len, status = res[:, 0].astype(np.int64), res[:, 2]
+    dec_info = None
+    if a.mode == "decode":
+        # append the container's 4-zero terminator to every coded payload, then time the decoder
+        lens_t = torch.from_numpy(out_len.astype(np.int64)).to(dev)
+        colz = torch.arange(4, device=dev)[None, :] + lens_t[:, None]
+        d_out.scatter_(1, colz, torch.zeros((nb, 4), dtype=torch.uint8, device=dev))
+        back = torch.empty((nb, stride_in), dtype=torch.uint8, device=dev)
+        r2 = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
+
+        def dstep():
+            tot = 0.0
+            for plan, idx in groups:
+                run = [idx[0]]
+                for i in idx[1:] + [None]:
+                    if i is not None and i == run[-1] + 1:
+                        run.append(i)
+                        continue
+                    n = len(run)
+                    io = (C.c_uint64 * n)(*[int(j) * stride_out for j in run])
+                    il = (C.c_uint32 * n)(*[int(out_len[j]) + 4 for j in run])
+                    oo = (C.c_uint64 * n)(*[int(j) * stride_in for j in run])
+                    oc = (C.c_uint32 * n)(*[bs + 8] * n)
+                    rc = L.zpq_decode_device(plan._h, C.c_void_p(d_out.data_ptr()), io, il, n, C.c_void_p(back.data_ptr()),
+                                             oo, oc, C.c_void_p(r2.data_ptr() + 16 * int(run[0])), None, 1)
+                    if rc:
+                        raise RuntimeError(L.zpq_last_error().decode())
+                    tot += z.last_timing()[1]
+                    run = [i]
+            return tot
+
+        sync_all()
+        td0 = time.perf_counter()
+        dcode_ms = 0.0
+        for _ in range(a.steps):
+            dcode_ms += dstep()
+        sync_all()
+        delapsed = time.perf_counter() - td0
+        if world > 1:
+            from zpaq_amd import dist as zd
+            delapsed = zd.max_over_ranks(delapsed)
+        r2h = r2.cpu().numpy()
+        dec_ok = bool((r2h[:, 2] == 0).all() and (r2h[:, 0] == bs + 1).all() and
+                      bool((back[:, :bs + 1] == d_in[:, :bs + 1]).all()))
+        dec_info = {"elapsed": delapsed, "code_ms": dcode_ms, "ok": dec_ok}
     if a.distribute and world > 1:
         from zpaq_amd import dist as zd
         host_out = d_out.cpu().numpy()
@@ -293,11 +339,16 @@ def main():
     except Exception:
         pass
     total_bytes = float(nb) * bs * world * a.steps
+    if dec_info:
+        elapsed, code_ms, ok = dec_info["elapsed"], dec_info["code_ms"], ok and dec_info["ok"]
+        kname = kname.replace("encode", "decode")
+        traffic = None
     value = total_bytes / 1e6 / elapsed
     code_s = code_ms / 1e3 / max(a.steps, 1)          # coding-kernel time per step (this rank)
     achieved = algo_bytes / 1e9 / code_s if code_s > 0 else 0.0
     line = {
-        "metric": "compress MB/s + bit-identical ratio, -m5 over 1024x1 MiB blocks",
+        "metric": ("compress" if a.mode == "encode" else "decompress") +
+                  " MB/s + bit-identical ratio, -m5 over 1024x1 MiB blocks",
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""North-star sweep (BASELINE.json): MB/s on highly compressible and random blocks from 64 KiB up,
+plus the mixed corpus of config 4 and the decode-only leg of config 5, one MI355X.  Runs bench.py
+repeatedly and writes one JSON line per point to the given file.
+
+    python profiles/sweep.py gpurun_out/sweep.jsonl [--max-mib 4]
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--warmup", "0"] + args
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
+    if not lines:
+        return {"error": r.stderr[-500:], "args": args}
+    j = json.loads(lines[-1])
+    return {"args": " ".join(args), "MBps": round(j["value"], 2), "kernel_MBps": round(
+        j["config"]["blocks_per_gpu"] * j["config"]["block_bytes"] / 1e3 / j["kernel_ms"]["code"], 2),
+        "ratio": j["ratio"], "ok": j["all_status_ok"], "verified": j["roundtrip_verified_blocks"],
+        "ncomp": j["config"]["ncomp"], "state_GiB": round(j["config"]["state_GiB_per_gpu"], 1),
+        "roofline_frac": round(j["roofline"]["frac"], 4), "kernel": j["roofline"]["kernel"]}
+
+
+def main():
+    out = sys.argv[1]
+    max_mib = float(sys.argv[sys.argv.index("--max-mib") + 1]) if "--max-mib" in sys.argv else 4
+    pts = []
+    for kind in ("zeros", "lcg", "pattern"):
+        for kib, blocks in ((64, 1024), (256, 1024), (1024, 512), (4096, 256), (16384, 64)):
+            if kib / 1024 > max_mib:
+                continue
+            pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
+    pts.append(["--kind", "mixed", "--blocks", "1024", "--block-bytes", str(256 * 1024)])      # config 4 shape
+    pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--mode", "decode"])   # config 5
+    pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--method", "4"])
+    with open(out, "w") as fh:
+        for p in pts:
+            res = run(p)
+            fh.write(json.dumps(res) + "\n")
+            fh.flush()
+            print(res, flush=True)
+
+
+if __name__ == "__main__":
+    main()
