@@ -181,35 +181,27 @@ def main():
     d_res = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
     L = z.lib()
 
-    def launch(plan, idx, decode=False, src=None, src_len=None, dst=None, dst_cap=None, res=None):
-        n = len(idx)
-        io = (C.c_uint64 * n)(*[int(i) * (stride_out if decode else stride_in) for i in idx])
-        il = (C.c_uint32 * n)(*([bs + 1] * n if src_len is None else src_len))
-        oo = (C.c_uint64 * n)(*[int(i) * (stride_in if decode else stride_out) for i in idx])
-        oc = (C.c_uint32 * n)(*([cap] * n if dst_cap is None else dst_cap))
-        r = res if res is not None else d_res
-        res_ptr = r.data_ptr() + 16 * int(idx[0]) if res is None else r.data_ptr()
-        fn = L.zpq_decode_device if decode else L.zpq_encode_device
-        rc = fn(plan._h, C.c_void_p((src if src is not None else d_in).data_ptr()), io, il, n,
-                C.c_void_p((dst if dst is not None else d_out).data_ptr()), oo, oc, C.c_void_p(res_ptr), None, 1)
-        if rc:
-            raise RuntimeError(L.zpq_last_error().decode())
-        return z.last_timing()
+    # one plan pointer per block: the engine groups blocks by plan and runs the groups concurrently
+    plan_of = [None] * nb
+    for pl, idx in groups:
+        for i in idx:
+            plan_of[i] = pl
+    PA = (C.c_void_p * nb)(*[p._h for p in plan_of])
+    IO = (C.c_uint64 * nb)(*[i * stride_in for i in range(nb)])
+    IL = (C.c_uint32 * nb)(*[bs + 1] * nb)
+    OO = (C.c_uint64 * nb)(*[i * stride_out for i in range(nb)])
+    OC = (C.c_uint32 * nb)(*[cap] * nb)
+    L.zpq_code_device_multi.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_int]
 
     def step():
-        init_ms = code_ms = 0.0
-        for plan, idx in groups:
-            # blocks of one plan are contiguous runs in practice; launch per contiguous run
-            run = [idx[0]]
-            for i in idx[1:] + [None]:
-                if i is not None and i == run[-1] + 1:
-                    run.append(i)
-                    continue
-                t = launch(plan, run)
-                init_ms += t[0]
-                code_ms += t[1]
-                run = [i]
-        return init_ms, code_ms
+        rc = L.zpq_code_device_multi(0, PA, C.c_void_p(d_in.data_ptr()), IO, IL, nb, C.c_void_p(d_out.data_ptr()),
+                                     OO, OC, C.c_void_p(d_res.data_ptr()), None, 1)
+        if rc:
+            raise RuntimeError(L.zpq_last_error().decode())
+        t = z.last_timing()
+        return t[0], t[1]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -246,26 +238,15 @@ def main():
         back = torch.empty((nb, stride_in), dtype=torch.uint8, device=dev)
         r2 = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
 
+        DIL = (C.c_uint32 * nb)(*[int(out_len[j]) + 4 for j in range(nb)])
+        DOC = (C.c_uint32 * nb)(*[bs + 8] * nb)
+
         def dstep():
-            tot = 0.0
-            for plan, idx in groups:
-                run = [idx[0]]
-                for i in idx[1:] + [None]:
-                    if i is not None and i == run[-1] + 1:
-                        run.append(i)
-                        continue
-                    n = len(run)
-                    io = (C.c_uint64 * n)(*[int(j) * stride_out for j in run])
-                    il = (C.c_uint32 * n)(*[int(out_len[j]) + 4 for j in run])
-                    oo = (C.c_uint64 * n)(*[int(j) * stride_in for j in run])
-                    oc = (C.c_uint32 * n)(*[bs + 8] * n)
-                    rc = L.zpq_decode_device(plan._h, C.c_void_p(d_out.data_ptr()), io, il, n, C.c_void_p(back.data_ptr()),
-                                             oo, oc, C.c_void_p(r2.data_ptr() + 16 * int(run[0])), None, 1)
-                    if rc:
-                        raise RuntimeError(L.zpq_last_error().decode())
-                    tot += z.last_timing()[1]
-                    run = [i]
-            return tot
+            rc = L.zpq_code_device_multi(1, PA, C.c_void_p(d_out.data_ptr()), OO, DIL, nb, C.c_void_p(back.data_ptr()),
+                                         IO, DOC, C.c_void_p(r2.data_ptr()), None, 1)
+            if rc:
+                raise RuntimeError(L.zpq_last_error().decode())
+            return z.last_timing()[1]
 
         sync_all()
         td0 = time.perf_counter()
@@ -298,32 +279,28 @@ def main():
     verified = 0
     nv = min(a.verify_blocks, nb)
     if ok and nv:
-        for plan, idx in groups:
-            vi = [i for i in idx if i < nv]
-            if not vi or vi != list(range(vi[0], vi[0] + len(vi))):
-                continue
-            coded = d_out[vi[0]:vi[0] + len(vi)].clone()
-            lens = [int(out_len[i]) for i in vi]
-            for k, ln in enumerate(lens):           # append the 4-zero terminator the container adds
-                coded[k, ln:ln + 4] = 0
-            back = torch.empty((len(vi), stride_in), dtype=torch.uint8, device=dev)
-            r2 = torch.zeros((len(vi), 4), dtype=torch.int32, device=dev)
-            n = len(vi)
-            io = (C.c_uint64 * n)(*[k * stride_out for k in range(n)])
-            il = (C.c_uint32 * n)(*[ln + 4 for ln in lens])
-            oo = (C.c_uint64 * n)(*[k * stride_in for k in range(n)])
-            vb = min(bs, a.verify_bytes) + 1      # "decode first k bytes" (Decompresser::decompress(n))
-            oc = (C.c_uint32 * n)(*[vb if vb < bs + 1 else bs + 8] * n)
-            rc = L.zpq_decode_device(plan._h, C.c_void_p(coded.data_ptr()), io, il, n, C.c_void_p(back.data_ptr()),
-                                     oo, oc, C.c_void_p(r2.data_ptr()), None, 0)
-            torch.cuda.synchronize()
-            if rc:
-                raise RuntimeError(L.zpq_last_error().decode())
-            r2h = r2.cpu().numpy()
-            for k, i in enumerate(vi):
-                good = r2h[k, 2] == 0 and r2h[k, 0] == vb and bool((back[k, :vb] == d_in[i, :vb]).all())
-                verified += int(good)
-                ok = ok and good
+        vb = min(bs, a.verify_bytes) + 1      # "decode first k bytes" (Decompresser::decompress(n))
+        coded = d_out[:nv].clone()
+        lens = [int(out_len[i]) for i in range(nv)]
+        for k, ln in enumerate(lens):           # append the 4-zero terminator the container adds
+            coded[k, ln:ln + 4] = 0
+        back = torch.empty((nv, stride_in), dtype=torch.uint8, device=dev)
+        r2 = torch.zeros((nv, 4), dtype=torch.int32, device=dev)
+        vPA = (C.c_void_p * nv)(*[plan_of[i]._h for i in range(nv)])
+        vio = (C.c_uint64 * nv)(*[k * stride_out for k in range(nv)])
+        vil = (C.c_uint32 * nv)(*[ln + 4 for ln in lens])
+        voo = (C.c_uint64 * nv)(*[k * stride_in for k in range(nv)])
+        voc = (C.c_uint32 * nv)(*[vb if vb < bs + 1 else bs + 8] * nv)
+        rc = L.zpq_code_device_multi(1, vPA, C.c_void_p(coded.data_ptr()), vio, vil, nv, C.c_void_p(back.data_ptr()),
+                                     voo, voc, C.c_void_p(r2.data_ptr()), None, 0)
+        torch.cuda.synchronize()
+        if rc:
+            raise RuntimeError(L.zpq_last_error().decode())
+        r2h = r2.cpu().numpy()
+        for k in range(nv):
+            good = r2h[k, 2] == 0 and r2h[k, 0] == vb and bool((back[k, :vb] == d_in[k, :vb]).all())
+            verified += int(good)
+            ok = ok and good
 
     # which kernel coded the blocks (3 = per-header specialised, 2 = generic wave, 1 = generic one-lane)
     note = C.create_string_buffer(512)

@@ -136,6 +136,12 @@ int zpq_decode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in
                       const uint32_t* in_len, uint32_t nblocks, void* d_out,
                       const uint64_t* out_off, const uint32_t* max_out,
                       zpq_block_result* d_res, void* stream, int timed);
+/* Same, with one plan PER BLOCK (plans[b]): blocks are grouped by plan internally and the groups
+ * run concurrently on side streams; results keep the caller's block order.  decode = 0 / 1. */
+int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* d_in,
+                          const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks,
+                          void* d_out, const uint64_t* out_off, const uint32_t* cap,
+                          zpq_block_result* d_res, void* stream, int timed);
 /* Durations (ms, hipEvent) of the last timed call on this process: Predictor
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run(args):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--warmup", "0"] + args
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
     if not lines:
         return {"error": r.stderr[-500:], "args": args}

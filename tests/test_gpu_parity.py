@@ -201,3 +201,19 @@ def test_zeros_known_answers(gpu):
     a64, a1m = gpu.compress_blocks([np.zeros(65536, np.uint8), np.zeros(1 << 20, np.uint8)], "5")
     assert len(a64) == 317 and hashlib.sha1(a64).hexdigest() == "071deeac62e6fc28932fe84d52c26b7b6debe788"
     assert len(a1m) == 341 and hashlib.sha1(a1m).hexdigest() == "33f41ec44b376e492954d759ddd560f07ee7734b"
+
+
+def test_decode_reference_archives_with_preprocessing(gpu):
+    """Reference archives of methods 3 and 4 (LZ77 / BWT / E8E9 pre-processing + a context model):
+    the model is decoded on the GPU, the PCOMP program from the archive is run on the host."""
+    if not have_ref():
+        pytest.skip("oracle/_ref not present")
+    from oracle.oracle_py import Ref
+    ref = Ref()
+    parts, stream = [], b""
+    for kind, n, m in [("lcg", 40000, "3"), ("text", 60000, "3"), ("text", 50000, "3,128,1"), ("records", 30000, "4,30,0"),
+                       ("text", 30000, "4,128,3"), ("pattern", 20000, "3,200,2")]:
+        d = corpus.block(kind, n, 99)
+        parts.append(d.tobytes())
+        stream += ref.compress_block(d, m)
+    assert gpu.decompress(stream) == b"".join(parts)

@@ -157,3 +157,17 @@ def test_stored_blocks_are_host_only_and_bit_exact(zlib_, golden):
     a = zlib_.compress_block(gen_input(e), "0", e["filename"], e["comment"])
     assert len(a) == e["len"] and hashlib.sha1(a).hexdigest() == e["sha1"]
     assert zlib_.decompress(a) == gen_input(e).tobytes()
+
+
+def test_pcomp_postprocessing_decodes_reference_lz77_archives(zlib_, ref):
+    """Methods 0/1/2 have no model (n = 0): the whole decode path -- container scan, stored framing,
+    PCOMP post-processor running the LZ77 / E8E9 programs carried in the archive -- is host work."""
+    for kind, n in [("text", 150000), ("zeros", 65536), ("lcg", 30000), ("records", 60000), ("text", 0), ("text", 1)]:
+        d = corpus.block(kind, n, 321)
+        for m in ["1", "2", "1,200,1", "2,128,3", "1,60,2", "0"]:
+            a = ref.compress_block(d, m)
+            assert zlib_.decompress(a) == d.tobytes(), (kind, n, m)
+    # several blocks / methods in one stream
+    parts = [corpus.block("text", 5000, 1), corpus.block("pattern", 7000, 2), corpus.block("lcg", 100, 3)]
+    stream = b"".join(ref.compress_block(p, m) for p, m in zip(parts, ["1", "2", "0"]))
+    assert zlib_.decompress(stream) == b"".join(p.tobytes() for p in parts)

@@ -125,7 +125,7 @@ int zpq_encode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in
                       zpq_block_result* d_res, void* stream, int timed) {
   ZPQ_TRY
   if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
-  engine_code_device(false, plan, d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, (BlockResult*)d_res,
+  engine_code_device(false, &plan, true, d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, (BlockResult*)d_res,
                      stream, timed != 0);
   return ZPQ_OK;
   ZPQ_CATCH
@@ -136,7 +136,19 @@ int zpq_decode_device(const zpq_plan* plan, const void* d_in, const uint64_t* in
                       zpq_block_result* d_res, void* stream, int timed) {
   ZPQ_TRY
   if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
-  engine_code_device(true, plan, d_in, in_off, in_len, nblocks, d_out, out_off, max_out, (BlockResult*)d_res,
+  engine_code_device(true, &plan, true, d_in, in_off, in_len, nblocks, d_out, out_off, max_out, (BlockResult*)d_res,
+                     stream, timed != 0);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* d_in, const uint64_t* in_off,
+                          const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
+                          const uint32_t* cap, zpq_block_result* d_res, void* stream, int timed) {
+  ZPQ_TRY
+  for (uint32_t b = 0; b < nblocks; ++b)
+    if (!plans[b] || plans[b]->hdr().n == 0) fail(ZPQ_E_ARG, "needs modelled plans");
+  engine_code_device(decode != 0, plans, false, d_in, in_off, in_len, nblocks, d_out, out_off, cap, (BlockResult*)d_res,
                      stream, timed != 0);
   return ZPQ_OK;
   ZPQ_CATCH

@@ -50,11 +50,17 @@ struct Engine {
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
   int last_kind = 0;
+  int jit_left = 0;                    // hipRTC compilations still allowed in the current call
 };
 
 Engine& eng() {
   static Engine e;
   return e;
+}
+
+int jit_budget() {
+  if (const char* v = getenv("ZPAQ_AMD_MAX_JIT")) return atoi(v);
+  return 4;
 }
 
 void require_ready(Engine& e) {
@@ -159,7 +165,15 @@ static int kernel_kind(Engine& e, const zpq_plan* plan) {
     return 1;
   }
   if (want == 2) return 2;
-  if (spec_kernel_for(p)) return 3;
+  // Each unseen header costs a ~2-4 s hipRTC compile.  A batch whose blocks all carry different
+  // (data-dependent) chains must not spend minutes compiling: a few per call, the rest run on the
+  // generic wave kernel this time and are picked up by later calls.
+  bool did = false;
+  if (spec_kernel_for(p, want == 3 || e.jit_left > 0, nullptr, &did)) {
+    if (did && e.jit_left > 0) --e.jit_left;
+    return 3;
+  }
+  if (did && e.jit_left > 0) --e.jit_left;
   if (want == 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
   return 2;
 }
@@ -169,6 +183,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note) {
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
+  e.jit_left = jit_budget();
   const int k = kernel_kind(e, p);
   note = p->spec_note;
   return k;
@@ -215,9 +230,10 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     const LaunchGroup& g = groups[gi];
     hipStream_t gs = (nside && gi % (nside + 1)) ? e.side[gi % (nside + 1) - 1] : st;
     if (gs != st && gi <= nside) HIP_CHECK(hipStreamWaitEvent(gs, fork, 0));
-    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
-    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
-    else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res + g.first, g.count, e.d_tables, gs));
+    // every kernel writes res[job.res_slot] relative to the SAME results base
+    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
+    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
+    else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
   }
   for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
     hipEvent_t done;
@@ -246,6 +262,7 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
   const size_t nb = blocks.size();
+  e.jit_left = jit_budget();
   results.assign(nb, BlockResult{0, 0, 0, 0});
   size_t pos = 0;
   e.last = Timing{};
@@ -303,6 +320,7 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
       j.out = (uint8_t*)e.io_out.p + o_off;
       j.in_len = hb.in_len + hb.prefix_len;
       j.out_cap = hb.out_cap;
+      j.res_slot = (uint32_t)k;
       if (hb.prefix_len) memcpy(stage.data() + i_off, hb.prefix, hb.prefix_len);
       if (hb.in_len) memcpy(stage.data() + i_off + hb.prefix_len, hb.in, hb.in_len);
       out_off[k] = o_off;
@@ -333,38 +351,59 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
   }
 }
 
-void engine_code_device(bool decode, const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
-                        const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                        const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed) {
+void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan, const void* d_in,
+                        const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks, void* d_out,
+                        const uint64_t* out_off, const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
   hipStream_t st = stream ? (hipStream_t)stream : e.stream;
-  const uint64_t a = plan->hdr().arena_bytes;
-  if (a * (uint64_t)nblocks > e.budget)
-    fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
-  e.arena.ensure(a * (uint64_t)nblocks);
-  e.jobs.ensure((size_t)nblocks * sizeof(BlockJob));
-  const uint8_t* dplan = plan_on_device(e, plan);
-  std::vector<BlockJob> jobs(nblocks);
+  e.jit_left = jit_budget();
+  auto plan_of = [&](uint32_t b) { return one_plan ? plans[0] : plans[b]; };
+  uint64_t need = 0, max_arena = 0;
   for (uint32_t b = 0; b < nblocks; ++b) {
-    BlockJob& j = jobs[b];
+    const uint64_t a = plan_of(b)->hdr().arena_bytes;
+    need += a;
+    max_arena = std::max(max_arena, a);
+  }
+  if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
+  e.arena.ensure(need);
+  e.jobs.ensure((size_t)nblocks * sizeof(BlockJob));
+  // group blocks by (kernel kind, plan); results keep the caller's block order through res_slot
+  std::vector<uint32_t> order(nblocks);
+  std::vector<int> kind_of(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) { order[b] = b; kind_of[b] = kernel_kind(e, plan_of(b)); }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
+    if (kind_of[x] == 3) return plan_of(x) < plan_of(y);
+    return false;
+  });
+  std::vector<BlockJob> jobs(nblocks);
+  std::vector<LaunchGroup> groups;
+  uint64_t a_off = 0;
+  for (uint32_t k = 0; k < nblocks; ++k) {
+    const uint32_t b = order[k];
+    const zpq_plan* pl = plan_of(b);
+    BlockJob& j = jobs[k];
     memset(&j, 0, sizeof(j));
-    j.plan = dplan;
-    j.arena = (uint8_t*)e.arena.p + a * b;
+    j.plan = plan_on_device(e, pl);
+    j.arena = (uint8_t*)e.arena.p + a_off;
     j.in = (const uint8_t*)d_in + in_off[b];
     j.out = (uint8_t*)d_out + out_off[b];
     j.in_len = in_len[b];
     j.out_cap = out_cap[b];
+    j.res_slot = b;
+    a_off += pl->hdr().arena_bytes;
+    SpecKernel* sk = kind_of[b] == 3 ? (SpecKernel*)pl->spec : nullptr;
+    if (!groups.empty() && groups.back().kind == kind_of[b] && groups.back().spec == sk) ++groups.back().count;
+    else groups.push_back(LaunchGroup{kind_of[b], sk, k, 1});
   }
   HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), (size_t)nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));   // jobs vector goes out of scope below
-  const int kd = kernel_kind(e, plan);
-  std::vector<LaunchGroup> groups(1, LaunchGroup{kd, kd == 3 ? (SpecKernel*)plan->spec : nullptr, 0, nblocks});
   e.last = Timing{};
-  e.last_kind = kd;
-  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, a, st, timed);
+  e.last_kind = groups.empty() ? 0 : groups[0].kind;
+  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed);
 }
 
 int engine_selftest(int32_t out[8]) {

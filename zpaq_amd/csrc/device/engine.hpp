@@ -37,10 +37,11 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note);
 // Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.
 void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);
 
-// Device-resident batch of one plan; results land in the device array d_res.
-void engine_code_device(bool decode, const zpq_plan* plan, const void* d_in, const uint64_t* in_off,
-                        const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                        const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed);
+// Device-resident batch; plans[0] for every block when one_plan, else plans[b] per block.  Results
+// land in the device array d_res in the caller's block order.
+void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan, const void* d_in,
+                        const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks, void* d_out,
+                        const uint64_t* out_off, const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed);
 
 int engine_selftest(int32_t out[8]);
 

@@ -65,6 +65,7 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
   const BlockJob job = jobs[b];
+  BlockResult& out_res = res[job.res_slot];
   SerialCtx s;
   serial_open(s, job, tb);
   uint32_t low = 1, high = 0xFFFFFFFFu;
@@ -98,8 +99,8 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
     }
     if (!status) encode(1, 0);
     if (!status && n > job.out_cap) status = 3;
-    res[b].out_len = n;
-    res[b].consumed = job.in_len;
+    out_res.out_len = n;
+    out_res.consumed = job.in_len;
   } else {
     // Decoder::decompress / decode (libzpaq.cpp:2104-2155)
     uint32_t rp = 0, n = 0, curr = 0;
@@ -137,11 +138,11 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
       if (status || eos) break;
       job.out[n++] = (uint8_t)(c - 256);
     }
-    res[b].out_len = n;
-    res[b].consumed = eos ? rp : 0;
+    out_res.out_len = n;
+    out_res.consumed = eos ? rp : 0;
   }
-  res[b].status = status;
-  res[b].steps = steps;
+  out_res.status = status;
+  out_res.steps = steps;
 }
 
 // ---------------------------------------------------------------- selftest

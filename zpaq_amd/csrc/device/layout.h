@@ -71,7 +71,8 @@ struct BlockJob {
   uint8_t* out;
   uint32_t in_len;
   uint32_t out_cap;       // encode: capacity; decode: max bytes to decode
-  uint32_t pad[2];
+  uint32_t res_slot;      // index of this block's BlockResult in the results array
+  uint32_t pad;
 };
 
 struct BlockResult {      // 16 bytes

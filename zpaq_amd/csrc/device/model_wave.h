@@ -377,6 +377,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
   job.out = (uint8_t*)uni64((uint64_t)job.out);
   job.in_len = uni(job.in_len);
   job.out_cap = uni(job.out_cap);
+  const uint32_t rslot = uni(job.res_slot);
   const PlanHeader* ph = (const PlanHeader*)job.plan;
   const CompDesc* comp = (const CompDesc*)(job.plan + uni(ph->off_comp));
 
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
     }
     if (!status) encode(1, 0);
     if (!status && n > job.out_cap) status = 3;
-    if (lane == 0) { res[b].out_len = n; res[b].consumed = job.in_len; }
+    if (lane == 0) { res[rslot].out_len = n; res[rslot].consumed = job.in_len; }
   } else {
     uint32_t rp = 0, n = 0, curr = 0;
     bool eos = false;
@@ -518,9 +519,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
       if (lane == 0) job.out[n] = (uint8_t)(c - 256);
       ++n;
     }
-    if (lane == 0) { res[b].out_len = n; res[b].consumed = eos ? rp : 0; }
+    if (lane == 0) { res[rslot].out_len = n; res[rslot].consumed = eos ? rp : 0; }
   }
-  if (lane == 0) { res[b].status = status; res[b].steps = steps; }
+  if (lane == 0) { res[rslot].status = status; res[rslot].steps = steps; }
 #ifdef ZPQ_PROF
   if (lane == 0 && b == 0) {
     prof[4] = __builtin_readcyclecounter() - prof_t0;

@@ -196,6 +196,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   g_u8* const out_ptr = (g_u8*)sp_uni64((unsigned long long)job.out);
   job.in_len = sp_uni(job.in_len);
   job.out_cap = sp_uni(job.out_cap);
+  const unsigned rslot = sp_uni(job.res_slot);
   lds_u8* const wl = (lds_u8*)&wave_lds[wave][0];
 
   // ---- per-lane component constants (selected from the constexpr chain) ----
@@ -348,13 +349,20 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     //     lanes without a row work on their dummy slot)
     if (nib) {
       asm volatile("" ::"v"(touch_a), "v"(touch_b));
-      G128(roff + rowoff) = make_uint4(row0, row1, row2, row3);             // write the old row back
       const unsigned cx = h + 16u * (unsigned)c8;
       const unsigned chk = (cx >> sizebits) & 255u;
       const unsigned h0 = (cx * 16u) & (rmask - 15u);
-      const uint4 r0 = G128(roff + h0);
-      const uint4 r1 = G128(roff + (h0 ^ 16u));
-      const uint4 r2 = G128(roff + (h0 ^ 32u));
+      // The three candidate rows are fetched BEFORE the old row is written back, so that waiting
+      // for them does not also wait for that store (vmcnt retires in order); if the old row is one
+      // of the candidates, its register copy -- newer than memory -- is forwarded instead.
+      uint4 r0 = G128(roff + h0);
+      uint4 r1 = G128(roff + (h0 ^ 16u));
+      uint4 r2 = G128(roff + (h0 ^ 32u));
+      const uint4 oldrow = make_uint4(row0, row1, row2, row3);
+      G128(roff + rowoff) = oldrow;
+      if (rowoff == h0) r0 = oldrow;
+      if (rowoff == (h0 ^ 16u)) r1 = oldrow;
+      if (rowoff == (h0 ^ 32u)) r2 = oldrow;
       // Predictor::find (libzpaq.cpp:2072-2088)
       const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
       const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
@@ -633,7 +641,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     }
     if (!status) encode(1, 0);
     if (!status && n > job.out_cap) status = 3;
-    if (lane == 0) { res[b].out_len = n; res[b].consumed = job.in_len; }
+    if (lane == 0) { res[rslot].out_len = n; res[rslot].consumed = job.in_len; }
   } else {
     unsigned rp = 0, n = 0, curr = 0;
     bool eos = false;
@@ -671,9 +679,9 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       if (lane == 0) out_ptr[n] = (unsigned char)(ch - 256);
       ++n;
     }
-    if (lane == 0) { res[b].out_len = n; res[b].consumed = eos ? rp : 0; }
+    if (lane == 0) { res[rslot].out_len = n; res[rslot].consumed = eos ? rp : 0; }
   }
-  if (lane == 0) { res[b].status = status; res[b].steps = steps; }
+  if (lane == 0) { res[rslot].status = status; res[rslot].steps = steps; }
 #ifdef ZPQ_PROF
   if (lane == 0 && b == 0) {
     prof[3] = __builtin_readcyclecounter() - prof_t0;

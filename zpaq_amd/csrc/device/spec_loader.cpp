@@ -99,7 +99,7 @@ static bool compile_hiprtc(const std::string& source, std::vector<char>& code, s
   return true;
 }
 
-SpecKernel* spec_kernel_for(zpq_plan* plan) {
+SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit, bool* jit_deferred, bool* did_jit) {
   if (plan->spec_state > 0) return (SpecKernel*)plan->spec;
   if (plan->spec_state < 0) return nullptr;
   plan->spec_state = -1;
@@ -114,6 +114,13 @@ SpecKernel* spec_kernel_for(zpq_plan* plan) {
     code.assign(blob.begin(), blob.end());
     origin = "cache:" + key;
   } else {
+    if (!allow_jit) {                       // not prebuilt and the caller's JIT budget is spent
+      plan->spec_state = 0;
+      plan->spec_note = "hipRTC compile deferred (JIT budget of this batch spent)";
+      if (jit_deferred) *jit_deferred = true;
+      return nullptr;
+    }
+    if (did_jit) *did_jit = true;
     std::string log;
     if (!compile_hiprtc(source, code, log)) {
       plan->spec_note = "hipRTC compile failed: " + log.substr(0, 2000);

@@ -19,7 +19,9 @@ struct SpecKernel {
 // Looks in the in-tree cache (zpaq_amd/spec_cache/<key>.hsaco, filled by
 // zpaq_amd/prebuild.py at build time), else compiles with hipRTC and stores the
 // code object back into the cache directory when that is writable.
-SpecKernel* spec_kernel_for(zpq_plan* plan);
+// allow_jit = false: only the in-tree cache is consulted; a miss leaves the plan untried (a later call may
+// compile it) and *jit_deferred is set.
+SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit = true, bool* jit_deferred = nullptr, bool* did_jit = nullptr);
 void spec_kernel_release(zpq_plan* plan);
 
 // Source text + cache key (with the template-header digest) for prebuilding.

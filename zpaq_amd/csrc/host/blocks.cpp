@@ -3,9 +3,14 @@
 // coder itself replaced by one device batch.
 #include "blocks.hpp"
 
+#include <sched.h>
+
+#include <atomic>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
+#include <thread>
 
 #include "../device/engine.hpp"
 #include "../device/plan.hpp"
@@ -67,6 +72,31 @@ void encode_jobs(std::vector<EncJob>& jobs) {
   }
 }
 
+// Per-block host work (SHA-1, period scan, header assembly, archive stitching) is independent per
+// block: spread it over the host cores the process may use, like zpaq.cpp's compressThread pool.
+template <class F>
+void parallel_blocks(size_t n, F&& fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw ? hw : 1, (unsigned)CPU_COUNT(&set));
+  const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 32), n / 4));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<size_t> next(0);
+  std::exception_ptr err;
+  std::atomic<bool> failed(false);
+  std::vector<std::thread> pool;
+  for (size_t t = 0; t < nt; ++t)
+    pool.emplace_back([&] {
+      try {
+        for (size_t i; (i = next.fetch_add(1)) < n && !failed;) fn(i);
+      } catch (...) {
+        if (!failed.exchange(true)) err = std::current_exception();
+      }
+    });
+  for (auto& th : pool) th.join();
+  if (failed) std::rethrow_exception(err);
+}
+
 }  // namespace
 
 void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool dosha1,
@@ -74,14 +104,13 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   if (!method || !method[0]) fail(ZPQ_E_ARG, "empty method");
   const size_t nb = in.size();
   struct Work {
-    std::vector<U8> pp, coded;
+    std::vector<U8> pp, coded, header;
     U8 sha1[20];
   };
   std::vector<Work> work(nb);
   archives.assign(nb, std::vector<U8>());
-  PlanCache plans;   // blocks with identical headers share one plan
-  std::vector<EncJob> jobs;
-  for (size_t b = 0; b < nb; ++b) {
+  // 1. host front half, parallel over blocks
+  parallel_blocks(nb, [&](size_t b) {
     Work& w = work[b];
     const U32 n = in[b].n;
     if ((U64)n > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
@@ -97,13 +126,21 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     if (as.pcomp.empty()) w.pp.push_back(0);
     else { w.pp.push_back(1); w.pp.insert(w.pp.end(), as.pcomp.begin(), as.pcomp.end()); }
     if (as.hcomp[6] == 0) write_stored_payload(archives[b], w.pp.data(), w.pp.size(), in[b].data, n);
-    else jobs.push_back(EncJob{plan_for(plans, as.hcomp), w.pp.data(), (U32)w.pp.size(), in[b].data, n, &w.coded});
-  }
+    else w.header = as.hcomp;
+  });
+  // 2. one device batch for every modelled block (blocks with identical headers share a plan)
+  PlanCache plans;
+  std::vector<EncJob> jobs;
+  for (size_t b = 0; b < nb; ++b)
+    if (!work[b].header.empty())
+      jobs.push_back(EncJob{plan_for(plans, work[b].header), work[b].pp.data(), (U32)work[b].pp.size(), in[b].data,
+                            in[b].n, &work[b].coded});
   encode_jobs(jobs);
-  for (size_t b = 0; b < nb; ++b) {
+  // 3. stitch the archives
+  parallel_blocks(nb, [&](size_t b) {
     archives[b].insert(archives[b].end(), work[b].coded.begin(), work[b].coded.end());
     write_block_epilogue(archives[b], dosha1 ? work[b].sha1 : nullptr);
-  }
+  });
 }
 
 std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size_t npp, const U8* data, size_t n) {
@@ -124,7 +161,8 @@ void decode_jobs(std::vector<DecJob>& jobs) {
   std::vector<U64> cap(jobs.size());
   for (size_t i = 0; i < jobs.size(); ++i) {
     todo[i] = i;
-    cap[i] = (jobs[i].hint ? jobs[i].hint : 4 * (U64)jobs[i].len) + 65536 + 8;
+    // the hint is the uncompressed size; an LZ77/BWT coded stream can exceed it by a few percent
+    cap[i] = (jobs[i].hint ? jobs[i].hint + jobs[i].hint / 16 : 4 * (U64)jobs[i].len) + 65536 + 8;
   }
   while (!todo.empty()) {
     std::vector<HostBlock> hb;
@@ -160,18 +198,11 @@ std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload,
   return decoded;
 }
 
-void strip_pp(const std::vector<U8>& decoded, const U8*& data, size_t& len) {
-  if (decoded.empty()) fail(ZPQ_E_CORRUPT, "Unexpected EOS");
-  if (decoded[0] == 1) fail(ZPQ_E_UNSUPPORTED, "PCOMP post-processing is outside this build's hot-path scope");
-  if (decoded[0] != 0) fail(ZPQ_E_CORRUPT, "unknown post processing type");
-  data = decoded.data() + 1;
-  len = decoded.size() - 1;
-}
-
 void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, size_t)>& sink) {
   struct Seg {
     FoundSegment fs;
     zpq_plan* plan = nullptr;     // null: stored block
+    std::vector<U8> header;
     size_t payload_end = 0;
     std::vector<U8> decoded;      // PP byte(s) + data
     U64 hint = 0;
@@ -190,6 +221,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
       if (modeled && ++nseg > 1)
         fail(ZPQ_E_UNSUPPORTED, "multi-segment modelled blocks are outside this build's scope");
       s->plan = plan;
+      s->header = blk.header;
       s->payload_end = skip_payload(a, n, pos, modeled);
       pos = s->payload_end;
       read_segment_end(a, n, pos, s->fs);
@@ -219,13 +251,14 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
         p += l;
       }
     }
-    const U8* data; size_t len;
-    strip_pp(s->decoded, data, len);
+    std::vector<U8> data;
+    post_process(s->header, s->decoded, data);
+    std::vector<U8>().swap(s->decoded);
     if (s->fs.has_sha1) {
-      Sha1 h; h.update(data, len);
+      Sha1 h; h.update(data.data(), data.size());
       if (memcmp(h.result(), s->fs.sha1, 20) != 0) fail(ZPQ_E_CORRUPT, "segment checksum mismatch");
     }
-    sink(data, len);
+    sink(data.data(), data.size());
   }
 }
 

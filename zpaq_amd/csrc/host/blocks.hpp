@@ -33,8 +33,8 @@ std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload,
 // receives each segment's post-processed data in order.
 void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, size_t)>& sink);
 
-// Split a decoded segment (PP header + data) into its data part; fails with
-// ZPQ_E_UNSUPPORTED for PCOMP programs (PostProcessor::write 2195-2241).
-void strip_pp(const std::vector<U8>& decoded, const U8*& data, size_t& len);
+// PostProcessor::write (2195-2241): turns a decoded segment (PP header + payload) into the
+// segment's data -- either passing it through or running the PCOMP program it carries.
+void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data);
 
 }  // namespace zpq

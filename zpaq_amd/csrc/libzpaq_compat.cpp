@@ -281,10 +281,13 @@ void Decompresser::decode_segment() {
       for (U32 i = 0; i < len; ++i) { const int c = getc(); if (c < 0) error("unexpected end of file"); decoded_.push_back((U8)c); }
     }
   }
-  if (decoded_.empty()) error("Unexpected EOS");
-  if (decoded_[0] == 1) error("PCOMP post-processing is outside this build's hot-path scope");
-  if (decoded_[0] != 0) error("unknown post processing type");
-  dpos_ = 1;
+  // PostProcessor: pass through, or run the PCOMP program carried by the segment
+  guarded([&] {
+    std::vector<U8> data;
+    zpq::post_process(header_, decoded_, data);
+    decoded_.swap(data);
+  });
+  dpos_ = 0;
   seg_decoded_ = true;
 }
 
