@@ -31,14 +31,18 @@ def main():
     out = sys.argv[1]
     max_mib = float(sys.argv[sys.argv.index("--max-mib") + 1]) if "--max-mib" in sys.argv else 4
     pts = []
-    for kind in ("zeros", "lcg", "pattern"):
-        for kib, blocks in ((64, 1024), (256, 1024), (1024, 512), (4096, 256), (16384, 64)):
-            if kib / 1024 > max_mib:
-                continue
-            pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
-    pts.append(["--kind", "mixed", "--blocks", "1024", "--block-bytes", str(256 * 1024)])      # config 4 shape
-    pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--mode", "decode"])   # config 5
-    pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--method", "4"])
+    which = sys.argv[sys.argv.index("--set") + 1] if "--set" in sys.argv else "all"
+    if which in ("all", "sizes"):
+        for kind in ("zeros", "lcg"):
+            for kib, blocks in ((64, 1024), (256, 1024), (1024, 512), (4096, 256), (16384, 64)):
+                if kib / 1024 > max_mib:
+                    continue
+                pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
+    if which in ("all", "configs"):
+        pts.append(["--kind", "mixed", "--blocks", "1024", "--block-bytes", str(256 * 1024)])      # config 4 shape
+        pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--mode", "decode"])   # config 5
+        pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--method", "4"])
+        pts.append(["--kind", "pattern", "--blocks", "256", "--block-bytes", str(64 * 1024)])     # one chain per block: JIT budget
     with open(out, "w") as fh:
         for p in pts:
             res = run(p)

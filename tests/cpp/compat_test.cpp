@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
     CHECK(threw);
 
     if (gpu) {
-      const std::string d1 = text(300000, 7);
+      const std::string d1 = text(60000, 7);
       CHECK(roundtrip_stream(d1, "5") == d1);
       CHECK(roundtrip_stream(d1, "4") == d1);
       // batched extension: 5 buffers -> 5 blocks in one device batch, then one decompress() over all
@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
       // Compressor with an explicit ZPAQL config (max-style chain fragment) + streaming Decompresser
       const char* cfg = "comp 2 8 0 0 3 0 icm 12 1 isse 14 0 2 mix 8 0 2 24 255 hcomp c++ *c=a b=c a=0 d= 1 hash *d=a halt end\n";
       libzpaq::StringBuffer src, a2, o2;
-      src.write(d1.data(), 50000);
+      src.write(d1.data(), 30000);
       libzpaq::Compressor co;
       co.setOutput(&a2);
       co.setInput(&src);
@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
       CHECK(o2.size() == 12345);
       de.decompress(-1);
       de.readSegmentEnd();
-      CHECK(o2.size() == 50000 && memcmp(o2.c_str(), d1.data(), 50000) == 0);
+      CHECK(o2.size() == 30000 && memcmp(o2.c_str(), d1.data(), 30000) == 0);
     }
   } catch (std::exception& e) {
     fprintf(stderr, "exception: %s\n", e.what());
