@@ -217,3 +217,40 @@ def test_decode_reference_archives_with_preprocessing(gpu):
         parts.append(d.tobytes())
         stream += ref.compress_block(d, m)
     assert gpu.decompress(stream) == b"".join(parts)
+
+
+def test_random_hcomp_programs_all_kernels(gpu, oracle, golden):
+    """HCOMP -> HIP translation (hipRTC path) and both interpreters against the reference's archives."""
+    for kernel in KERNELS:
+        gpu.set_kernel(kernel)
+        try:
+            cases = golden["vm_cases"] if kernel != 3 else golden["vm_cases"][:6]    # ~3 s of hipRTC each
+            plans = [gpu.Plan(bytes.fromhex(e["header"])) for e in cases]
+            inputs = [b"\0" + gen_input(e).tobytes() for e in cases]
+            coded = gpu.encode_batch(plans, inputs)
+            bad = []
+            for e, c in zip(cases, coded):
+                a = b64(e)
+                ps = e["payload_start"]
+                if a[ps:ps + len(c) + 4] != c + b"\0\0\0\0":
+                    bad.append(e["name"])
+            assert not bad, (kernel, bad)
+            res = gpu.decode_batch(plans, [b64(e)[e["payload_start"]:] for e in cases], [e["n"] + 64 for e in cases])
+            for e, (dec, used) in zip(cases, res):
+                assert dec == b"\0" + gen_input(e).tobytes(), (kernel, e["name"])
+        finally:
+            gpu.set_kernel(0)
+
+
+def test_more_than_64_components_uses_the_generic_kernel(gpu, golden):
+    import ctypes as C
+    e = [c for c in golden["config_cases"] if c["name"] == "seventy_components"][0]
+    plan = gpu.Plan(bytes.fromhex(e["header"]))
+    note = C.create_string_buffer(512)
+    assert gpu.lib().zpq_plan_kernel_kind(plan._h, note, 512) == 1
+    a = b64(e)
+    ps = e["payload_start"]
+    d = gen_input(e).tobytes()
+    c = gpu.encode_batch([plan], [b"\0" + d])[0]
+    assert a[ps:ps + len(c) + 4] == c + b"\0\0\0\0"
+    assert gpu.decompress(a) == d

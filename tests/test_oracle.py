@@ -134,3 +134,17 @@ def test_oracle_decoder_detects_corruption(oracle, golden):
         assert dec[1:] != gen_input(e).tobytes()
     except RuntimeError:
         pass
+
+
+def test_oracle_random_hcomp_programs(oracle, golden):
+    """Random ZPAQL programs (all operand kinds, swaps, hash/hashd, R, div/mod by zero, shifts,
+    IF/ELSE, IFL/ELSEL long jumps, DO loops): pins the oracle's HCOMP VM to the reference's."""
+    assert len(golden["vm_cases"]) >= 10
+    for e in golden["vm_cases"]:
+        _check_entry(oracle, e, b64(e))
+
+
+def test_oracle_seventy_components(oracle, golden):
+    e = [c for c in golden["config_cases"] if c["name"] == "seventy_components"][0]
+    assert bytes.fromhex(e["header"])[6] == 70
+    _check_entry(oracle, e, b64(e))
