@@ -80,6 +80,9 @@ double zpq_plan_algo_bytes_per_byte(const zpq_plan*);
  * precompile it to <cache dir>/<key>.hsaco; at run time the engine loads that
  * file or falls back to hipRTC.  Needs no GPU. */
 int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
+/* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
+ * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
+size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
 /* Which kernel will code this plan on the current device: 3 specialised,
  * 2 generic wave, 1 generic one-lane.  note (optional) receives where the
  * specialised kernel came from ("cache:<key>" / "hiprtc") or why it is not used. */

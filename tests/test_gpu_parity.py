@@ -143,6 +143,14 @@ def test_specialised_kernel_is_the_one_running(gpu, golden):
     kind = L.zpq_plan_kernel_kind(plan2._h, note, 4096)
     assert kind == 3, note.value
     assert note.value.startswith(b"hiprtc") or note.value.startswith(b"cache:")
+    # a header that certainly was not prebuilt: must come out of hipRTC, and code correctly
+    e = golden["vm_cases"][7]
+    plan3 = gpu.Plan(bytes.fromhex(e["header"]))
+    assert L.zpq_plan_kernel_kind(plan3._h, note, 4096) == 3, note.value
+    assert note.value.startswith(b"hiprtc"), note.value
+    c = gpu.encode_batch([plan3], [b"\0" + gen_input(e).tobytes()])[0]
+    a = b64(e)
+    assert a[e["payload_start"]:e["payload_start"] + len(c)] == c
 
 
 def test_decoder_status_codes(gpu, golden):

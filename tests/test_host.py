@@ -204,3 +204,16 @@ def test_codegen_translates_random_hcomp_and_compiles_for_gfx950(zlib_, golden, 
             assert r.returncode == 0, r.stdout[-3000:]
             built += 1
     assert built == 3
+
+
+def test_hiprtc_compiles_a_generated_kernel_without_a_gpu(zlib_, golden):
+    """The run-time specialisation path (hipRTC, used for headers nobody prebuilt) must compile on
+    its own: hipRTC has no C library headers, so the kernel template may not depend on any."""
+    import ctypes as C
+    L = zlib_.lib()
+    L.zpq_plan_spec_jit.restype = C.c_size_t
+    L.zpq_plan_spec_jit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    plan = zlib_.Plan(bytes.fromhex(golden["vm_cases"][3]["header"]))
+    log = C.create_string_buffer(16384)
+    n = L.zpq_plan_spec_jit(plan._h, log, len(log))
+    assert n > 10000, log.value.decode(errors="replace")[:3000]

@@ -72,6 +72,18 @@ int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) {
   catch (const std::exception& ex) { set_last_error(ex.what()); return -ZPQ_E_DEVICE; }
 }
 
+size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
+  try {
+    std::string l;
+    const size_t n = p ? spec_jit_compile_only(*p, l) : 0;
+    if (log && cap) { strncpy(log, l.c_str(), cap - 1); log[cap - 1] = 0; }
+    return n;
+  } catch (const std::exception& ex) {
+    if (log && cap) { strncpy(log, ex.what(), cap - 1); log[cap - 1] = 0; }
+    return 0;
+  }
+}
+
 const char* zpq_spec_cache_dir(void) { static std::string s; s = spec_cache_dir(); return s.c_str(); }
 const char* zpq_spec_include_dir(void) { static std::string s; s = spec_include_dir(); return s.c_str(); }
 

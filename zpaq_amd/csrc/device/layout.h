@@ -11,6 +11,16 @@
 #pragma once
 #ifndef __HIPCC_RTC__
 #include <stdint.h>
+#else
+// hipRTC has no C library headers; its built-in prelude keeps the fixed-width types in a namespace
+using __hip_internal::int8_t;
+using __hip_internal::int16_t;
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint8_t;
+using __hip_internal::uint16_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
 #endif
 
 namespace zpq {

@@ -99,6 +99,14 @@ static bool compile_hiprtc(const std::string& source, std::vector<char>& code, s
   return true;
 }
 
+size_t spec_jit_compile_only(const zpq_plan& plan, std::string& log) {
+  std::string source, key, why;
+  if (!spec_source_and_key(plan, source, key, why)) { log = why; return 0; }
+  std::vector<char> code;
+  if (!compile_hiprtc(source, code, log)) return 0;
+  return code.size();
+}
+
 SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit, bool* jit_deferred, bool* did_jit) {
   if (plan->spec_state > 0) return (SpecKernel*)plan->spec;
   if (plan->spec_state < 0) return nullptr;

@@ -26,6 +26,8 @@ void spec_kernel_release(zpq_plan* plan);
 
 // Source text + cache key (with the template-header digest) for prebuilding.
 bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
+// hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
+size_t spec_jit_compile_only(const zpq_plan& plan, std::string& log);
 std::string spec_include_dir();
 std::string spec_cache_dir();
 
