@@ -157,6 +157,13 @@ def main():
         dist_ms["scatter"] = (time.perf_counter() - t0) * 1e3
         blocks = mine.cpu().numpy()
         del full
+    elif a.kind == "text":
+        # same bytes as corpus.zipf_text, generated on this rank's GPU (seconds instead of minutes of host time)
+        from zpaq_amd import corpus, corpus_torch
+        d_blocks = corpus_torch.text_blocks(nb, bs, corpus.BASE_SEED + rank * nb, dev)
+        blocks = d_blocks.cpu().numpy()
+        del d_blocks
+        torch.cuda.empty_cache()
     else:
         blocks = make_corpus(a.kind, nb, bs, first=rank * nb)
 

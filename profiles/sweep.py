@@ -38,6 +38,9 @@ def main():
                 if kib / 1024 > max_mib:
                     continue
                 pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
+    if which == "sizes4":
+        for kind in ("zeros", "lcg"):
+            pts.append(["--kind", kind, "--blocks", "256", "--block-bytes", str(4096 * 1024)])
     if which in ("all", "configs"):
         pts.append(["--kind", "mixed", "--blocks", "1024", "--block-bytes", str(256 * 1024)])      # config 4 shape
         pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--mode", "decode"])   # config 5

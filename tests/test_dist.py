@@ -78,3 +78,11 @@ def test_two_rank_scatter_gather_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
     assert "RANK0_OK" in outs[0]
+
+
+def test_torch_corpus_generator_on_cpu():
+    import torch
+    from zpaq_amd import corpus, corpus_torch
+    o = corpus_torch.text_blocks(3, 50000, 777, torch.device("cpu"), chunk=2).numpy()
+    for b in range(3):
+        assert (o[b] == corpus.zipf_text(50000, 777 + b)).all()

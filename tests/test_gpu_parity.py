@@ -262,3 +262,12 @@ def test_more_than_64_components_uses_the_generic_kernel(gpu, golden):
     c = gpu.encode_batch([plan], [b"\0" + d])[0]
     assert a[ps:ps + len(c) + 4] == c + b"\0\0\0\0"
     assert gpu.decompress(a) == d
+
+
+def test_torch_corpus_matches_numpy(gpu):
+    """bench.py generates its text corpus on the GPU; it must be the same bytes as the numpy generator."""
+    import torch
+    from zpaq_amd import corpus_torch
+    o = corpus_torch.text_blocks(3, 200000, corpus.BASE_SEED + 40, torch.device("cuda", 0), chunk=2).cpu().numpy()
+    for b in range(3):
+        assert (o[b] == corpus.zipf_text(200000, corpus.BASE_SEED + 40 + b)).all()

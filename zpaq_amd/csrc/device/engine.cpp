@@ -60,7 +60,7 @@ Engine& eng() {
 
 int jit_budget() {
   if (const char* v = getenv("ZPAQ_AMD_MAX_JIT")) return atoi(v);
-  return 4;
+  return 16;
 }
 
 void require_ready(Engine& e) {
