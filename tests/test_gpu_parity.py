@@ -2,6 +2,8 @@
 golden vectors made by the reference, and (when oracle/_ref travelled here) the
 reference itself.  Bit-exact everywhere: this is integer/byte work."""
 import hashlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +11,8 @@ import pytest
 from conftest import b64, gen_input
 from oracle.oracle_py import have_ref, parse_block
 from zpaq_amd import corpus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -265,9 +269,15 @@ def test_more_than_64_components_uses_the_generic_kernel(gpu, golden):
 
 
 def test_torch_corpus_matches_numpy(gpu):
-    """bench.py generates its text corpus on the GPU; it must be the same bytes as the numpy generator."""
-    import torch
-    from zpaq_amd import corpus_torch
-    o = corpus_torch.text_blocks(3, 200000, corpus.BASE_SEED + 40, torch.device("cuda", 0), chunk=2).cpu().numpy()
-    for b in range(3):
-        assert (o[b] == corpus.zipf_text(200000, corpus.BASE_SEED + 40 + b)).all()
+    """bench.py generates its text corpus on the GPU; it must be the same bytes as the numpy generator.
+    Runs in its own process, torch first, the way bench.py orders things (torch brings its own HIP runtime and
+    must initialise before libzpaq_amd.so is loaded)."""
+    import subprocess
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from zpaq_amd import corpus, corpus_torch\n"
+        "o = corpus_torch.text_blocks(3, 200000, corpus.BASE_SEED + 40, torch.device('cuda', 0), chunk=2).cpu().numpy()\n"
+        "assert all((o[b] == corpus.zipf_text(200000, corpus.BASE_SEED + 40 + b)).all() for b in range(3))\n"
+        "print('same')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
