@@ -268,6 +268,41 @@ def test_more_than_64_components_uses_the_generic_kernel(gpu, golden):
     assert gpu.decompress(a) == d
 
 
+DEEP_ISSE = "x0,0ci1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1m"   # 1 ICM + 17 ISSE: 35 KiB of side tables, more than a block's LDS
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_both_workgroup_shapes_and_arena_side_tables(gpu, oracle, golden, monkeypatch, waves):
+    """The specialised kernel exists in two workgroup shapes (4 / 8 blocks per workgroup; the engine picks by batch
+    size).  Force each one and check it bit-exact: standard chains (in the 8-block shape half of the -m5 side
+    tables live in the arena and are fetched a bit ahead), and a chain too deep for LDS in either shape."""
+    monkeypatch.setenv("ZPAQ_AMD_SPEC_WAVES", waves)
+    gpu.set_kernel(3)
+    try:
+        entries = [e for e in golden["method_cases"] if e["n"] <= 65536 and bytes.fromhex(e["header"])[6]]
+        entries += [golden["config_cases"][0], golden["level_cases"][2]]
+        plans, inputs, cache = [], [], {}
+        for e in entries:
+            hdr = bytes.fromhex(e["header"])
+            if hdr not in cache:
+                cache[hdr] = gpu.Plan(hdr)
+            plans.append(cache[hdr])
+            inputs.append(b"\0" + gen_input(e).tobytes())
+        deep_hdr, _, _ = gpu.method_to_header(DEEP_ISSE)
+        deep = gpu.Plan(deep_hdr)
+        for k, kind in enumerate(["text", "records", "lcg", "text"]):
+            plans.append(deep)
+            inputs.append(b"\0" + corpus.block(kind, 30000 + 1111 * k, 900 + k).tobytes())
+        hdrs = [bytes.fromhex(e["header"]) for e in entries] + [deep_hdr] * 4
+        coded = gpu.encode_batch(plans, inputs)
+        bad = [i for i, (h, inp, c) in enumerate(zip(hdrs, inputs, coded)) if c != oracle.encode(h, inp)]
+        assert not bad, bad
+        back = gpu.decode_batch(plans, [c + b"\0\0\0\0" for c in coded], [len(x) + 64 for x in inputs])
+        assert all(dec == inp for (dec, _), inp in zip(back, inputs))
+    finally:
+        gpu.set_kernel(0)
+
+
 def test_torch_corpus_matches_numpy(gpu):
     """bench.py generates its text corpus on the GPU; it must be the same bytes as the numpy generator.
     Runs in its own process, torch first, the way bench.py orders things (torch brings its own HIP runtime and

@@ -51,6 +51,7 @@ struct Engine {
   Timing last{};
   int last_kind = 0;
   int jit_left = 0;                    // hipRTC compilations still allowed in the current call
+  int cus = 256;                       // compute units of the device
 };
 
 Engine& eng() {
@@ -87,6 +88,7 @@ void engine_init_locked(int device) {
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     fail(ZPQ_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+  e.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (!e.stream) HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
   // constant tables
   const Tables& t = tables();
@@ -156,8 +158,12 @@ void engine_plan_release(zpq_plan* p) {
 // Which kernel codes a plan: 3 = per-header specialised kernel, 2 = generic
 // wave kernel, 1 = generic one-lane kernel.  kernel_choice 0 picks the best
 // available; 1/2/3 force one (3 fails loudly if specialisation is unavailable).
-static int kernel_kind(Engine& e, const zpq_plan* plan) {
+// `dense` = the launch holds more blocks than one wavefront per SIMD can take (4 x CUs): then the
+// 8-blocks-per-workgroup shape (two wavefronts per SIMD, half the side tables in LDS) has the higher
+// throughput; below that the 4-block shape (everything in LDS, one workgroup per CU) is faster.
+static int kernel_kind(Engine& e, const zpq_plan* plan, bool dense, SpecKernel** spec_out = nullptr) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
+  if (spec_out) *spec_out = nullptr;
   const int want = e.kernel_choice;
   if (want == 1) return 1;
   if (!plan->hdr().wave_ok) {
@@ -168,12 +174,16 @@ static int kernel_kind(Engine& e, const zpq_plan* plan) {
   // Each unseen header costs a ~2-4 s hipRTC compile.  A batch whose blocks all carry different
   // (data-dependent) chains must not spend minutes compiling: a few per call, the rest run on the
   // generic wave kernel this time and are picked up by later calls.
-  bool did = false;
-  if (spec_kernel_for(p, want == 3 || e.jit_left > 0, nullptr, &did)) {
+  const int forced = spec_variant_forced();
+  const int first = forced >= 0 ? forced : (dense ? 1 : 0);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int variant = attempt == 0 ? first : 1 - first;
+    if (attempt == 1 && (forced >= 0 || p->spec_state[variant] <= 0)) break;   // fall back only to a shape already loaded
+    bool did = false;
+    SpecKernel* k = spec_kernel_for(p, variant, want == 3 || e.jit_left > 0, nullptr, &did);
     if (did && e.jit_left > 0) --e.jit_left;
-    return 3;
+    if (k) { if (spec_out) *spec_out = k; return 3; }
   }
-  if (did && e.jit_left > 0) --e.jit_left;
   if (want == 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
   return 2;
 }
@@ -184,7 +194,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note) {
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
   e.jit_left = jit_budget();
-  const int k = kernel_kind(e, p);
+  const int k = kernel_kind(e, p, false);
   note = p->spec_note;
   return k;
 }
@@ -194,8 +204,8 @@ struct LaunchGroup { int kind; SpecKernel* spec; uint32_t first, count; };
 static hipError_t launch_spec(SpecKernel* k, bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t n,
                               const DeviceTables* d_tb, hipStream_t st) {
   void* args[4] = {(void*)&d_jobs, (void*)&d_res, (void*)&n, (void*)&d_tb};
-  const uint32_t wg = (n + 3) / 4;
-  return hipModuleLaunchKernel(decode ? k->decode : k->encode, wg, 1, 1, 256, 1, 1, 0, st, args, nullptr);
+  const uint32_t w = (uint32_t)k->waves;
+  return hipModuleLaunchKernel(decode ? k->decode : k->encode, (n + w - 1) / w, 1, 1, 64 * w, 1, 1, 0, st, args, nullptr);
 }
 
 // Launch init + coding kernels for jobs already resident on the device, grouped
@@ -292,7 +302,9 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     order.reserve(cnt);
     for (size_t i = pos; i < end; ++i) order.push_back(i);
     std::vector<int> kind_of(nb, 0);
-    for (size_t i = pos; i < end; ++i) kind_of[i] = kernel_kind(e, blocks[i].plan);
+    std::vector<SpecKernel*> spec_of(nb, nullptr);
+    const bool dense = cnt > (size_t)4 * e.cus;
+    for (size_t i = pos; i < end; ++i) kind_of[i] = kernel_kind(e, blocks[i].plan, dense, &spec_of[i]);
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
       if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
       if (kind_of[x] == 3) return blocks[x].plan < blocks[y].plan;
@@ -302,7 +314,8 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     for (size_t k = 0; k < cnt; ++k) {
       const zpq_plan* pl = blocks[order[k]].plan;
       const int kd = kind_of[order[k]];
-      SpecKernel* sk = kd == 3 ? (SpecKernel*)pl->spec : nullptr;
+      SpecKernel* sk = spec_of[order[k]];
+      (void)pl;
       if (!groups.empty() && groups.back().kind == kd && groups.back().spec == sk) ++groups.back().count;
       else groups.push_back(LaunchGroup{kd, sk, (uint32_t)k, 1});
     }
@@ -373,7 +386,9 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   // group blocks by (kernel kind, plan); results keep the caller's block order through res_slot
   std::vector<uint32_t> order(nblocks);
   std::vector<int> kind_of(nblocks);
-  for (uint32_t b = 0; b < nblocks; ++b) { order[b] = b; kind_of[b] = kernel_kind(e, plan_of(b)); }
+  std::vector<SpecKernel*> spec_of(nblocks, nullptr);
+  const bool dense = nblocks > 4u * (uint32_t)e.cus;
+  for (uint32_t b = 0; b < nblocks; ++b) { order[b] = b; kind_of[b] = kernel_kind(e, plan_of(b), dense, &spec_of[b]); }
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
     if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
     if (kind_of[x] == 3) return plan_of(x) < plan_of(y);
@@ -395,7 +410,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
     j.out_cap = out_cap[b];
     j.res_slot = b;
     a_off += pl->hdr().arena_bytes;
-    SpecKernel* sk = kind_of[b] == 3 ? (SpecKernel*)pl->spec : nullptr;
+    SpecKernel* sk = spec_of[b];
     if (!groups.empty() && groups.back().kind == kind_of[b] && groups.back().spec == sk) ++groups.back().count;
     else groups.push_back(LaunchGroup{kind_of[b], sk, k, 1});
   }

@@ -107,7 +107,9 @@ struct DeviceTables {
 // LDS plan of the specialised kernel (spec_kernel.h), known to the host code
 // generator: shared constant tables, then one region per wave (block).
 static const int kSpecTablesBytes = 32768 + 2688 + 4096 + 512 + 1024;                       // 41088
-static const int kSpecWaveLdsBytes = (((163840 - 256) - kSpecTablesBytes) / 4) & ~15;        // 30624
+static const int kSpecLdsBudget = 163840 - 256;                                             // gfx950: 160 KiB per workgroup
+// W blocks (waves) per workgroup share the budget: 4 -> 30624 B each, 8 -> 15312 B each
+static inline constexpr int spec_wave_lds_bytes(int waves) { return ((kSpecLdsBudget - kSpecTablesBytes) / waves) & ~15; }
 
 // Cap on HCOMP instructions per input byte: the reference has no limit (a
 // hostile header can loop forever); a device kernel must not hang.

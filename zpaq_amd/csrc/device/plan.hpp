@@ -12,9 +12,11 @@ struct zpq_plan {
   double algo_bytes = 0;
   void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
   int d_device = -1;
-  void* spec = nullptr;            // SpecKernel* (device/spec_loader.hpp)
-  int spec_state = 0;              // 0 not tried, 1 loaded, -1 unavailable
-  std::string spec_note;           // where the kernel came from / why it is unavailable
+  // per-header specialised kernels (device/spec_loader.hpp), one per workgroup shape:
+  // [0] 4 blocks per workgroup (all side tables in LDS), [1] 8 blocks per workgroup (2 wavefronts per SIMD)
+  void* spec[2] = {nullptr, nullptr};   // SpecKernel*
+  int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
+  std::string spec_note;                // where the last kernel came from / why it is unavailable
   const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
   const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }
 };

@@ -41,10 +41,8 @@ struct CompK {
   int slot;                    // ordinal among MIX (resp. SSE) components, else -1
 };
 
-constexpr int kSpecWaves = 4;                  // blocks per workgroup
-constexpr int kLdsBudget = 163840 - 256;       // gfx950: 160 KiB per workgroup, a little slack
 
-struct SpecTables {                            // shared by the 4 waves of a workgroup
+struct SpecTables {                            // shared by the waves of a workgroup
   int16_t stretch_hi[16384];                   // stretch(x) for x >= 16384; mirrored below
   uint16_t squash_mid[1344];                   // squash index 1376..2719
   int32_t dt[1024];
@@ -52,8 +50,6 @@ struct SpecTables {                            // shared by the 4 waves of a wor
   uint8_t ns[1024];
 };
 static_assert(sizeof(SpecTables) == kSpecTablesBytes, "host codegen and device disagree on LDS tables");
-constexpr int kSpecWaveLds = kSpecWaveLdsBytes;
-static_assert((int)sizeof(SpecTables) + kSpecWaves * kSpecWaveLds <= kLdsBudget, "LDS budget");
 
 __device__ __forceinline__ int sp_stretch(const SpecTables& T, unsigned x) {   // x in 0..32767
   const bool hi = x >= 16384u;
@@ -178,6 +174,9 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   static_assert(N >= 1 && N <= 64, "specialised kernel handles 1..64 components");
   constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
   constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
+  constexpr int kSpecWaves = Chain::WAVES;                 // blocks per workgroup, chosen by the generator
+  constexpr int kSpecWaveLds = spec_wave_lds_bytes(kSpecWaves);
+  static_assert((int)sizeof(SpecTables) + kSpecWaves * kSpecWaveLds <= kSpecLdsBudget, "LDS budget");
 
   __shared__ SpecTables T;
   __shared__ __attribute__((aligned(16))) unsigned char wave_lds[kSpecWaves][kSpecWaveLds];
@@ -205,7 +204,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   // Lanes without a table of some kind point at a private 64-byte dummy slot instead: loads and
   // stores can then be issued by ALL lanes with no exec-mask juggling (divergent branches were a
   // quarter of the instruction stream), and land harmlessly.
-  const unsigned dummy = (unsigned)Chain::OFF_RUN + (unsigned)lane * 64u;
+#ifndef ZPQ_DUMMY_STRIDE
+#define ZPQ_DUMMY_STRIDE 0   // idle lanes share ONE 64-byte line: their accesses coalesce into a single transaction
+#endif
+  const unsigned dummy = (unsigned)Chain::OFF_RUN + (unsigned)lane * (unsigned)ZPQ_DUMMY_STRIDE;
   const unsigned dummy_lds = (unsigned)(kSpecWaveLds - 512) + (unsigned)lane * 8u;
   unsigned type = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63, sizebits = 0;
   unsigned off0 = dummy, off1 = dummy;
@@ -275,6 +277,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   const unsigned roff = has_row ? off1 : dummy;             // base of the bit-history hash table
   const unsigned ldsq = (has_row && ldsoff >= 0) ? (unsigned)ldsoff : dummy_lds;   // side table in LDS
   const bool side_global = has_row && ldsoff < 0;           // side table left in the arena (LDS full)
+  const unsigned soff = side_global ? off0 : dummy;         // base of a side table that stayed in the arena
 
   // ---- per-lane mutable state ----
   unsigned bh = 0;             // ICM/ISSE: bit history of this bit (Component::cxt)
@@ -309,6 +312,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; ssec0[k] = 0; ssec1[k] = 0; }
+  // side tables in the arena: the entry of the NEXT bit is one of two known a bit ahead (both bit
+  // histories sit in the cached row), so both are fetched early; the entry trained by the previous
+  // update is forwarded from registers when the next bit selects it again.  Only with one wavefront
+  // per SIMD: with two, the other wavefront already covers the latency and the extra loads cost
+  // more than they save (2048 x 64 KiB -m5: 1536 ms with, 1420 ms without).
+  constexpr bool kSidePf = Chain::WAVES <= 4;
+  unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
+  unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
   unsigned rw = G32(goff);     // the element of a resident (single-entry) table
   bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
   int ylast = 0;
@@ -387,7 +398,24 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     unsigned q0 = L32(ldsq + 4u * el);
     unsigned q1 = L32(ldsq + 4u * el + (is_icm ? 0u : 4u));
     if constexpr (Chain::ANY_GLOBAL_SIDE) {
-      if (side_global) { q0 = G32(off0 + 4u * e0); q1 = G32(off0 + 4u * e0 + (is_icm ? 0u : 4u)); }
+      const unsigned sidx = side_global ? e0 : 0u;
+      if (nib || !kSidePf) {                                // new row: nothing was fetched ahead
+        const unsigned g0 = G32(soff + 4u * sidx), g1 = G32(soff + 4u * sidx + 4u);
+        q0 = side_global ? g0 : q0;
+        q1 = side_global ? g1 : q1;
+      } else {
+        const bool fwd = sidx == le0;
+        const unsigned g0 = fwd ? ln0 : (ylast ? scb0 : sca0), g1 = fwd ? ln1 : (ylast ? scb1 : sca1);
+        q0 = side_global ? g0 : q0;
+        q1 = side_global ? g1 : q1;
+      }
+      // candidates of the next bit (slots hm4a / hm4b of the same row; this bit's update only touches `slot`)
+      if constexpr (kSidePf) {
+      const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
+      const unsigned ea = side_global ? (is_icm ? bha : 2u * bha) : 0u, eb = side_global ? (is_icm ? bhb : 2u * bhb) : 0u;
+      sca0 = G32(soff + 4u * ea); sca1 = G32(soff + 4u * ea + 4u);
+      scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
+      }
     }
 #ifdef ZPQ_PROF
     const unsigned long long pb1 = __builtin_readcyclecounter();
@@ -530,7 +558,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     L32(ldsq + 4u * el) = n0;
     L32((is_isse && !side_global) ? ldsq + 4u * el + 4u : dummy_lds + 4u) = n1;
     if constexpr (Chain::ANY_GLOBAL_SIDE) {
-      if (side_global) { G32(off0 + 4u * e0) = n0; if (is_isse) G32(off0 + 4u * e0 + 4u) = n1; }
+      // idle lanes write their dummy; an ICM lane keeps word e0+1 (the next entry) unchanged
+      const unsigned sidx = side_global ? e0 : 0u;
+      G32(soff + 4u * sidx) = n0;
+      G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = n1;
+      le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
     }
     // per-bit global word: CM (Predictor::train) or MIX2 weight; idle lanes write their dummy
     const int errcm = yq - (int)(v0 >> 17);

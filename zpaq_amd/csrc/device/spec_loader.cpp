@@ -54,8 +54,14 @@ std::string spec_cache_dir() {
   return lib_dir() + "/spec_cache";
 }
 
-bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not) {
-  if (!generate_spec_source(plan, source, why_not)) return false;
+int spec_variant_forced() {
+  const char* e = getenv("ZPAQ_AMD_SPEC_WAVES");
+  if (!e || !e[0]) return -1;
+  return atoi(e) == 8 ? 1 : 0;
+}
+
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_spec_source(plan, variant == 1 ? 8 : 4, source, why_not)) return false;
   std::string h1, h2;
   const std::string inc = spec_include_dir();
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2)) {
@@ -99,21 +105,22 @@ static bool compile_hiprtc(const std::string& source, std::vector<char>& code, s
   return true;
 }
 
-size_t spec_jit_compile_only(const zpq_plan& plan, std::string& log) {
+size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log) {
   std::string source, key, why;
-  if (!spec_source_and_key(plan, source, key, why)) { log = why; return 0; }
+  if (!spec_source_and_key(plan, variant, source, key, why)) { log = why; return 0; }
   std::vector<char> code;
   if (!compile_hiprtc(source, code, log)) return 0;
   return code.size();
 }
 
-SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit, bool* jit_deferred, bool* did_jit) {
-  if (plan->spec_state > 0) return (SpecKernel*)plan->spec;
-  if (plan->spec_state < 0) return nullptr;
-  plan->spec_state = -1;
+SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* jit_deferred, bool* did_jit) {
+  variant = variant == 1 ? 1 : 0;
+  if (plan->spec_state[variant] > 0) return (SpecKernel*)plan->spec[variant];
+  if (plan->spec_state[variant] < 0) return nullptr;
+  plan->spec_state[variant] = -1;
   if (getenv("ZPAQ_AMD_NO_SPEC")) { plan->spec_note = "disabled by ZPAQ_AMD_NO_SPEC"; return nullptr; }
   std::string source, key, why;
-  if (!spec_source_and_key(*plan, source, key, why)) { plan->spec_note = why; return nullptr; }
+  if (!spec_source_and_key(*plan, variant, source, key, why)) { plan->spec_note = why; return nullptr; }
   std::vector<char> code;
   std::string origin;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
@@ -123,7 +130,7 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit, bool* jit_deferred, 
     origin = "cache:" + key;
   } else {
     if (!allow_jit) {                       // not prebuilt and the caller's JIT budget is spent
-      plan->spec_state = 0;
+      plan->spec_state[variant] = 0;
       plan->spec_note = "hipRTC compile deferred (JIT budget of this batch spent)";
       if (jit_deferred) *jit_deferred = true;
       return nullptr;
@@ -152,20 +159,24 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit, bool* jit_deferred, 
     delete k;
     return nullptr;
   }
+  int maxthr = 0;
+  if (hipFuncGetAttribute(&maxthr, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, k->encode) == hipSuccess && maxthr >= 64)
+    k->waves = maxthr / 64;
   k->origin = origin;
-  plan->spec = k;
-  plan->spec_state = 1;
+  plan->spec[variant] = k;
+  plan->spec_state[variant] = 1;
   plan->spec_note = origin;
   return k;
 }
 
 void spec_kernel_release(zpq_plan* plan) {
-  if (plan && plan->spec) {
-    SpecKernel* k = (SpecKernel*)plan->spec;
+  for (int v = 0; plan && v < 2; ++v) {
+    if (!plan->spec[v]) continue;
+    SpecKernel* k = (SpecKernel*)plan->spec[v];
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
-    plan->spec = nullptr;
-    plan->spec_state = 0;
+    plan->spec[v] = nullptr;
+    plan->spec_state[v] = 0;
   }
 }
 

@@ -11,6 +11,7 @@ struct SpecKernel {
   hipModule_t module = nullptr;
   hipFunction_t encode = nullptr;
   hipFunction_t decode = nullptr;
+  int waves = 4;        // blocks per workgroup (the kernel's launch bound / 64)
   std::string origin;   // "cache:<file>" or "hiprtc"
 };
 
@@ -21,13 +22,17 @@ struct SpecKernel {
 // code object back into the cache directory when that is writable.
 // allow_jit = false: only the in-tree cache is consulted; a miss leaves the plan untried (a later call may
 // compile it) and *jit_deferred is set.
-SpecKernel* spec_kernel_for(zpq_plan* plan, bool allow_jit = true, bool* jit_deferred = nullptr, bool* did_jit = nullptr);
+// variant 0: 4 blocks per workgroup, variant 1: 8 blocks per workgroup (see zpq_plan::spec)
+SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, bool* jit_deferred = nullptr,
+                            bool* did_jit = nullptr);
+// ZPAQ_AMD_SPEC_WAVES=4|8 forces one workgroup shape (tests, experiments, prebuild); -1 when unset
+int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
 
 // Source text + cache key (with the template-header digest) for prebuilding.
-bool spec_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
-size_t spec_jit_compile_only(const zpq_plan& plan, std::string& log);
+size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log);
 std::string spec_include_dir();
 std::string spec_cache_dir();
 

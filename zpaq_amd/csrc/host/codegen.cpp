@@ -11,6 +11,7 @@
 #include "codegen.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -161,13 +162,15 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
 
 }  // namespace
 
-bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string& why_not) {
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not) {
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
   if (ph.arena_bytes >= (1ull << 32)) { why_not = "model state of 4 GiB or more per block"; return false; }
   const CompDesc* comp = plan.comps();
   // LDS plan for the wave's region: H first, then ICM/ISSE side tables while they fit
+  if (waves != 4 && waves != 8) { why_not = "unsupported workgroup shape"; return false; }
+  const int wave_lds = spec_wave_lds_bytes(waves);
   int lds_used = 0, h_lds = -1;
   const int h_bytes = (int)(4u * (ph.hmask + 1));
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
@@ -184,7 +187,7 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
     int lds = -1, slot = -1;
     if (c.type == C_ICM || c.type == C_ISSE) {
       const int bytes = c.type == C_ICM ? 1024 : 2048;
-      if (lds_used + bytes <= kSpecWaveLdsBytes - 512) { lds = lds_used; lds_used += bytes; }   // last 512 B: dummy slots
+      if (lds_used + bytes <= wave_lds - 512) { lds = lds_used; lds_used += bytes; }   // last 512 B: dummy slots
       else any_global_side = true;
     }
     if (c.type == C_CM && c.mask0 < 511u && c.mask0 != 0u) any_nonpf_gl = true;
@@ -196,7 +199,7 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
           << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, " << lds << ","
           << slot << "},\n";
   }
-  o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ";\n"
+  o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ", WAVES = " << waves << ";\n"
     << "  static constexpr unsigned HMASK = " << ph.hmask << "u, MMASK = " << ph.mmask << "u;\n"
     << "  static constexpr int H_LDS = " << h_lds << ";\n"
     << "  static constexpr bool ANY_GLOBAL_SIDE = " << (any_global_side ? "true" : "false")
@@ -209,10 +212,10 @@ bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
   o << "};\n"
        "}  // namespace zpq_gen\n"
-       "extern \"C\" __global__ __launch_bounds__(256) void zpq_spec_encode(const zpq::BlockJob* jobs, "
+       "extern \"C\" __global__ __launch_bounds__(64 * zpq_gen::Chain::WAVES) void zpq_spec_encode(const zpq::BlockJob* jobs, "
        "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
        "  zpq::spec_kernel_body<zpq_gen::Chain, false>(jobs, res, nblocks, tb);\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(256) void zpq_spec_decode(const zpq::BlockJob* jobs, "
+       "extern \"C\" __global__ __launch_bounds__(64 * zpq_gen::Chain::WAVES) void zpq_spec_decode(const zpq::BlockJob* jobs, "
        "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
        "  zpq::spec_kernel_body<zpq_gen::Chain, true>(jobs, res, nblocks, tb);\n}\n";
   source = o.str();

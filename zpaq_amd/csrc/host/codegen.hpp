@@ -11,7 +11,9 @@ static const int kCodegenVersion = 2;
 // Emits the specialised translation unit for `plan`.  Returns false (with a
 // reason) when the chain cannot be specialised (n > 64, MIX wider than a wave,
 // untranslatable HCOMP): such plans run on the generic kernels.
-bool generate_spec_source(const zpq_plan& plan, std::string& source, std::string& why_not);
+// `waves` = blocks per workgroup the kernel is laid out for (4: every side table that fits 30 KiB in LDS,
+// one workgroup per CU; 8: half the LDS per block, two wavefronts per SIMD)
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not);
 
 // Cache key of a generated source: SHA-1 over the text (which embeds the codegen
 // version) -- the loader extends it with a digest of the kernel template headers.

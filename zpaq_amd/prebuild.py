@@ -101,15 +101,24 @@ def main(verbose=True):
     os.makedirs(cache, exist_ok=True)
     jobs, skipped = [], 0
     seen = set()
+    # every header in both workgroup shapes (zpq_plan_spec_source reads ZPAQ_AMD_SPEC_WAVES): 4 blocks per
+    # workgroup for batches of up to 4 x CUs blocks, 8 per workgroup (two wavefronts per SIMD) beyond that
+    forced = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
     for h, why in standard_headers().items():
-        src, key = source_and_key(h)
-        if src is None:
-            skipped += 1
-            continue
-        if key in seen:
-            continue
-        seen.add(key)
-        jobs.append((src, key, cache, inc))
+        for waves in ("4", "8"):
+            os.environ["ZPAQ_AMD_SPEC_WAVES"] = waves
+            src, key = source_and_key(h)
+            if src is None:
+                skipped += waves == "4"
+                continue
+            if key in seen:
+                continue
+            seen.add(key)
+            jobs.append((src, key, cache, inc))
+    if forced is None:
+        del os.environ["ZPAQ_AMD_SPEC_WAVES"]
+    else:
+        os.environ["ZPAQ_AMD_SPEC_WAVES"] = forced
     # drop stale code objects of older template versions
     for fn in os.listdir(cache):
         if fn.endswith(".hsaco") and fn[:-6] not in seen and not os.environ.get("ZPAQ_AMD_KEEP_CACHE"):
