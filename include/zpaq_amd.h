@@ -83,6 +83,9 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
+/* Introspection for tools and tests: the plan as the kernels see it (device/layout.h: PlanHeader,
+ * CompDesc[n], Segment[nseg], HCOMP bytes).  The pointer stays valid until zpq_plan_destroy. */
+const uint8_t* zpq_plan_blob(const zpq_plan*, size_t* len);
 /* Which kernel will code this plan on the current device: 3 specialised,
  * 2 generic wave, 1 generic one-lane.  note (optional) receives where the
  * specialised kernel came from ("cache:<key>" / "hiprtc") or why it is not used. */
@@ -187,7 +190,9 @@ int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hc
                  size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);
 /* Host copies of the predictor's constant tables (for tests): which = 0 squash
  * u16[4096], 1 stretch i16[32768], 2 dt i32[1024], 3 dt2k i32[256], 4 state
- * table u8[1024].  Returns bytes written. */
+ * table u8[1024], 5 ICM initial side table u32[256], 6 ISSE initial side table
+ * u32[512], 7 SSE initial row u32[32] (Predictor::init, libzpaq.cpp:1776-1846).
+ * Returns bytes written. */
 size_t zpq_table(int which, void* out, size_t cap);
 
 #ifdef __cplusplus

@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE: build and run the host-side wavefront emulator (wave_emu.h) for one block header.
+
+The kernel text is exactly what the engine would hand to hipcc / hipRTC (zpq_plan_spec_source); here it is
+compiled for the host against wave_emu.h and executed lane by lane.  Used by tests/test_emu.py."""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+from typing import List, Sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+EMU = os.path.join(ROOT, "tests", "emu")
+BUILD = os.path.join(ROOT, "build", "emu")
+
+
+def kernel_source(header: bytes, waves: int) -> str:
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_spec_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    plan = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    old = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
+    os.environ["ZPAQ_AMD_SPEC_WAVES"] = str(waves)
+    try:
+        rc = L.zpq_plan_spec_source(plan._h, buf, len(buf), C.byref(ln), key)
+    finally:
+        if old is None:
+            del os.environ["ZPAQ_AMD_SPEC_WAVES"]
+        else:
+            os.environ["ZPAQ_AMD_SPEC_WAVES"] = old
+    if rc != 0:
+        raise RuntimeError(L.zpq_last_error().decode())
+    return buf.value.decode()
+
+
+def build(header: bytes, waves: int, extra_flags: Sequence[str] = ()) -> str:
+    """Compile the emulator executable for this header/shape (cached under build/emu); returns its path."""
+    import zpaq_amd as z
+    src = kernel_source(header, waves)
+    deps = b"".join(open(p, "rb").read() for p in (
+        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "emu_main.cpp"),
+        os.path.join(ROOT, "zpaq_amd", "csrc", "device", "spec_kernel.h"),
+        os.path.join(ROOT, "zpaq_amd", "csrc", "device", "layout.h")))
+    key = hashlib.sha1(src.encode() + deps + " ".join(extra_flags).encode()).hexdigest()[:20]
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, f"emu_{key}")
+    if os.path.exists(exe):
+        return exe
+    gen = os.path.join(BUILD, f"gen_{key}.cpp")
+    with open(gen, "w") as fh:
+        fh.write('#include "wave_emu.h"\n' + src)
+    libdir = os.path.dirname(z.library_path())
+    cmd = ["g++", "-O1", "-std=c++17", "-w", *extra_flags, "-I", EMU, "-I", os.path.join(ROOT, "zpaq_amd", "csrc", "device"),
+           "-I", os.path.join(ROOT, "include"), gen, os.path.join(EMU, "emu_main.cpp"), os.path.join(EMU, "wave_emu.cpp"),
+           "-L", libdir, "-lzpaq_amd", f"-Wl,-rpath,{libdir}", "-o", exe + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    os.remove(gen)
+    if r.returncode != 0:
+        raise RuntimeError("emulator build failed:\n" + r.stdout[-4000:])
+    os.replace(exe + ".tmp", exe)
+    return exe
+
+
+def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int = 4, out_cap: int | None = None):
+    """Code every input as one block (one wavefront each).  Returns [(bytes, status, consumed)]."""
+    exe = build(header, waves)
+    cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
+    with tempfile.TemporaryDirectory(dir=BUILD) as td:
+        hp = os.path.join(td, "h.bin")
+        open(hp, "wb").write(header)
+        paths = []
+        for i, d in enumerate(inputs):
+            p = os.path.join(td, f"in{i}")
+            open(p, "wb").write(bytes(d))
+            paths.append(p)
+        r = subprocess.run([exe, "dec" if decode else "enc", str(waves), hp, str(cap), os.path.join(td, "out"), *paths],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(f"emulator failed ({r.returncode}): {r.stderr[-2000:]}")
+        res = []
+        for i in range(len(inputs)):
+            line = [l for l in r.stdout.splitlines() if l.startswith(f"block {i} ")][0].split()
+            status, consumed = int(line[3]), int(line[7])
+            res.append((open(os.path.join(td, f"out.{i}"), "rb").read(), status, consumed))
+        return res

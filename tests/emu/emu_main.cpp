@@ -1,0 +1,134 @@
+// TEST INFRASTRUCTURE -- driver of the host-side wavefront emulator (see wave_emu.h).
+//
+//   emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input> [<input> ...]
+//
+// Runs the generated specialised kernel (compiled into this executable from the text
+// zpq_plan_spec_source returns) over the given inputs, one ZPAQ block per wavefront,
+// `waves` blocks per workgroup, and writes <out_prefix>.<k> for block k.  The plan, the
+// arena layout and the constant tables come from libzpaq_amd.so's host code -- the same
+// objects the engine uploads to the GPU; the arena is initialised here the way
+// init_arena_kernel does it (device/kernels.hip).
+#include "wave_emu.h"
+
+#include <string>
+#include <vector>
+
+#include "layout.h"
+#include "zpaq_amd.h"
+
+extern "C" void zpq_spec_encode(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
+                                const zpq::DeviceTables* tb);
+extern "C" void zpq_spec_decode(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
+                                const zpq::DeviceTables* tb);
+
+namespace {
+
+std::vector<uint8_t> slurp(const char* path) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+  fclose(f);
+  return v;
+}
+
+struct Launch {
+  bool dec;
+  const zpq::BlockJob* jobs;
+  zpq::BlockResult* res;
+  unsigned nblocks;
+  const zpq::DeviceTables* tb;
+};
+
+void kernel_thunk(void* p) {
+  Launch* l = (Launch*)p;
+  if (l->dec) zpq_spec_decode(l->jobs, l->res, l->nblocks, l->tb);
+  else zpq_spec_encode(l->jobs, l->res, l->nblocks, l->tb);
+}
+
+void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb) {
+  const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
+  const zpq::Segment* segs = (const zpq::Segment*)(blob + ph->off_seg);
+  for (uint32_t s = 0; s < ph->nseg; ++s) {
+    const zpq::Segment& sg = segs[s];
+    uint32_t* dst = (uint32_t*)(arena + sg.off);
+    const uint64_t n = sg.bytes / 4;
+    switch (sg.kind) {
+      case zpq::F_ZERO: break;   // calloc'ed
+      case zpq::F_U32: for (uint64_t i = 0; i < n; ++i) dst[i] = sg.value; break;
+      case zpq::F_SSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.sse_row[i & 31] | sg.value; break;
+      case zpq::F_ICM: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.icm_init[i]; break;
+      case zpq::F_ISSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.isse_init[i]; break;
+      case zpq::F_MATCHBUF: dst[0] = 1; break;
+      default: fprintf(stderr, "emu_run: unknown segment kind %u\n", sg.kind); exit(2);
+    }
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 7) { fprintf(stderr, "usage: emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
+  const bool dec = !strcmp(argv[1], "dec");
+  const unsigned waves = (unsigned)atoi(argv[2]);
+  const std::vector<uint8_t> header = slurp(argv[3]);
+  const uint32_t out_cap = (uint32_t)strtoul(argv[4], nullptr, 10);
+  const std::string prefix = argv[5];
+  const unsigned nb = (unsigned)(argc - 6);
+
+  zpq_plan* plan = nullptr;
+  if (zpq_plan_create(header.data(), header.size(), &plan) != 0) { fprintf(stderr, "plan: %s\n", zpq_last_error()); return 2; }
+  size_t blob_len = 0;
+  const uint8_t* blob = zpq_plan_blob(plan, &blob_len);
+  const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
+
+  static zpq::DeviceTables tb;
+  int32_t dt2k[256];
+  if (!zpq_table(1, tb.stretch, sizeof tb.stretch) || !zpq_table(0, tb.squash, sizeof tb.squash) ||
+      !zpq_table(2, tb.dt, sizeof tb.dt) || !zpq_table(3, dt2k, sizeof dt2k) || !zpq_table(4, tb.ns, sizeof tb.ns) ||
+      !zpq_table(5, tb.icm_init, sizeof tb.icm_init) || !zpq_table(6, tb.isse_init, sizeof tb.isse_init) ||
+      !zpq_table(7, tb.sse_row, sizeof tb.sse_row)) { fprintf(stderr, "tables unavailable\n"); return 2; }
+  memcpy(tb.dt2k, dt2k, sizeof dt2k);
+
+  std::vector<std::vector<uint8_t>> ins(nb), outs(nb);
+  std::vector<zpq::BlockJob> jobs(nb);
+  std::vector<zpq::BlockResult> res(nb);
+  // one contiguous arena pool like the engine's, so that neighbouring blocks' arenas touch
+  uint8_t* pool = (uint8_t*)calloc((size_t)nb, ph->arena_bytes);
+  if (!pool) { fprintf(stderr, "arena pool: out of memory\n"); return 2; }
+  for (unsigned b = 0; b < nb; ++b) {
+    ins[b] = slurp(argv[6 + b]);
+    outs[b].assign((size_t)out_cap + 64, 0xEE);
+    init_arena(pool + (size_t)b * ph->arena_bytes, blob, tb);
+    memset(&jobs[b], 0, sizeof(jobs[b]));
+    jobs[b].plan = blob;
+    jobs[b].arena = pool + (size_t)b * ph->arena_bytes;
+    jobs[b].in = ins[b].data();
+    jobs[b].out = outs[b].data();
+    jobs[b].in_len = (uint32_t)ins[b].size();
+    jobs[b].out_cap = out_cap;
+    jobs[b].res_slot = b;
+    res[b] = zpq::BlockResult{0, 0, -1, 0};
+  }
+  Launch l{dec, jobs.data(), res.data(), nb, &tb};
+  for (unsigned wg = 0; wg < (nb + waves - 1) / waves; ++wg) emu::run_workgroup(kernel_thunk, &l, 64 * waves, wg);
+  for (unsigned b = 0; b < nb; ++b) {
+    // guard bytes past the capacity must be untouched
+    for (unsigned k = 0; k < 64; ++k)
+      if (outs[b][(size_t)out_cap + k] != 0xEE) { fprintf(stderr, "block %u wrote past its output capacity\n", b); return 3; }
+    const std::string path = prefix + "." + std::to_string(b);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { perror(path.c_str()); return 2; }
+    const uint32_t n = res[b].out_len < out_cap ? res[b].out_len : out_cap;
+    fwrite(outs[b].data(), 1, n, f);
+    fclose(f);
+    printf("block %u status %d out_len %u consumed %u steps %u\n", b, res[b].status, res[b].out_len, res[b].consumed,
+           res[b].steps);
+  }
+  printf("cross_lane_ops %lu\n", emu::cross_lane_ops());
+  free(pool);
+  zpq_plan_destroy(plan);
+  return 0;
+}

@@ -1,0 +1,150 @@
+// TEST INFRASTRUCTURE -- runtime of the host-side wavefront emulator (see wave_emu.h).
+// One OS thread, one fiber per lane, hand-rolled x86-64 context switch.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+
+#include <vector>
+
+#include "wave_emu.h"
+
+namespace emu {
+
+Dim3 g_threadIdx{0, 0, 0}, g_blockIdx{0, 0, 0}, g_blockDim{1, 1, 1};
+
+enum State { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Fiber {
+  void* sp = nullptr;
+  void* stack = nullptr;
+  unsigned tid = 0;
+  State state = READY;
+  unsigned long nops = 0;      // cross-lane exchanges done (parity selects the exchange buffer)
+};
+
+static const size_t kStack = 512 * 1024;
+static std::vector<Fiber> g_fibers;
+static Fiber* g_cur = nullptr;
+static void* g_sched_sp = nullptr;
+static KernelFn g_fn = nullptr;
+static void* g_args = nullptr;
+static std::vector<int> g_xbuf;          // [wave][2][64]
+static unsigned long g_ops = 0;
+
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch,.-emu_switch
+)");
+
+static void to_scheduler() { emu_switch(&g_cur->sp, g_sched_sp); }
+
+static void trampoline() {
+  g_fn(g_args);
+  g_cur->state = DONE;
+  to_scheduler();
+  abort();   // a finished fiber is never resumed
+}
+
+int lane_id() { return (int)(g_cur->tid & 63u); }
+
+int* wave_exchange(int value) {
+  Fiber* f = g_cur;
+  const unsigned wave = f->tid >> 6, lane = f->tid & 63u;
+  int* buf = &g_xbuf[((size_t)wave * 2 + (f->nops & 1)) * 64];
+  buf[lane] = value;
+  ++f->nops;
+  if (f->tid == 0) ++g_ops;
+  f->state = WAIT_WAVE;
+  to_scheduler();
+  return buf;
+}
+
+void block_barrier() {
+  g_cur->state = WAIT_BLOCK;
+  to_scheduler();
+}
+
+unsigned long cross_lane_ops() { return g_ops; }
+
+void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) {
+  g_fn = fn;
+  g_args = args;
+  g_blockIdx = Dim3{bx, 0, 0};
+  g_blockDim = Dim3{threads, 1, 1};
+  const unsigned waves = (threads + 63) / 64;
+  g_xbuf.assign((size_t)waves * 2 * 64, 0);
+  g_fibers.assign(threads, Fiber{});
+  for (unsigned t = 0; t < threads; ++t) {
+    Fiber& f = g_fibers[t];
+    f.tid = t;
+    f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (f.stack == MAP_FAILED) { perror("mmap"); abort(); }
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // keeps the entry frame 16-byte aligned like a real call
+    *--sp = (void*)&trampoline;      // `ret` target of the first switch
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+    f.sp = sp;
+  }
+  for (;;) {
+    bool ran = false;
+    for (unsigned t = 0; t < threads; ++t) {
+      Fiber& f = g_fibers[t];
+      if (f.state != READY) continue;
+      g_cur = &f;
+      g_threadIdx = Dim3{t, 0, 0};
+      emu_switch(&g_sched_sp, f.sp);
+      ran = true;
+    }
+    // release wavefronts whose live lanes have all arrived at the same exchange
+    unsigned done = 0, at_barrier = 0;
+    for (unsigned w = 0; w < waves; ++w) {
+      unsigned waiting = 0, live = 0;
+      const unsigned lo = w * 64, hi = lo + 64 < threads ? lo + 64 : threads;
+      for (unsigned t = lo; t < hi; ++t) {
+        if (g_fibers[t].state == DONE) { ++done; continue; }
+        ++live;
+        if (g_fibers[t].state == WAIT_WAVE) ++waiting;
+        if (g_fibers[t].state == WAIT_BLOCK) ++at_barrier;
+      }
+      if (live && waiting == live) {
+        for (unsigned t = lo; t < hi; ++t)
+          if (g_fibers[t].state == WAIT_WAVE) g_fibers[t].state = READY;
+        ran = true;
+      }
+    }
+    if (done == threads) break;
+    if (at_barrier && at_barrier + done == threads) {
+      for (unsigned t = 0; t < threads; ++t)
+        if (g_fibers[t].state == WAIT_BLOCK) g_fibers[t].state = READY;
+      ran = true;
+    }
+    if (!ran) { fprintf(stderr, "wave_emu: deadlock -- the lanes of a wavefront disagree about the next cross-lane operation "
+                           "(one sits in divergent control flow) or a barrier is not reached by every thread\n"); abort(); }
+  }
+  for (Fiber& f : g_fibers) munmap(f.stack, kStack);
+  g_fibers.clear();
+}
+
+}  // namespace emu

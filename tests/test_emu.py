@@ -1,0 +1,67 @@
+"""CPU (-m "not gpu"): the DEVICE source of the specialised coder, executed on the host by the wavefront
+emulator under tests/emu (64 lanes as fibers; readlane / DPP / shuffles / LDS modelled after the gfx9 ISA), must
+produce the oracle's bytes.  The GPU parity tests remain the proof for the hardware; this catches logic errors in
+spec_kernel.h and in the generator before a GPU is involved, for both workgroup shapes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import b64, gen_input
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
+
+from zpaq_amd import corpus  # noqa: E402
+
+DEEP_ISSE = "x0,0ci1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1m"
+
+
+def _check(oracle, header, datas, waves):
+    inputs = [b"\0" + bytes(d) for d in datas]
+    enc = emu.run(header, inputs, waves=waves)
+    for inp, (coded, status, consumed) in zip(inputs, enc):
+        assert status == 0 and consumed == len(inp)
+        assert coded == oracle.encode(header, inp)
+    dec = emu.run(header, [c + b"\0\0\0\0" for c, _, _ in enc], decode=True, waves=waves,
+                  out_cap=max(len(x) for x in inputs))
+    for inp, (c, _, _), (plain, status, consumed) in zip(inputs, enc, dec):
+        # a block that fills its capacity exactly stops before the end-of-stream marker
+        assert status == 0 and plain == inp[:len(plain)] and len(plain) == len(inp)
+
+
+def _ragged(n):
+    return [corpus.block("text", n, 5).tobytes(), corpus.block("records", n + 37, 6).tobytes(),
+            corpus.block("lcg", n // 2, 7).tobytes(), corpus.block("zeros", n // 3, 8).tobytes(), b""]
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("method", ["5", "4", "5,128,1"])
+def test_standard_chains_in_both_shapes(zlib_, oracle, method, waves):
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method(method, blk))
+    _check(oracle, header, _ragged(700), waves)
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_side_tables_in_the_arena(zlib_, oracle, waves):
+    """17 ISSE + 1 ICM do not fit a block's LDS in either shape: the last ones stay in the arena
+    (fetched one bit ahead with register forwarding in the 4-block shape)."""
+    header, _, _ = zlib_.method_to_header(DEEP_ISSE)
+    _check(oracle, header, _ragged(900), waves)
+
+
+def test_all_nine_component_types_and_legacy_models(zlib_, oracle, golden):
+    for e in [golden["config_cases"][0]] + golden["level_cases"]:
+        header = bytes.fromhex(e["header"])
+        _check(oracle, header, [gen_input(e).tobytes()[:1500]], 4)
+
+
+def test_random_hcomp_programs(zlib_, oracle, golden):
+    """The generator's HCOMP -> C++ translation (jumps, all operand modes) against the oracle's interpreter."""
+    for e in golden["vm_cases"][:6]:
+        header = bytes.fromhex(e["header"])
+        if header[6] == 0:
+            continue
+        _check(oracle, header, [corpus.block("text", 400, 31).tobytes(), corpus.block("lcg", 300, 32).tobytes()], 4)

@@ -85,6 +85,11 @@ size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
   }
 }
 
+const uint8_t* zpq_plan_blob(const zpq_plan* p, size_t* len) {
+  if (len) *len = p ? p->blob.size() : 0;
+  return p ? p->blob.data() : nullptr;
+}
+
 const char* zpq_spec_cache_dir(void) { static std::string s; s = spec_cache_dir(); return s.c_str(); }
 const char* zpq_spec_include_dir(void) { static std::string s; s = spec_include_dir(); return s.c_str(); }
 
@@ -264,6 +269,9 @@ size_t zpq_table(int which, void* out, size_t cap) {
       case 2: src = t.dt; n = sizeof(t.dt); break;
       case 3: src = t.dt2k; n = sizeof(t.dt2k); break;
       case 4: src = t.ns; n = sizeof(t.ns); break;
+      case 5: src = t.icm_init; n = sizeof(t.icm_init); break;
+      case 6: src = t.isse_init; n = sizeof(t.isse_init); break;
+      case 7: src = t.sse_row; n = sizeof(t.sse_row); break;
       default: return 0;
     }
     if (n > cap) return 0;

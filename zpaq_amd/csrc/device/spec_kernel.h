@@ -30,6 +30,19 @@
 
 #include "layout.h"
 
+// Compiler fences for register values (no instructions): KEEP = "this value is used" (keeps a prefetch
+// load alive), OPAQUE = "forget what you know about this value".  The host-side wavefront emulator
+// (tests/emu, test infrastructure) defines ZPQ_EMU and needs neither.
+#ifndef ZPQ_EMU
+#define ZPQ_KEEP2(a, b) asm volatile("" ::"v"(a), "v"(b))
+#define ZPQ_KEEP3(a, b, c) asm volatile("" ::"v"(a), "v"(b), "v"(c))
+#define ZPQ_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define ZPQ_KEEP2(a, b) ((void)(a), (void)(b))
+#define ZPQ_KEEP3(a, b, c) ((void)(a), (void)(b), (void)(c))
+#define ZPQ_OPAQUE(x) ((void)(x))
+#endif
+
 namespace zpq {
 
 // ---- compile-time description of one component (emitted by the generator) ----
@@ -67,6 +80,15 @@ __device__ __forceinline__ int sp_clamp512k(int x) { return min(max(x, -(1 << 19
 __device__ __forceinline__ int sp_rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ unsigned sp_rlu(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ unsigned sp_uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+// HCOMP's condition flag: wave-uniform by construction; telling the compiler so keeps the VM's
+// branches scalar.  (The emulator runs HCOMP on one lane only -- no cross-lane traffic there.)
+__device__ __forceinline__ unsigned vm_flag(bool c) {
+#ifndef ZPQ_EMU
+  return sp_uni(c ? 1u : 0u);
+#else
+  return c ? 1u : 0u;
+#endif
+}
 __device__ __forceinline__ unsigned long long sp_uni64(unsigned long long v) {
   return (unsigned long long)sp_uni((unsigned)(v >> 32)) << 32 | sp_uni((unsigned)v);
 }
@@ -359,7 +381,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     // (B) ICM / ISSE: bit-history row in registers, probed once per nibble (all lanes take part;
     //     lanes without a row work on their dummy slot)
     if (nib) {
-      asm volatile("" ::"v"(touch_a), "v"(touch_b));
+      ZPQ_KEEP2(touch_a, touch_b);
       const unsigned cx = h + 16u * (unsigned)c8;
       const unsigned chk = (cx >> sizebits) & 255u;
       const unsigned h0 = (cx * 16u) & (rmask - 15u);
@@ -505,7 +527,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     //     id made opaque so that the "lane == I" merges are two cheap VALU ops per step instead of
     //     loop-invariant SGPR masks that spill.
     int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
+    ZPQ_OPAQUE(lane_o);
     if constexpr (kIsseFast) {
 #pragma unroll
       for (int it = 0; it < kIsseDepth; ++it) {
@@ -531,7 +553,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     else pj = __shfl(p, (int)(a2 & 63));
     {
       int lane_u = lane;
-      asm volatile("" : "+v"(lane_u));
+      ZPQ_OPAQUE(lane_u);
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         constexpr CompK c = Chain::comp[i];
@@ -595,11 +617,23 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   // byte k it already computes the contexts of byte k+1 and touches the lines byte k+1 will probe
   // first (hash rows of the first nibble, bit-0 MIX/SSE rows, CM line), which hides the only HBM
   // round trip left exposed per byte.  The decoder cannot (the byte is its output).
+  // HCOMP is wave-uniform work: every lane runs the same program on the same machine state and the
+  // same M/H/R (identical stores from all lanes coalesce).  The host-side emulator (tests/emu) runs
+  // lanes one after the other, so there only lane 0 may apply the program's read-modify-writes.
+  auto run_hcomp = [&](unsigned input) __attribute__((always_inline)) -> int {
+#ifndef ZPQ_EMU
+    return Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+#else
+    int e = 0;
+    if (lane == 0) e = Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    return __builtin_amdgcn_readfirstlane(e);
+#endif
+  };
   unsigned h_next = 0, ka0 = 0, ka1 = 0, ka2 = 0;
   auto run_ahead = [&](int ch) __attribute__((always_inline)) -> int {
-    asm volatile("" ::"v"(ka0), "v"(ka1), "v"(ka2));
+    ZPQ_KEEP3(ka0, ka1, ka2);
     SP_PROF_BEGIN
-    const int e = Chain::hcomp((unsigned)ch, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    const int e = run_hcomp((unsigned)ch);
     SP_PROF_END(2)
     if (e) return e;
     h_next = vm_H[(unsigned)lane & Chain::HMASK];
@@ -626,7 +660,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     if (c8 >= 256) {
       if constexpr (DEC) {
         SP_PROF_BEGIN
-        const int e = Chain::hcomp((unsigned)(c8 - 256), vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+        const int e = run_hcomp((unsigned)(c8 - 256));
         SP_PROF_END(2)
         if (e) return e;
         h = vm_H[(unsigned)lane & Chain::HMASK];

@@ -141,9 +141,9 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
         case 8: st = "a ^= " + v + ";"; break;
         case 9: st = "a <<= ((" + v + ") & 31u);"; break;
         case 10: st = "a >>= ((" + v + ") & 31u);"; break;
-        case 11: st = "f = zpq::sp_uni(a == (" + v + "));"; break;
-        case 12: st = "f = zpq::sp_uni(a < (" + v + "));"; break;
-        default: st = "f = zpq::sp_uni(a > (" + v + "));"; break;
+        case 11: st = "f = zpq::vm_flag(a == (" + v + "));"; break;
+        case 12: st = "f = zpq::vm_flag(a < (" + v + "));"; break;
+        default: st = "f = zpq::vm_flag(a > (" + v + "));"; break;
       }
     } else if (op == 255) { st = jump(prog[pc + 1] + 256 * prog[pc + 2], ""); falls = false; }
     else { st = "goto Lerr;"; falls = false; }

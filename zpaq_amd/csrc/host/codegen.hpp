@@ -6,7 +6,7 @@
 
 namespace zpq {
 
-static const int kCodegenVersion = 2;
+static const int kCodegenVersion = 3;
 
 // Emits the specialised translation unit for `plan`.  Returns false (with a
 // reason) when the chain cannot be specialised (n > 64, MIX wider than a wave,

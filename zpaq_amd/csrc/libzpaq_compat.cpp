@@ -121,7 +121,7 @@ void compress(Reader* in, Writer* out, const char* method, const char* filename,
   }
   const size_t block = ((size_t)0x100000 << bs) - 4096;
   const size_t kBatchBytes = (size_t)1 << 31;   // host staging bound per batch
-  const size_t kBatch = std::max<size_t>(1, std::min<size_t>(1024, kBatchBytes / block));
+  const size_t kBatch = std::max<size_t>(1, std::min<size_t>(2048, kBatchBytes / block));   // 2048 = 8 blocks per CU: two wavefronts per SIMD
   bool first = true, eof = !in;
   while (!eof) {
     std::vector<StringBuffer*> bufs;
