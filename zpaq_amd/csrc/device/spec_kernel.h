@@ -343,6 +343,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
   unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
   unsigned rw = G32(goff);     // the element of a resident (single-entry) table
+  // LDS lookups that update needs but whose index is known during predict are issued there, where
+  // their latency hides behind the dependent chain: both successors of the bit history, the
+  // adaptation rate of the CM word, and squash(p) of every lane (lane N-1's is the coder's probability)
+  unsigned nspair = 0, dtv = 0;
+  int sq = 0;
+  unsigned ssetr[NSSE], ssedt[NSSE];   // SSE: the entry that will be trained and its adaptation rate
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) { ssetr[k] = 0; ssedt[k] = 0; }
   bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
   int ylast = 0;
 
@@ -367,14 +375,22 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   };
 
   // ---------------------------------------------------------------- predict
-  auto predict = [&]() __attribute__((always_inline)) -> unsigned {
-    const bool nib = (c8 == 1) || ((c8 & 0xf0) == 16);
+  // predict / update / after_bit take the bit's position in the byte (0 = first, most significant) as a
+  // compile-time tag: the byte loop is unrolled, and everything that depends only on the position --
+  // nibble starts, early-fetch validity, the hmap4 update rule, byte completion -- is decided at compile
+  // time instead of by a ladder of scalar compares and branches per bit.  Tag -1 = position unknown
+  // (decide at run time; ZPQ_UNROLL_BITS=0).
+  auto predict = [&](auto bitc) __attribute__((always_inline)) -> unsigned {
+    constexpr int B = decltype(bitc)::value;
+    const bool nib = B >= 0 ? (B == 0 || B == 4) : ((c8 == 1) || ((c8 & 0xf0) == 16));
     const int slot = hmap4 & 15;
-    const bool more = c8 < 128;               // another bit of this byte follows
+    const bool more = B >= 0 ? B < 7 : c8 < 128;               // another bit of this byte follows
+    const bool pf_now = B >= 0 ? B > 0 : pf_valid;             // candidates were fetched during the previous bit
+    const bool last_of_nibble = B >= 0 ? B == 3 : (c8 >= 8 && c8 < 16);
     const int c8a = c8 * 2, c8b = c8 * 2 + 1;
-    const int hm4a = (c8a >= 16 && c8a < 32) ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
-    const int hm4b = (c8b >= 16 && c8b < 32) ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
-                                             : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+    const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+    const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                    : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
 #ifdef ZPQ_PROF
     const unsigned long long pb0 = __builtin_readcyclecounter();
 #endif
@@ -407,13 +423,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
       row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
       row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
-    } else if (c8 >= 8 && c8 < 16) {
+    } else if (last_of_nibble) {
       // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
       const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
       touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
       touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
     }
     bh = row_get(row0, row1, row2, row3, slot);                              // bit history
+    nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];            // ns[4*bh] | ns[4*bh+1] << 8
     // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]; idle lanes: their dummy
     const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
     const unsigned el = side_global ? 0u : e0;             // LDS view: a lane whose table is global uses its dummy
@@ -452,7 +469,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     //     on every path.
     unsigned gw;
     gidx = g_index(c8, hmap4);
-    if (pf_valid) {
+    if (pf_now) {
       gw = ylast ? gwc1 : gwc0;
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
         constexpr CompK c = Chain::comp[decltype(ic)::value];
@@ -514,7 +531,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
 #endif
     // (C) MATCH: pure register work (predicted byte and 2048/len were fetched at the byte boundary)
     const bool m_on = is_match && ra != 0;
-    rc = m_on ? ((mpred >> (7 - (31 - __builtin_clz((unsigned)c8)))) & 1u) : rc;
+    const int bitpos = B >= 0 ? B : 31 - __builtin_clz((unsigned)c8);   // bits of this byte already coded
+    rc = m_on ? ((mpred >> (7 - bitpos)) & 1u) : rc;
     const unsigned msx = (rc ? 0u - mdd : mdd) & 32767u;
     // (D) one stretch lookup for every context-only component
     const unsigned sx = is_icm ? (q0 >> 8) : (is_cm ? (gw >> 17) : msx);
@@ -522,6 +540,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     p = (is_icm || is_cm || m_on) ? st : (is_match ? 0 : p);
     v0 = has_row ? q0 : gw;
     v1 = q1;
+    dtv = (unsigned)T.dt[v0 & 0x3ffu];
     // (E) dependent components.  ISSE chains first, all at once, when every ISSE is fed by its left
     //     neighbour; then the rest in index order, unrolled with literal lanes.  `lane_o` is the lane
     //     id made opaque so that the "lane == I" merges are two cheap VALU ops per step instead of
@@ -535,9 +554,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         p = is_isse ? val : p;
       }
     }
-    Dep<Chain, 0>::predict(T, lane_o, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx);
+    Dep<Chain, 0>::predict(T, lane_o, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt);
     pf_valid = more;
-    const unsigned prr = sp_uni((unsigned)sp_squash(T, sp_rl(p, N - 1)));
+    sq = sp_squash(T, sp_clamp2k(p));
+    const unsigned prr = sp_rlu((unsigned)sq, N - 1);     // p[N-1] is already within +-2047
 #ifdef ZPQ_PROF
     prof[6] += __builtin_readcyclecounter() - pb2;
 #endif
@@ -545,7 +565,9 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   };
 
   // ----------------------------------------------------------------- update
-  auto update = [&](int y) __attribute__((always_inline)) {
+  auto update = [&](auto bitc, int y) __attribute__((always_inline)) {
+    constexpr int B = decltype(bitc)::value;
+    const bool byte_done = B >= 0 ? B == 7 : c8 >= 128;          // this bit completes the byte
     const int slot = hmap4 & 15;
     // inputs that live in other lanes: ISSE needs p[j]; MIX2 needs p[j] - p[k]
     int pj, pdiff = 0;
@@ -564,10 +586,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       });
     }
     // every lane's LDS lookups, issued together
-    const int sq = sp_squash(T, sp_clamp2k(p));
-    const unsigned nsv = T.ns[(bh & 255u) * 4u + (unsigned)y];
+    const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
     const unsigned count = v0 & 0x3ffu;
-    const unsigned dtv = (unsigned)T.dt[count];
     const int yq = y * 32767;
     const int err = yq - sq;
     // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
@@ -596,7 +616,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     rw = gnew;
     // MATCH (Predictor::update0 case MATCH, libzpaq.cpp:1985-2008)
     ra = (is_match && (int)rc != y) ? 0u : ra;
-    if (c8 >= 128 && is_match) {                           // this bit completes the byte
+    if (byte_done && is_match) {
       const unsigned mask = mask1;
       G8(off1 + (rlimit & mask)) = (unsigned char)(c8 * 2 + y);
       rlimit = (rlimit + 1) & mask;
@@ -609,7 +629,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       G32(eo) = rlimit;
       if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
     }
-    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx);
+    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
     ylast = y;
   };
 
@@ -654,10 +674,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     return 0;
   };
 
-  auto after_bit = [&](int y) __attribute__((always_inline)) -> int {   // c8 / hmap4 bookkeeping (libzpaq.cpp:2055-2065)
-    { SP_PROF_BEGIN update(y); SP_PROF_END(1) }
+  auto after_bit = [&](auto bitc, int y) __attribute__((always_inline)) -> int {   // c8 / hmap4 bookkeeping (libzpaq.cpp:2055-2065)
+    constexpr int B = decltype(bitc)::value;
+    { SP_PROF_BEGIN update(bitc, y); SP_PROF_END(1) }
     c8 += c8 + y;
-    if (c8 >= 256) {
+    if (B >= 0 ? B == 7 : c8 >= 256) {
       if constexpr (DEC) {
         SP_PROF_BEGIN
         const int e = run_hcomp((unsigned)(c8 - 256));
@@ -669,12 +690,24 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       }
       hmap4 = 1;
       c8 = 1;
-    } else if (c8 >= 16 && c8 < 32) {
+    } else if (B >= 0 ? B == 3 : (c8 >= 16 && c8 < 32)) {
       hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
     } else {
       hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + y) & 0xf);
     }
     return 0;
+  };
+
+  // the 8 bits of a byte: unrolled with the position as a compile-time tag, or a plain loop (tag -1)
+#ifndef ZPQ_UNROLL_BITS
+#define ZPQ_UNROLL_BITS 1
+#endif
+  auto for_bits = [&](auto&& f) __attribute__((always_inline)) {
+    if constexpr (ZPQ_UNROLL_BITS) {
+      static_for<0, 8>([&](auto ic) __attribute__((always_inline)) { f(ic, decltype(ic)::value); });
+    } else {
+      for (int pos = 0; pos < 8; ++pos) f(IC<-1>{}, pos);
+    }
   };
 
   if (!DEC) {
@@ -695,15 +728,15 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       status = run_ahead(ch);
       if (status) break;
       encode(0, 0);
-      for (int i = 7; i >= 0; --i) {
+      for_bits([&](auto bitc, int pos) __attribute__((always_inline)) {
+        if (status) return;
         unsigned pr;
-        { SP_PROF_BEGIN pr = predict(); SP_PROF_END(0) }
-        const int y = (ch >> i) & 1;
+        { SP_PROF_BEGIN pr = predict(bitc); SP_PROF_END(0) }
+        const int y = (ch >> (7 - pos)) & 1;
         encode(y, pr * 2 + 1);
-        status = after_bit(y);
+        status = after_bit(bitc, y);
         ++steps;
-        if (status) break;
-      }
+      });
     }
     if (!status) encode(1, 0);
     if (!status && n > job.out_cap) status = 3;
@@ -715,32 +748,35 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       if (rp >= job.in_len) { status = 6; break; }
       curr = curr << 8 | sp_uni(in_ptr[rp++]);
     }
+    // Decoder::decode (libzpaq.cpp:2159-2181); sets `status` on a corrupt or truncated stream
+    auto decode = [&](unsigned pr) __attribute__((always_inline)) -> int {
+      if (curr < low || curr > high) { status = 2; return 0; }
+      const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
+      int y;
+      if (curr <= mid) { y = 1; high = mid; } else { y = 0; low = mid + 1; }
+      while ((high ^ low) < 0x1000000u) {
+        high = high << 8 | 255u;
+        low = low << 8;
+        low += (low == 0);
+        if (rp >= job.in_len) { status = 6; break; }
+        curr = curr << 8 | sp_uni(in_ptr[rp++]);
+      }
+      return y;
+    };
     while (!status && !eos && n < job.out_cap) {
       int ch = 1;
-      for (int bit = -1; bit < 8; ++bit) {
-        unsigned pr = 0;
-        if (bit >= 0) pr = predict() * 2 + 1;
-        if (curr < low || curr > high) { status = 2; break; }
-        const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
-        int y;
-        if (curr <= mid) { y = 1; high = mid; } else { y = 0; low = mid + 1; }
-        while ((high ^ low) < 0x1000000u) {
-          high = high << 8 | 255u;
-          low = low << 8;
-          low += (low == 0);
-          if (rp >= job.in_len) { status = 6; break; }
-          curr = curr << 8 | sp_uni(in_ptr[rp++]);
-        }
-        if (status) break;
-        if (bit < 0) {
-          if (y) { eos = true; if (curr != 0) status = 2; break; }
-        } else {
-          ch += ch + y;
-          status = after_bit(y);
-          ++steps;
-          if (status) break;
-        }
-      }
+      const int flag = decode(0);                       // end-of-stream flag, coded with p = 0
+      if (status) break;
+      if (flag) { eos = true; if (curr != 0) status = 2; break; }
+      for_bits([&](auto bitc, int) __attribute__((always_inline)) {
+        if (status) return;
+        const unsigned pr = predict(bitc) * 2 + 1;
+        const int y = decode(pr);
+        if (status) return;
+        ch += ch + y;
+        status = after_bit(bitc, y);
+        ++steps;
+      });
       if (status || eos) break;
       if (lane == 0) out_ptr[n] = (unsigned char)(ch - 256);
       ++n;
@@ -763,7 +799,8 @@ template <class Chain, int I>
 struct Dep {
   template <int NM, int NS>
   static __device__ __forceinline__ void predict(const SpecTables& T, int lane, int c8, int& p, int w0, int w1,
-                                                 int (&mixw)[NM], unsigned (&ssev)[NS], unsigned (&ssecx)[NS]) {
+                                                 int (&mixw)[NM], unsigned (&ssev)[NS], unsigned (&ssecx)[NS],
+                                                 unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_ISSE) {
@@ -795,16 +832,18 @@ struct Dep {
         const unsigned e0 = sp_rlu(ssev[c.slot], pq), e1 = sp_rlu(ssev[c.slot], pq + 1);
         const int val = sp_stretch(T, ((e0 >> 10) * (unsigned)(64 - wt) + (e1 >> 10) * (unsigned)wt) >> 13);
         p = lane == I ? val : p;
-        ssecx[c.slot] += (unsigned)(pq + (wt >> 5));        // element trained in update
+        ssecx[c.slot] += (unsigned)(pq + (wt >> 5));        // element trained in update ...
+        ssetr[c.slot] = (wt >> 5) ? e1 : e0;                // ... which is one of the two just read
+        ssedt[c.slot] = (unsigned)T.dt[ssetr[c.slot] & 0x3ffu];
       }
-      Dep<Chain, I + 1>::predict(T, lane, c8, p, w0, w1, mixw, ssev, ssecx);
+      Dep<Chain, I + 1>::predict(T, lane, c8, p, w0, w1, mixw, ssev, ssecx, ssetr, ssedt);
     }
   }
 
   template <int NM, int NS>
   static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int sq, int p,
                                                 int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&ssev)[NS],
-                                                unsigned (&ssecx)[NS]) {
+                                                unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_MIX) {
@@ -817,14 +856,14 @@ struct Dep {
       } else if constexpr (c.type == C_SSE) {
         // Predictor::train on cm[cxt]; the word is still in lane (cxt & 31) of the row registers
         const unsigned e = ssecx[c.slot];
-        const unsigned v = sp_rlu(ssev[c.slot], (int)(e & 31u));
+        const unsigned v = ssetr[c.slot];
         const unsigned count = v & 0x3ffu;
         const int err = y * 32767 - (int)(v >> 17);
-        const unsigned prod = (unsigned)err * (unsigned)T.dt[count];
+        const unsigned prod = (unsigned)err * ssedt[c.slot];
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
         *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
       }
-      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx);
+      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
     }
   }
 };
