@@ -154,7 +154,7 @@ constexpr bool sse_pf(const CompK& c) { return c.mask0 >= 32u * 256u - 1u; }
 __device__ __forceinline__ int sp_mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 
 // value of the lane to the left (lane 0 receives 0): DPP wave_shr:1
-__device__ __forceinline__ int sp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int sp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
 
 // ISSE fast path: every ISSE takes its input from the lane on its left, and that lane is a
 // context-only component or another ISSE.  Then all ISSE chains of the model are resolved together
@@ -342,6 +342,24 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   constexpr bool kSidePf = Chain::WAVES <= 4;
   unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
   unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
+  // MIX / SSE rows: lane t reads word t of the selected row.  The lane's part of the address (table base +
+  // 4 t) is loop invariant and kept in a register the compiler may not look through: otherwise it folds the
+  // table base into 64-bit pointer arithmetic and spends four instructions per load instead of one add.
+  unsigned mixbase[NMIX], ssebase[NSSE];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) mixbase[k] = dummy;
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) ssebase[k] = dummy;
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr CompK c = Chain::comp[decltype(ic)::value];
+    if constexpr (c.type == C_MIX) {
+      mixbase[c.slot] = (unsigned)c.t0 + 4u * (unsigned)min(lane, (int)c.a3 - 1);
+      ZPQ_OPAQUE(mixbase[c.slot]);
+    } else if constexpr (c.type == C_SSE) {
+      ssebase[c.slot] = (unsigned)c.t0 + 4u * (unsigned)(lane & 31);
+      ZPQ_OPAQUE(ssebase[c.slot]);
+    }
+  });
   unsigned rw = G32(goff);     // the element of a resident (single-entry) table
   // LDS lookups that update needs but whose index is known during predict are issued there, where
   // their latency hides behind the dependent chain: both successors of the bit history, the
@@ -486,11 +504,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) {
           const unsigned r = ((sp_rlu(h, i) + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
-          mixw[c.slot] = (int)G32((unsigned)c.t0 + 4u * (r + (unsigned)min(lane, (int)c.a3 - 1)));
+          mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * r);
         }
         if constexpr (c.type == C_SSE && sse_pf(c)) {
           const unsigned cx0 = ((sp_rlu(h, i) + (unsigned)c8) * 32u) & c.mask0;
-          ssev[c.slot] = G32((unsigned)c.t0 + 4u * (cx0 + (unsigned)(lane & 31)));
+          ssev[c.slot] = G32(ssebase[c.slot] + 4u * cx0);
         }
       });
     }
@@ -499,23 +517,21 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         const unsigned hi = sp_rlu(h, i);
-        const unsigned ln = (unsigned)min(lane, (int)c.a3 - 1);
         mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
         if constexpr (mix_pf(c)) {
-          mixc0[c.slot] = (int)G32((unsigned)c.t0 + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3 + ln));
-          mixc1[c.slot] = (int)G32((unsigned)c.t0 + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3 + ln));
+          mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3));
+          mixc1[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3));
         } else {
-          mixw[c.slot] = (int)G32((unsigned)c.t0 + 4u * (mixrow[c.slot] + ln));
+          mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
         }
       } else if constexpr (c.type == C_SSE) {
         const unsigned hi = sp_rlu(h, i);
-        const unsigned ln = (unsigned)(lane & 31);
         ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
         if constexpr (sse_pf(c)) {
-          ssec0[c.slot] = G32((unsigned)c.t0 + 4u * ((((hi + (unsigned)c8a) * 32u) & c.mask0) + ln));
-          ssec1[c.slot] = G32((unsigned)c.t0 + 4u * ((((hi + (unsigned)c8b) * 32u) & c.mask0) + ln));
+          ssec0[c.slot] = G32(ssebase[c.slot] + 4u * (((hi + (unsigned)c8a) * 32u) & c.mask0));
+          ssec1[c.slot] = G32(ssebase[c.slot] + 4u * (((hi + (unsigned)c8b) * 32u) & c.mask0));
         } else {
-          ssev[c.slot] = G32((unsigned)c.t0 + 4u * (ssecx[c.slot] + ln));
+          ssev[c.slot] = G32(ssebase[c.slot] + 4u * ssecx[c.slot]);
         }
       }
     });
@@ -548,11 +564,12 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     int lane_o = lane;
     ZPQ_OPAQUE(lane_o);
     if constexpr (kIsseFast) {
+      // every lane runs the same multiply-add; lanes that are not ISSE use weight 0 and addend p << 16,
+      // which reproduces their p (all predictions are within +-2047, so the clamp is the identity)
+      const int iw = is_isse ? (int)v0 : 0;
+      const int ia = is_isse ? (int)v1 * 64 : (int)((unsigned)p << 16);
 #pragma unroll
-      for (int it = 0; it < kIsseDepth; ++it) {
-        const int val = sp_clamp2k(sp_mad24((int)v0, sp_shr1(p), (int)v1 * 64) >> 16);
-        p = is_isse ? val : p;
-      }
+      for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
     }
     Dep<Chain, 0>::predict(T, lane_o, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt);
     pf_valid = more;
@@ -629,7 +646,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       G32(eo) = rlimit;
       if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
     }
-    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
+    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, mixbase, ssev, ssecx, ssetr, ssedt);
     ylast = y;
   };
 
@@ -665,10 +682,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         const unsigned r = ((sp_rlu(h_next, i) + (1u & c.a5)) & c.mask0) * c.a3;
-        ka2 ^= G32((unsigned)c.t0 + 4u * (r + (unsigned)min(lane, (int)c.a3 - 1)));
+        ka2 ^= G32(mixbase[c.slot] + 4u * r);
       } else if constexpr (c.type == C_SSE) {
         const unsigned cx0 = ((sp_rlu(h_next, i) + 1u) * 32u) & c.mask0;
-        ka2 ^= G32((unsigned)c.t0 + 4u * (cx0 + (unsigned)(lane & 31)));
+        ka2 ^= G32(ssebase[c.slot] + 4u * cx0);
       }
     });
     return 0;
@@ -842,8 +859,9 @@ struct Dep {
 
   template <int NM, int NS>
   static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int sq, int p,
-                                                int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&ssev)[NS],
-                                                unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
+                                                int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&mixbase)[NM],
+                                                unsigned (&ssev)[NS], unsigned (&ssecx)[NS], unsigned (&ssetr)[NS],
+                                                unsigned (&ssedt)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_MIX) {
@@ -851,7 +869,7 @@ struct Dep {
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
         const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, pin, 1 << 12) >> 13));
-        const unsigned wo = lane < (int)c.a3 ? (unsigned)c.t0 + 4u * (mixrow[c.slot] + (unsigned)lane) : dummy;
+        const unsigned wo = lane < (int)c.a3 ? mixbase[c.slot] + 4u * mixrow[c.slot] : dummy;
         *(g_i32*)(arena + wo) = w;
       } else if constexpr (c.type == C_SSE) {
         // Predictor::train on cm[cxt]; the word is still in lane (cxt & 31) of the row registers
@@ -863,7 +881,7 @@ struct Dep {
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
         *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
       }
-      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
+      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, mixbase, ssev, ssecx, ssetr, ssedt);
     }
   }
 };
