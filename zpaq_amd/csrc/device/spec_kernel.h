@@ -93,6 +93,22 @@ __device__ __forceinline__ unsigned long long sp_uni64(unsigned long long v) {
   return (unsigned long long)sp_uni((unsigned)(v >> 32)) << 32 | sp_uni((unsigned)v);
 }
 
+// sum of lanes 0..LANES-1 (the other lanes hold 0); result wave-uniform.  Row scans by DPP, then one
+// readlane per 16-lane row that can hold an input.
+template <int LANES>
+__device__ __forceinline__ int sp_lanes_sum(int x) {
+  int v = x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  int s = sp_rl(v, 15);
+  if constexpr (LANES > 16) s += sp_rl(v, 31);
+  if constexpr (LANES > 32) s += sp_rl(v, 47);
+  if constexpr (LANES > 48) s += sp_rl(v, 63);
+  return s;
+}
+
 // 64-lane integer sum (DPP row scans + row broadcasts); result wave-uniform.
 __device__ __forceinline__ int sp_wave_sum(int x) {
   int v = x;
@@ -287,6 +303,8 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   const bool is_cm = (M_CM >> lane) & 1, is_icm = (M_ICM >> lane) & 1, is_isse = (M_ISSE >> lane) & 1;
   const bool is_match = (M_MATCH >> lane) & 1, is_mix2 = (M_MIX2 >> lane) & 1;
   const bool has_row = is_icm || is_isse;
+  const bool is_ctx = is_cm || is_icm || is_match;   // prediction = one stretch lookup
+  const unsigned ctx_shift = is_icm ? 8u : 17u;
   const bool gl = is_cm || is_mix2;           // lanes with one global table word per bit
   // may the next bit's word be fetched one bit early?  Only if consecutive bits can never
   // address the same element (else the early copy could miss this bit's update)
@@ -549,13 +567,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const bool m_on = is_match && ra != 0;
     const int bitpos = B >= 0 ? B : 31 - __builtin_clz((unsigned)c8);   // bits of this byte already coded
     rc = m_on ? ((mpred >> (7 - bitpos)) & 1u) : rc;
-    const unsigned msx = (rc ? 0u - mdd : mdd) & 32767u;
-    // (D) one stretch lookup for every context-only component
-    const unsigned sx = is_icm ? (q0 >> 8) : (is_cm ? (gw >> 17) : msx);
-    const int st = sp_stretch(T, sx & 32767u);
-    p = (is_icm || is_cm || m_on) ? st : (is_match ? 0 : p);
+    // no match: predict stretch(16384) = 0 (Predictor::predict0 case MATCH, "p[i]=0")
+    const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
     v0 = has_row ? q0 : gw;
     v1 = q1;
+    // (D) one stretch lookup for every context-only component: ICM looks up cm >> 8, CM cm >> 17
+    const unsigned sx = is_match ? msx : (v0 >> ctx_shift);
+    const int st = sp_stretch(T, sx & 32767u);
+    p = is_ctx ? st : p;
     dtv = (unsigned)T.dt[v0 & 0x3ffu];
     // (E) dependent components.  ISSE chains first, all at once, when every ISSE is fed by its left
     //     neighbour; then the rest in index order, unrolled with literal lanes.  `lane_o` is the lane
@@ -627,7 +646,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int errcm = yq - (int)(v0 >> 17);
     const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
     const int err2 = __mul24(err, (int)a4) >> 5;
-    const int w2 = min(max((int)v0 + ((err2 * pdiff + (1 << 12)) >> 13), 0), 65535);
+    const int w2 = min(max((int)v0 + (sp_mad24(err2, pdiff, 1 << 12) >> 13), 0), 65535);   // 19-bit x 13-bit
     const unsigned gnew = is_cm ? cm_new : (unsigned)w2;
     G32(goff + 4u * gidx) = gnew;
     rw = gnew;
@@ -832,14 +851,14 @@ struct Dep {
         p = lane == I ? val : p;
       } else if constexpr (c.type == C_MIX2) {
         const int pj = sp_rl(p, (int)c.a2), pk = sp_rl(p, (int)c.a3);
-        const int val = (w0 * pj + (65536 - w0) * pk) >> 16;
+        const int val = sp_mad24(w0, pj, __mul24(65536 - w0, pk)) >> 16;   // 17-bit x 12-bit products
         p = lane == I ? val : p;
       } else if constexpr (c.type == C_MIX) {
         // inputs p[j..j+m-1] sit in lanes j..j+m-1; weight t sits in lane t
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
         const int x = lane < (int)c.a3 ? __mul24(mixw[c.slot] >> 8, pin) : 0;
-        const int val = sp_clamp2k(sp_wave_sum(x) >> 8);
+        const int val = sp_clamp2k(sp_lanes_sum<(int)c.a3>(x) >> 8);
         p = lane == I ? val : p;
       } else if constexpr (c.type == C_SSE) {
         int pq = sp_rl(p, (int)c.a2) + 992;
@@ -877,7 +896,7 @@ struct Dep {
         const unsigned v = ssetr[c.slot];
         const unsigned count = v & 0x3ffu;
         const int err = y * 32767 - (int)(v >> 17);
-        const unsigned prod = (unsigned)err * ssedt[c.slot];
+        const unsigned prod = (unsigned)__mul24(err, (int)ssedt[c.slot]);    // low 32 bits, like Predictor::train
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
         *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
       }
