@@ -153,6 +153,19 @@ __device__ __forceinline__ void row_set(unsigned& r0, unsigned& r1, unsigned& r2
 template <class Chain, int I>
 struct Dep;   // forward
 
+// Per-lane constants of the dependent components, as VGPR masks / offsets (see lane_mask in the kernel
+// body): on gfx950 a v_cmp that writes an SGPR mask needs two wait states before a v_cndmask may read
+// it, so "lane == I ? a : b" costs three issue slots; a blend with a ready mask costs one.
+template <int N, int NM, int NS>
+struct LaneK {
+  unsigned is[N];       // all ones in lane i
+  unsigned mixin[NM];   // all ones in the lanes that hold an input / weight of MIX slot k (lane < m)
+  unsigned mixst[NM];   // where the lane stores its weight of the selected row: table base + 4 lane, or the dummy
+  unsigned ssest[NS];   // lane 0: SSE table base, other lanes: the dummy
+  unsigned lane0;       // all ones in lane 0
+};
+__device__ __forceinline__ unsigned sp_blend(unsigned m, unsigned a, unsigned b) { return (a & m) | (b & ~m); }
+
 // compile-time loop: f(IC<B>{}), f(IC<B+1>{}), ...
 template <int I> struct IC { static constexpr int value = I; };
 template <int B, int E, class F>
@@ -318,6 +331,25 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   const unsigned ldsq = (has_row && ldsoff >= 0) ? (unsigned)ldsoff : dummy_lds;   // side table in LDS
   const bool side_global = has_row && ldsoff < 0;           // side table left in the arena (LDS full)
   const unsigned soff = side_global ? off0 : dummy;         // base of a side table that stayed in the arena
+  // Lane-class selects in the per-bit code are bit blends with per-lane constant masks held in
+  // VGPRs (one v_bfi_b32 each), not v_cndmask on loop-invariant SGPR-pair predicates: the bit loop
+  // had run out of SGPRs and was spilling those predicates to VGPR lanes.  The masks are opaque to
+  // the optimiser, which otherwise rewrites the lane classes as range tests on the lane id.
+  auto lane_mask = [&](bool b) __attribute__((always_inline)) -> unsigned {
+    unsigned m = b ? 0xFFFFFFFFu : 0u;
+    ZPQ_OPAQUE(m);
+    return m;
+  };
+  auto blend = [](unsigned m, unsigned a, unsigned b) __attribute__((always_inline)) -> unsigned {
+    return (a & m) | (b & ~m);
+  };
+  const unsigned m_cm = lane_mask(is_cm), m_isse = lane_mask(is_isse), m_icm = lane_mask(is_icm);
+  const unsigned m_match = lane_mask(is_match), m_row = lane_mask(has_row), m_ctx = lane_mask(is_ctx);
+  const unsigned m_res = lane_mask(resident), m_pf = lane_mask(pf_lane);
+  const unsigned m_lds2 = lane_mask(is_isse && !side_global);     // lanes with a second side-table word in LDS
+  const unsigned bh_shift = is_isse ? 1u : 0u;                    // ISSE entries are two words wide
+  const unsigned q1off = is_icm ? 0u : 4u;
+  const unsigned n1base = (is_isse && !side_global) ? ldsq + 4u : dummy_lds + 4u;
 
   // ---- per-lane mutable state ----
   unsigned bh = 0;             // ICM/ISSE: bit history of this bit (Component::cxt)
@@ -376,6 +408,27 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     } else if constexpr (c.type == C_SSE) {
       ssebase[c.slot] = (unsigned)c.t0 + 4u * (unsigned)(lane & 31);
       ZPQ_OPAQUE(ssebase[c.slot]);
+    }
+  });
+  LaneK<N, NMIX, NSSE> lk;
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) { lk.mixin[k] = 0; lk.mixst[k] = dummy; }
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) lk.ssest[k] = dummy;
+  lk.lane0 = lane_mask(lane == 0);
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr CompK c = Chain::comp[i];
+    lk.is[i] = 0;
+    if constexpr (c.type == C_AVG || c.type == C_MIX2 || c.type == C_MIX || c.type == C_SSE || c.type == C_ISSE)
+      lk.is[i] = lane_mask(lane == i);
+    if constexpr (c.type == C_MIX) {
+      lk.mixin[c.slot] = lane_mask(lane < (int)c.a3);
+      lk.mixst[c.slot] = lane < (int)c.a3 ? (unsigned)c.t0 + 4u * (unsigned)lane : dummy;
+      ZPQ_OPAQUE(lk.mixst[c.slot]);
+    } else if constexpr (c.type == C_SSE) {
+      lk.ssest[c.slot] = lane == 0 ? (unsigned)c.t0 : dummy;
+      ZPQ_OPAQUE(lk.ssest[c.slot]);
     }
   });
   unsigned rw = G32(goff);     // the element of a resident (single-entry) table
@@ -468,10 +521,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     bh = row_get(row0, row1, row2, row3, slot);                              // bit history
     nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];            // ns[4*bh] | ns[4*bh+1] << 8
     // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]; idle lanes: their dummy
-    const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
+    const unsigned e0 = (bh << bh_shift) & m_row;
     const unsigned el = side_global ? 0u : e0;             // LDS view: a lane whose table is global uses its dummy
     unsigned q0 = L32(ldsq + 4u * el);
-    unsigned q1 = L32(ldsq + 4u * el + (is_icm ? 0u : 4u));
+    unsigned q1 = L32(ldsq + 4u * el + q1off);
     if constexpr (Chain::ANY_GLOBAL_SIDE) {
       const unsigned sidx = side_global ? e0 : 0u;
       if (nib || !kSidePf) {                                // new row: nothing was fetched ahead
@@ -554,11 +607,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       }
     });
     {
-      const unsigned ia = pf_lane ? g_index(c8a, hm4a) : 0u, ib = pf_lane ? g_index(c8b, hm4b) : 0u;
+      const unsigned ia = g_index(c8a, hm4a) & m_pf, ib = g_index(c8b, hm4b) & m_pf;
       gwc0 = G32(goff + 4u * ia);
       gwc1 = G32(goff + 4u * ib);
     }
-    gw = resident ? rw : gw;
+    gw = blend(m_res, rw, gw);
 #ifdef ZPQ_PROF
     const unsigned long long pb2 = __builtin_readcyclecounter();
     prof[5] += pb2 - pb1;
@@ -569,28 +622,25 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     rc = m_on ? ((mpred >> (7 - bitpos)) & 1u) : rc;
     // no match: predict stretch(16384) = 0 (Predictor::predict0 case MATCH, "p[i]=0")
     const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
-    v0 = has_row ? q0 : gw;
+    v0 = blend(m_row, q0, gw);
     v1 = q1;
     // (D) one stretch lookup for every context-only component: ICM looks up cm >> 8, CM cm >> 17
-    const unsigned sx = is_match ? msx : (v0 >> ctx_shift);
+    const unsigned sx = blend(m_match, msx, v0 >> ctx_shift);
     const int st = sp_stretch(T, sx & 32767u);
-    p = is_ctx ? st : p;
+    p = (int)blend(m_ctx, (unsigned)st, (unsigned)p);
     dtv = (unsigned)T.dt[v0 & 0x3ffu];
     // (E) dependent components.  ISSE chains first, all at once, when every ISSE is fed by its left
-    //     neighbour; then the rest in index order, unrolled with literal lanes.  `lane_o` is the lane
-    //     id made opaque so that the "lane == I" merges are two cheap VALU ops per step instead of
-    //     loop-invariant SGPR masks that spill.
-    int lane_o = lane;
-    ZPQ_OPAQUE(lane_o);
+    //     neighbour; then the rest in index order, unrolled with literal lanes; results are merged
+    //     into p with the per-lane masks of `lk`.
     if constexpr (kIsseFast) {
       // every lane runs the same multiply-add; lanes that are not ISSE use weight 0 and addend p << 16,
       // which reproduces their p (all predictions are within +-2047, so the clamp is the identity)
-      const int iw = is_isse ? (int)v0 : 0;
-      const int ia = is_isse ? (int)v1 * 64 : (int)((unsigned)p << 16);
+      const int iw = (int)(v0 & m_isse);
+      const int ia = (int)blend(m_isse, v1 << 6, (unsigned)p << 16);
 #pragma unroll
       for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
     }
-    Dep<Chain, 0>::predict(T, lane_o, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt);
+    Dep<Chain, 0>::predict(T, lane, lk, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt);
     pf_valid = more;
     sq = sp_squash(T, sp_clamp2k(p));
     const unsigned prr = sp_rlu((unsigned)sq, N - 1);     // p[N-1] is already within +-2047
@@ -609,18 +659,14 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     int pj, pdiff = 0;
     if constexpr (kIsseFast) pj = sp_shr1(p);
     else pj = __shfl(p, (int)(a2 & 63));
-    {
-      int lane_u = lane;
-      ZPQ_OPAQUE(lane_u);
-      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        constexpr CompK c = Chain::comp[i];
-        if constexpr (c.type == C_MIX2) {
-          const int d = sp_rl(p, (int)c.a2) - sp_rl(p, (int)c.a3);
-          pdiff = lane_u == i ? d : pdiff;
-        }
-      });
-    }
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_MIX2) {
+        const int d = sp_rl(p, (int)c.a2) - sp_rl(p, (int)c.a3);
+        pdiff |= (int)((unsigned)d & lk.is[i]);
+      }
+    });
     // every lane's LDS lookups, issued together
     const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
     const unsigned count = v0 & 0x3ffu;
@@ -628,13 +674,13 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int err = yq - sq;
     // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
     row_set(row0, row1, row2, row3, slot, nsv);
-    const unsigned n0 = is_icm ? v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2)
-                               : (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13));
+    const unsigned n0 = blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
+                              (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
     const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-    const unsigned e0 = is_icm ? bh : (is_isse ? 2u * bh : 0u);
+    const unsigned e0 = (bh << bh_shift) & m_row;
     const unsigned el = side_global ? 0u : e0;
     L32(ldsq + 4u * el) = n0;
-    L32((is_isse && !side_global) ? ldsq + 4u * el + 4u : dummy_lds + 4u) = n1;
+    L32(n1base + ((4u * el) & m_lds2)) = n1;
     if constexpr (Chain::ANY_GLOBAL_SIDE) {
       // idle lanes write their dummy; an ICM lane keeps word e0+1 (the next entry) unchanged
       const unsigned sidx = side_global ? e0 : 0u;
@@ -647,7 +693,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
     const int err2 = __mul24(err, (int)a4) >> 5;
     const int w2 = min(max((int)v0 + (sp_mad24(err2, pdiff, 1 << 12) >> 13), 0), 65535);   // 19-bit x 13-bit
-    const unsigned gnew = is_cm ? cm_new : (unsigned)w2;
+    const unsigned gnew = blend(m_cm, cm_new, (unsigned)w2);
     G32(goff + 4u * gidx) = gnew;
     rw = gnew;
     // MATCH (Predictor::update0 case MATCH, libzpaq.cpp:1985-2008)
@@ -665,7 +711,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       G32(eo) = rlimit;
       if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
     }
-    Dep<Chain, 0>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, mixbase, ssev, ssecx, ssetr, ssedt);
+    Dep<Chain, 0>::update(T, arena, lane, lk, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
     ylast = y;
   };
 
@@ -834,32 +880,32 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
 template <class Chain, int I>
 struct Dep {
   template <int NM, int NS>
-  static __device__ __forceinline__ void predict(const SpecTables& T, int lane, int c8, int& p, int w0, int w1,
-                                                 int (&mixw)[NM], unsigned (&ssev)[NS], unsigned (&ssecx)[NS],
-                                                 unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
+  static __device__ __forceinline__ void predict(const SpecTables& T, int lane, const LaneK<Chain::N, NM, NS>& lk, int c8,
+                                                 int& p, int w0, int w1, int (&mixw)[NM], unsigned (&ssev)[NS],
+                                                 unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_ISSE) {
         if constexpr (!isse_left_fed<Chain>()) {
           const int pj = sp_rl(p, (int)c.a2);
           const int val = sp_clamp2k(sp_mad24(w0, pj, w1 * 64) >> 16);
-          p = lane == I ? val : p;
+          p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
         }
       } else if constexpr (c.type == C_AVG) {
         const int pj = sp_rl(p, (int)c.a1), pk = sp_rl(p, (int)c.a2);
         const int val = (pj * (int)c.a3 + pk * (256 - (int)c.a3)) >> 8;
-        p = lane == I ? val : p;
+        p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
       } else if constexpr (c.type == C_MIX2) {
         const int pj = sp_rl(p, (int)c.a2), pk = sp_rl(p, (int)c.a3);
         const int val = sp_mad24(w0, pj, __mul24(65536 - w0, pk)) >> 16;   // 17-bit x 12-bit products
-        p = lane == I ? val : p;
+        p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
       } else if constexpr (c.type == C_MIX) {
         // inputs p[j..j+m-1] sit in lanes j..j+m-1; weight t sits in lane t
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
-        const int x = lane < (int)c.a3 ? __mul24(mixw[c.slot] >> 8, pin) : 0;
+        const int x = (int)((unsigned)__mul24(mixw[c.slot] >> 8, pin) & lk.mixin[c.slot]);
         const int val = sp_clamp2k(sp_lanes_sum<(int)c.a3>(x) >> 8);
-        p = lane == I ? val : p;
+        p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
       } else if constexpr (c.type == C_SSE) {
         int pq = sp_rl(p, (int)c.a2) + 992;
         pq = min(max(pq, 0), 1983);
@@ -867,20 +913,20 @@ struct Dep {
         pq >>= 6;
         const unsigned e0 = sp_rlu(ssev[c.slot], pq), e1 = sp_rlu(ssev[c.slot], pq + 1);
         const int val = sp_stretch(T, ((e0 >> 10) * (unsigned)(64 - wt) + (e1 >> 10) * (unsigned)wt) >> 13);
-        p = lane == I ? val : p;
+        p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
         ssecx[c.slot] += (unsigned)(pq + (wt >> 5));        // element trained in update ...
         ssetr[c.slot] = (wt >> 5) ? e1 : e0;                // ... which is one of the two just read
         ssedt[c.slot] = (unsigned)T.dt[ssetr[c.slot] & 0x3ffu];
       }
-      Dep<Chain, I + 1>::predict(T, lane, c8, p, w0, w1, mixw, ssev, ssecx, ssetr, ssedt);
+      Dep<Chain, I + 1>::predict(T, lane, lk, c8, p, w0, w1, mixw, ssev, ssecx, ssetr, ssedt);
     }
   }
 
   template <int NM, int NS>
-  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane, unsigned dummy, int y, int sq, int p,
-                                                int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&mixbase)[NM],
-                                                unsigned (&ssev)[NS], unsigned (&ssecx)[NS], unsigned (&ssetr)[NS],
-                                                unsigned (&ssedt)[NS]) {
+  static __device__ __forceinline__ void update(const SpecTables& T, g_u8* arena, int lane,
+                                                const LaneK<Chain::N, NM, NS>& lk, int y, int sq, int p,
+                                                int (&mixw)[NM], unsigned (&mixrow)[NM], unsigned (&ssev)[NS],
+                                                unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_MIX) {
@@ -888,7 +934,7 @@ struct Dep {
         int pin = p;
         if constexpr (c.a2 != 0) pin = __shfl(p, (lane + (int)c.a2) & 63);
         const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, pin, 1 << 12) >> 13));
-        const unsigned wo = lane < (int)c.a3 ? mixbase[c.slot] + 4u * mixrow[c.slot] : dummy;
+        const unsigned wo = lk.mixst[c.slot] + ((4u * mixrow[c.slot]) & lk.mixin[c.slot]);
         *(g_i32*)(arena + wo) = w;
       } else if constexpr (c.type == C_SSE) {
         // Predictor::train on cm[cxt]; the word is still in lane (cxt & 31) of the row registers
@@ -898,9 +944,9 @@ struct Dep {
         const int err = y * 32767 - (int)(v >> 17);
         const unsigned prod = (unsigned)__mul24(err, (int)ssedt[c.slot]);    // low 32 bits, like Predictor::train
         const unsigned nv = v + (prod & 0xFFFFFC00u) + (count < c.limit ? 1u : 0u);
-        *(g_u32*)(arena + (lane == 0 ? (unsigned)c.t0 + 4u * (e & c.mask0) : dummy)) = nv;
+        *(g_u32*)(arena + lk.ssest[c.slot] + ((4u * (e & c.mask0)) & lk.lane0)) = nv;
       }
-      Dep<Chain, I + 1>::update(T, arena, lane, dummy, y, sq, p, mixw, mixrow, mixbase, ssev, ssecx, ssetr, ssedt);
+      Dep<Chain, I + 1>::update(T, arena, lane, lk, y, sq, p, mixw, mixrow, ssev, ssecx, ssetr, ssedt);
     }
   }
 };
