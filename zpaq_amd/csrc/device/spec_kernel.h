@@ -150,6 +150,27 @@ __device__ __forceinline__ void row_set(unsigned& r0, unsigned& r1, unsigned& r2
   r3 = sel == 3 ? ((r3 & m) | b) : r3;
 }
 
+// The same with the bit's position in its nibble known (NB = 0..3): the slot index is 1, 2..3, 4..7 or
+// 8..15, so the register holding it is known except for the last position (NB < 0: unknown, generic).
+template <int NB>
+__device__ __forceinline__ unsigned row_get_nb(unsigned r0, unsigned r1, unsigned r2, unsigned r3, int idx) {
+  if constexpr (NB < 0) return row_get(r0, r1, r2, r3, idx);
+  const unsigned w = NB <= 1 ? r0 : (NB == 2 ? r1 : ((idx & 4) ? r3 : r2));
+  return (w >> ((idx & 3) * 8)) & 255u;
+}
+template <int NB>
+__device__ __forceinline__ void row_set_nb(unsigned& r0, unsigned& r1, unsigned& r2, unsigned& r3, int idx, unsigned v) {
+  if constexpr (NB < 0) { row_set(r0, r1, r2, r3, idx, v); return; }
+  const int sh = (idx & 3) * 8;
+  const unsigned m = ~(255u << sh), b = v << sh;
+  if constexpr (NB <= 1) r0 = (r0 & m) | b;
+  else if constexpr (NB == 2) r1 = (r1 & m) | b;
+  else {
+    r2 = (idx & 4) ? r2 : ((r2 & m) | b);
+    r3 = (idx & 4) ? ((r3 & m) | b) : r3;
+  }
+}
+
 template <class Chain, int I>
 struct Dep;   // forward
 
@@ -440,6 +461,15 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   unsigned ssetr[NSSE], ssedt[NSSE];   // SSE: the entry that will be trained and its adaptation rate
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssetr[k] = 0; ssedt[k] = 0; }
+  // wave-uniform copies of the contexts of the MIX / SSE components (they select rows; constant for a byte)
+  unsigned hmix[NMIX], hsse[NSSE], hmix_n[NMIX], hsse_n[NSSE];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) { hmix[k] = 0; hmix_n[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) { hsse[k] = 0; hsse_n[k] = 0; }
+  int pdv[N];                  // MIX2: p[j] - p[k] of this bit (wave-uniform), read in predict, reused by update
+#pragma unroll
+  for (int k = 0; k < N; ++k) pdv[k] = 0;
   bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
   int ylast = 0;
 
@@ -518,7 +548,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
       touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
     }
-    bh = row_get(row0, row1, row2, row3, slot);                              // bit history
+    bh = row_get_nb<(B >= 0 ? (B & 3) : -1)>(row0, row1, row2, row3, slot);   // bit history
     nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];            // ns[4*bh] | ns[4*bh+1] << 8
     // side table: ICM one word at [bh]; ISSE two words at [2*bh], [2*bh+1]; idle lanes: their dummy
     const unsigned e0 = (bh << bh_shift) & m_row;
@@ -574,11 +604,11 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         constexpr int i = decltype(ic)::value;
         constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) {
-          const unsigned r = ((sp_rlu(h, i) + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
+          const unsigned r = ((hmix[c.slot] + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
           mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * r);
         }
         if constexpr (c.type == C_SSE && sse_pf(c)) {
-          const unsigned cx0 = ((sp_rlu(h, i) + (unsigned)c8) * 32u) & c.mask0;
+          const unsigned cx0 = ((hsse[c.slot] + (unsigned)c8) * 32u) & c.mask0;
           ssev[c.slot] = G32(ssebase[c.slot] + 4u * cx0);
         }
       });
@@ -587,7 +617,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr int i = decltype(ic)::value;
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
-        const unsigned hi = sp_rlu(h, i);
+        const unsigned hi = hmix[c.slot];
         mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
         if constexpr (mix_pf(c)) {
           mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3));
@@ -596,7 +626,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
           mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
         }
       } else if constexpr (c.type == C_SSE) {
-        const unsigned hi = sp_rlu(h, i);
+        const unsigned hi = hsse[c.slot];
         ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
         if constexpr (sse_pf(c)) {
           ssec0[c.slot] = G32(ssebase[c.slot] + 4u * (((hi + (unsigned)c8a) * 32u) & c.mask0));
@@ -640,7 +670,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
 #pragma unroll
       for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
     }
-    Dep<Chain, 0>::predict(T, lane, lk, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt);
+    Dep<Chain, 0>::predict(T, lane, lk, c8, p, (int)v0, (int)v1, mixw, ssev, ssecx, ssetr, ssedt, pdv);
     pf_valid = more;
     sq = sp_squash(T, sp_clamp2k(p));
     const unsigned prr = sp_rlu((unsigned)sq, N - 1);     // p[N-1] is already within +-2047
@@ -662,10 +692,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       constexpr CompK c = Chain::comp[i];
-      if constexpr (c.type == C_MIX2) {
-        const int d = sp_rl(p, (int)c.a2) - sp_rl(p, (int)c.a3);
-        pdiff |= (int)((unsigned)d & lk.is[i]);
-      }
+      if constexpr (c.type == C_MIX2) pdiff |= (int)((unsigned)pdv[i] & lk.is[i]);
     });
     // every lane's LDS lookups, issued together
     const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
@@ -673,7 +700,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int yq = y * 32767;
     const int err = yq - sq;
     // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
-    row_set(row0, row1, row2, row3, slot, nsv);
+    row_set_nb<(B >= 0 ? (B & 3) : -1)>(row0, row1, row2, row3, slot, nsv);
     const unsigned n0 = blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
                               (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
     const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
@@ -746,10 +773,12 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr int i = decltype(ic)::value;
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
-        const unsigned r = ((sp_rlu(h_next, i) + (1u & c.a5)) & c.mask0) * c.a3;
+        hmix_n[c.slot] = sp_rlu(h_next, i);
+        const unsigned r = ((hmix_n[c.slot] + (1u & c.a5)) & c.mask0) * c.a3;
         ka2 ^= G32(mixbase[c.slot] + 4u * r);
       } else if constexpr (c.type == C_SSE) {
-        const unsigned cx0 = ((sp_rlu(h_next, i) + 1u) * 32u) & c.mask0;
+        hsse_n[c.slot] = sp_rlu(h_next, i);
+        const unsigned cx0 = ((hsse_n[c.slot] + 1u) * 32u) & c.mask0;
         ka2 ^= G32(ssebase[c.slot] + 4u * cx0);
       }
     });
@@ -767,8 +796,18 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         SP_PROF_END(2)
         if (e) return e;
         h = vm_H[(unsigned)lane & Chain::HMASK];
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          constexpr CompK c = Chain::comp[i];
+          if constexpr (c.type == C_MIX) hmix[c.slot] = sp_rlu(h, i);
+          if constexpr (c.type == C_SSE) hsse[c.slot] = sp_rlu(h, i);
+        });
       } else {
         h = h_next;            // computed by run_ahead() when this byte started
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) hmix[k] = hmix_n[k];
+#pragma unroll
+        for (int k = 0; k < NSSE; ++k) hsse[k] = hsse_n[k];
       }
       hmap4 = 1;
       c8 = 1;
@@ -882,7 +921,8 @@ struct Dep {
   template <int NM, int NS>
   static __device__ __forceinline__ void predict(const SpecTables& T, int lane, const LaneK<Chain::N, NM, NS>& lk, int c8,
                                                  int& p, int w0, int w1, int (&mixw)[NM], unsigned (&ssev)[NS],
-                                                 unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS]) {
+                                                 unsigned (&ssecx)[NS], unsigned (&ssetr)[NS], unsigned (&ssedt)[NS],
+                                                 int (&pdv)[Chain::N]) {
     if constexpr (I < Chain::N) {
       constexpr CompK c = Chain::comp[I];
       if constexpr (c.type == C_ISSE) {
@@ -897,6 +937,7 @@ struct Dep {
         p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
       } else if constexpr (c.type == C_MIX2) {
         const int pj = sp_rl(p, (int)c.a2), pk = sp_rl(p, (int)c.a3);
+        pdv[I] = pj - pk;                                                   // update trains on this difference
         const int val = sp_mad24(w0, pj, __mul24(65536 - w0, pk)) >> 16;   // 17-bit x 12-bit products
         p = (int)sp_blend(lk.is[I], (unsigned)val, (unsigned)p);
       } else if constexpr (c.type == C_MIX) {
@@ -918,7 +959,7 @@ struct Dep {
         ssetr[c.slot] = (wt >> 5) ? e1 : e0;                // ... which is one of the two just read
         ssedt[c.slot] = (unsigned)T.dt[ssetr[c.slot] & 0x3ffu];
       }
-      Dep<Chain, I + 1>::predict(T, lane, lk, c8, p, w0, w1, mixw, ssev, ssecx, ssetr, ssedt);
+      Dep<Chain, I + 1>::predict(T, lane, lk, c8, p, w0, w1, mixw, ssev, ssecx, ssetr, ssedt, pdv);
     }
   }
 
