@@ -130,7 +130,7 @@ def test_decode_reference_archives(gpu, golden, kernel):
         gpu.set_kernel(0)
 
 
-def test_specialised_kernel_is_the_one_running(gpu, golden):
+def test_specialised_kernel_is_the_one_running(gpu, golden, oracle):
     """Standard chains come from the in-tree code-object cache; data-dependent ones through hipRTC."""
     import ctypes as C
     L = gpu.lib()
@@ -147,14 +147,14 @@ def test_specialised_kernel_is_the_one_running(gpu, golden):
     kind = L.zpq_plan_kernel_kind(plan2._h, note, 4096)
     assert kind == 3, note.value
     assert note.value.startswith(b"hiprtc") or note.value.startswith(b"cache:")
-    # a header that certainly was not prebuilt: must come out of hipRTC, and code correctly
-    e = golden["vm_cases"][7]
-    plan3 = gpu.Plan(bytes.fromhex(e["header"]))
+    # a header that certainly was not prebuilt (no build step knows this chain): must come out of hipRTC, and
+    # code correctly
+    h3, _, _ = gpu.method_to_header("x0,0ci2,1,1c0,3m16s")
+    plan3 = gpu.Plan(h3)
     assert L.zpq_plan_kernel_kind(plan3._h, note, 4096) == 3, note.value
     assert note.value.startswith(b"hiprtc"), note.value
-    c = gpu.encode_batch([plan3], [b"\0" + gen_input(e).tobytes()])[0]
-    a = b64(e)
-    assert a[e["payload_start"]:e["payload_start"] + len(c)] == c
+    d3 = b"\0" + corpus.block("text", 50000, 4242).tobytes()
+    assert gpu.encode_batch([plan3], [d3])[0] == oracle.encode(h3, d3)
 
 
 def test_decoder_status_codes(gpu, golden):

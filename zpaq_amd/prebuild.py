@@ -5,7 +5,7 @@
 For every standard block header -- the chains compressBlock generates for
 methods "4" and "5" (.. "9") at each block-size exponent, with and without the
 text hint, plus the headers recorded in tests/golden/golden.json (legacy
-min/mid/max models, the all-nine-types config) -- ask the library for the
+min/mid/max models, the all-nine-types config, the random HCOMP programs) -- ask the library for the
 generated HIP source (zpq_plan_spec_source) and compile it with
 `hipcc --genco --offload-arch=gfx950` into zpaq_amd/spec_cache/<key>.hsaco.
 hipcc cross-compiles without a GPU.  Headers not covered here (e.g. level-5
@@ -48,7 +48,7 @@ def standard_headers():
     gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
     if os.path.exists(gpath):
         g = json.load(open(gpath))
-        for sect in ("method_cases", "config_cases", "level_cases"):
+        for sect in ("method_cases", "config_cases", "level_cases", "vm_cases"):
             for e in g[sect]:
                 h = bytes.fromhex(e["header"])
                 if h[6]:
