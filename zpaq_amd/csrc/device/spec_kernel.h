@@ -7,21 +7,28 @@
 // everything below is ordinary hand-written HIP for gfx950 that the compiler
 // folds against those constants.
 //
-// Mapping: one ZPAQ block per wavefront, component i on lane i (n <= 64), four
-// blocks per workgroup.  What changed against the generic kernel (model_wave.h):
-//   * the small hot tables live in LDS: half of stretch (mirrored), the
-//     non-trivial part of squash, dt, the state table, and -- per block -- the
-//     ICM/ISSE bit-history->probability side tables and HCOMP's H array;
+// Mapping: one ZPAQ block per wavefront, component i on lane i (n <= 64),
+// Chain::WAVES (4 or 8) blocks per workgroup.  The ideas, in the order they
+// appear below (DESIGN.md section 4.1 has the measurements behind each):
+//   * small hot tables in LDS: half of stretch (mirrored), the non-trivial part
+//     of squash, dt, the state table, and -- per block -- HCOMP's H array and as
+//     many ICM/ISSE bit-history->probability side tables as fit;
 //   * the 16-byte bit-history row of every ICM/ISSE is cached in 4 VGPRs for the
 //     4 bits of a nibble: one probe (3 x 16 B in one 64-B line) + one 16-B
 //     write-back per nibble instead of a byte load/store per bit;
-//   * all global loads of a bit (CM word, MIX2 weight, MIX rows, SSE row) have
-//     addresses that depend only on (h, c8, hmap4): they are issued together at
-//     the top of predict and overlap the LDS work; MIX weights and the SSE row
-//     stay in registers for update (no re-load);
+//   * every global word of a bit (CM word, MIX2 weight, MIX rows, SSE row) has an
+//     address that depends only on (h, c8, hmap4): both candidates of the NEXT
+//     bit are fetched during this one; what predict read stays in registers for
+//     update (no re-load);
+//   * the 8 bits of a byte are unrolled with the bit position as a compile-time
+//     tag, so position-dependent control flow disappears;
+//   * lane-class selects are bit blends with per-lane constant masks in VGPRs;
+//     lanes without a table of some kind work on one shared dummy line, so no
+//     per-bit code needs the exec mask;
 //   * the dependent chain (ISSE/AVG/MIX2/MIX/SSE) is unrolled at compile time
 //     with literal lane numbers (v_readlane / DPP), no descriptor fetches;
-//   * HCOMP runs as compiled code, not through an interpreter.
+//   * HCOMP runs as compiled code, not through an interpreter; the arithmetic
+//     coder runs on the scalar unit.
 // Integer arithmetic is bit-exact with Predictor::predict0/update0.
 #pragma once
 #ifndef __HIPCC_RTC__
@@ -53,7 +60,6 @@ struct CompK {
   int lds;                     // byte offset of the side table in the wave's LDS region, or -1
   int slot;                    // ordinal among MIX (resp. SSE) components, else -1
 };
-
 
 struct SpecTables {                            // shared by the waves of a workgroup
   int16_t stretch_hi[16384];                   // stretch(x) for x >= 16384; mirrored below
@@ -109,28 +115,14 @@ __device__ __forceinline__ int sp_lanes_sum(int x) {
   return s;
 }
 
-// 64-lane integer sum (DPP row scans + row broadcasts); result wave-uniform.
-__device__ __forceinline__ int sp_wave_sum(int x) {
-  int v = x;
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
-  return sp_rl(v, 63);
-}
-
 // LDS-qualified views: loads/stores through these are ds_read/ds_write, never flat.
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
-typedef __attribute__((address_space(3))) int2 lds_i2;
 
 // Explicit global-memory views of the arena: pointers loaded from the job
 // descriptor are generic to the compiler, and flat_* accesses would tie vmcnt
 // and lgkmcnt together (every LDS wait would also wait for HBM).
 typedef __attribute__((address_space(1))) unsigned char g_u8;
-typedef __attribute__((address_space(1))) unsigned short g_u16;
 typedef __attribute__((address_space(1))) unsigned g_u32;
 typedef __attribute__((address_space(1))) int g_i32;
 typedef __attribute__((address_space(1))) uint4 g_u128;
@@ -273,22 +265,24 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   // ---- per-lane component constants (selected from the constexpr chain) ----
   // Tables are addressed as arena + 32-bit offset (the arena of a specialised plan is < 4 GiB),
   // so every global access is "uniform base + VGPR offset" and needs no 64-bit address math.
-  // Lanes without a table of some kind point at a private 64-byte dummy slot instead: loads and
-  // stores can then be issued by ALL lanes with no exec-mask juggling (divergent branches were a
-  // quarter of the instruction stream), and land harmlessly.
+  // Lanes without a table of some kind point at a 64-byte dummy line instead: loads and stores can
+  // then be issued by ALL lanes with no exec-mask juggling (divergent branches were a quarter of the
+  // instruction stream), and land harmlessly.  The line is shared (stride 0): the idle lanes of a
+  // memory instruction coalesce into one transaction; with a private line per lane every instruction
+  // touched 64 lines, which cost 6 % with one wavefront per SIMD and all of the gain of two.
 #ifndef ZPQ_DUMMY_STRIDE
-#define ZPQ_DUMMY_STRIDE 0   // idle lanes share ONE 64-byte line: their accesses coalesce into a single transaction
+#define ZPQ_DUMMY_STRIDE 0
 #endif
   const unsigned dummy = (unsigned)Chain::OFF_RUN + (unsigned)lane * (unsigned)ZPQ_DUMMY_STRIDE;
   const unsigned dummy_lds = (unsigned)(kSpecWaveLds - 512) + (unsigned)lane * 8u;
-  unsigned type = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63, sizebits = 0;
+  unsigned a2 = 0, a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63, sizebits = 0;
   unsigned off0 = dummy, off1 = dummy;
   int ldsoff = -1;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if (lane == i) {
       const CompK c = Chain::comp[i];
-      type = c.type; a2 = c.a2; a3 = c.a3; a4 = c.a4; a5 = c.a5;
+      a2 = c.a2; a4 = c.a4; a5 = c.a5;
       limit = c.limit; mask0 = c.mask0; sizebits = c.a1 + 2;
       off0 = (unsigned)c.t0;
       if (c.type == C_ICM || c.type == C_ISSE || c.type == C_MATCH) { off1 = (unsigned)c.t1; mask1 = c.mask1; }
@@ -353,16 +347,13 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   const bool side_global = has_row && ldsoff < 0;           // side table left in the arena (LDS full)
   const unsigned soff = side_global ? off0 : dummy;         // base of a side table that stayed in the arena
   // Lane-class selects in the per-bit code are bit blends with per-lane constant masks held in
-  // VGPRs (one v_bfi_b32 each), not v_cndmask on loop-invariant SGPR-pair predicates: the bit loop
+  // VGPRs (one v_bfi_b32 / v_bitop3_b32 each), not v_cndmask on loop-invariant SGPR-pair predicates: the bit loop
   // had run out of SGPRs and was spilling those predicates to VGPR lanes.  The masks are opaque to
   // the optimiser, which otherwise rewrites the lane classes as range tests on the lane id.
   auto lane_mask = [&](bool b) __attribute__((always_inline)) -> unsigned {
     unsigned m = b ? 0xFFFFFFFFu : 0u;
     ZPQ_OPAQUE(m);
     return m;
-  };
-  auto blend = [](unsigned m, unsigned a, unsigned b) __attribute__((always_inline)) -> unsigned {
-    return (a & m) | (b & ~m);
   };
   const unsigned m_cm = lane_mask(is_cm), m_isse = lane_mask(is_isse), m_icm = lane_mask(is_icm);
   const unsigned m_match = lane_mask(is_match), m_row = lane_mask(has_row), m_ctx = lane_mask(is_ctx);
@@ -641,7 +632,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       gwc0 = G32(goff + 4u * ia);
       gwc1 = G32(goff + 4u * ib);
     }
-    gw = blend(m_res, rw, gw);
+    gw = sp_blend(m_res, rw, gw);
 #ifdef ZPQ_PROF
     const unsigned long long pb2 = __builtin_readcyclecounter();
     prof[5] += pb2 - pb1;
@@ -652,12 +643,12 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     rc = m_on ? ((mpred >> (7 - bitpos)) & 1u) : rc;
     // no match: predict stretch(16384) = 0 (Predictor::predict0 case MATCH, "p[i]=0")
     const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
-    v0 = blend(m_row, q0, gw);
+    v0 = sp_blend(m_row, q0, gw);
     v1 = q1;
     // (D) one stretch lookup for every context-only component: ICM looks up cm >> 8, CM cm >> 17
-    const unsigned sx = blend(m_match, msx, v0 >> ctx_shift);
+    const unsigned sx = sp_blend(m_match, msx, v0 >> ctx_shift);
     const int st = sp_stretch(T, sx & 32767u);
-    p = (int)blend(m_ctx, (unsigned)st, (unsigned)p);
+    p = (int)sp_blend(m_ctx, (unsigned)st, (unsigned)p);
     dtv = (unsigned)T.dt[v0 & 0x3ffu];
     // (E) dependent components.  ISSE chains first, all at once, when every ISSE is fed by its left
     //     neighbour; then the rest in index order, unrolled with literal lanes; results are merged
@@ -666,7 +657,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       // every lane runs the same multiply-add; lanes that are not ISSE use weight 0 and addend p << 16,
       // which reproduces their p (all predictions are within +-2047, so the clamp is the identity)
       const int iw = (int)(v0 & m_isse);
-      const int ia = (int)blend(m_isse, v1 << 6, (unsigned)p << 16);
+      const int ia = (int)sp_blend(m_isse, v1 << 6, (unsigned)p << 16);
 #pragma unroll
       for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
     }
@@ -701,7 +692,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const int err = yq - sq;
     // bit-history row and side table (ICM: one word; ISSE: two weights); idle lanes hit their dummies
     row_set_nb<(B >= 0 ? (B & 3) : -1)>(row0, row1, row2, row3, slot, nsv);
-    const unsigned n0 = blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
+    const unsigned n0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
                               (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
     const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
     const unsigned e0 = (bh << bh_shift) & m_row;
@@ -720,7 +711,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
     const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
     const int err2 = __mul24(err, (int)a4) >> 5;
     const int w2 = min(max((int)v0 + (sp_mad24(err2, pdiff, 1 << 12) >> 13), 0), 65535);   // 19-bit x 13-bit
-    const unsigned gnew = blend(m_cm, cm_new, (unsigned)w2);
+    const unsigned gnew = sp_blend(m_cm, cm_new, (unsigned)w2);
     G32(goff + 4u * gidx) = gnew;
     rw = gnew;
     // MATCH (Predictor::update0 case MATCH, libzpaq.cpp:1985-2008)
