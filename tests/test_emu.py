@@ -82,3 +82,12 @@ def test_every_golden_chain(zlib_, oracle, golden):
             data = corpus.block(e["kind"] if e["kind"] != "mixed" else "records", 600, 3).tobytes()
         _check(oracle, header, [data[:600]], 4)
     assert len(seen) >= 8
+
+
+@pytest.mark.parametrize("waves", [12, 16])
+def test_experimental_shapes(zlib_, oracle, waves):
+    """12 / 16 blocks per workgroup (3 / 4 wavefronts per SIMD, 10 / 7.5 KiB of LDS per block): generated for
+    experiments through ZPAQ_AMD_SPEC_WAVES, never chosen by the engine on its own; they must still be exact."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    _check(oracle, header, _ragged(500) + _ragged(300) + _ragged(200), waves)

@@ -53,7 +53,7 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   ZPQ_TRY
   if (!p) fail(ZPQ_E_ARG, "null plan");
   std::string source, key, why;
-  const int variant = spec_variant_forced() == 1 ? 1 : 0;   // ZPAQ_AMD_SPEC_WAVES=8 selects the 8-block workgroup shape
+  const int variant = spec_variant_forced() > 0 ? spec_variant_forced() : 0;   // ZPAQ_AMD_SPEC_WAVES selects the shape
   if (!spec_source_and_key(*p, variant, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
   if (len) *len = source.size();
   if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
@@ -76,7 +76,7 @@ int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) {
 size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
   try {
     std::string l;
-    const size_t n = p ? spec_jit_compile_only(*p, spec_variant_forced() == 1 ? 1 : 0, l) : 0;
+    const size_t n = p ? spec_jit_compile_only(*p, spec_variant_forced() > 0 ? spec_variant_forced() : 0, l) : 0;
     if (log && cap) { strncpy(log, l.c_str(), cap - 1); log[cap - 1] = 0; }
     return n;
   } catch (const std::exception& ex) {

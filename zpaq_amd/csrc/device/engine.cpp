@@ -177,8 +177,9 @@ static int kernel_kind(Engine& e, const zpq_plan* plan, bool dense, SpecKernel**
   const int forced = spec_variant_forced();
   const int first = forced >= 0 ? forced : (dense ? 1 : 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1 && forced >= 0) break;                                     // a forced shape has no fallback
     const int variant = attempt == 0 ? first : 1 - first;
-    if (attempt == 1 && (forced >= 0 || p->spec_state[variant] <= 0)) break;   // fall back only to a shape already loaded
+    if (attempt == 1 && p->spec_state[variant] <= 0) break;                     // fall back only to a shape already loaded
     bool did = false;
     SpecKernel* k = spec_kernel_for(p, variant, want == 3 || e.jit_left > 0, nullptr, &did);
     if (did && e.jit_left > 0) --e.jit_left;

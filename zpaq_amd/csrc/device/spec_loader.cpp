@@ -57,11 +57,12 @@ std::string spec_cache_dir() {
 int spec_variant_forced() {
   const char* e = getenv("ZPAQ_AMD_SPEC_WAVES");
   if (!e || !e[0]) return -1;
-  return atoi(e) == 8 ? 1 : 0;
+  const int w = atoi(e);
+  return (w == 8 || w == 12 || w == 16) ? w / 4 - 1 : 0;
 }
 
 bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not) {
-  if (!generate_spec_source(plan, variant == 1 ? 8 : 4, source, why_not)) return false;
+  if (!generate_spec_source(plan, 4 * ((variant >= 0 && variant <= 3 ? variant : 0) + 1), source, why_not)) return false;
   std::string h1, h2;
   const std::string inc = spec_include_dir();
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2)) {
@@ -114,7 +115,7 @@ size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log
 }
 
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* jit_deferred, bool* did_jit) {
-  variant = variant == 1 ? 1 : 0;
+  if (variant < 0 || variant > 3) variant = 0;
   if (plan->spec_state[variant] > 0) return (SpecKernel*)plan->spec[variant];
   if (plan->spec_state[variant] < 0) return nullptr;
   plan->spec_state[variant] = -1;
@@ -170,7 +171,7 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
 }
 
 void spec_kernel_release(zpq_plan* plan) {
-  for (int v = 0; plan && v < 2; ++v) {
+  for (int v = 0; plan && v < 4; ++v) {
     if (!plan->spec[v]) continue;
     SpecKernel* k = (SpecKernel*)plan->spec[v];
     if (k->module) (void)hipModuleUnload(k->module);

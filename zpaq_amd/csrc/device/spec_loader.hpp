@@ -22,10 +22,10 @@ struct SpecKernel {
 // code object back into the cache directory when that is writable.
 // allow_jit = false: only the in-tree cache is consulted; a miss leaves the plan untried (a later call may
 // compile it) and *jit_deferred is set.
-// variant 0: 4 blocks per workgroup, variant 1: 8 blocks per workgroup (see zpq_plan::spec)
+// variant v: 4 (v + 1) blocks per workgroup, v = 0..3 (see zpq_plan::spec)
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, bool* jit_deferred = nullptr,
                             bool* did_jit = nullptr);
-// ZPAQ_AMD_SPEC_WAVES=4|8 forces one workgroup shape (tests, experiments, prebuild); -1 when unset
+// ZPAQ_AMD_SPEC_WAVES=4|8|12|16 forces one workgroup shape (tests, experiments, prebuild): its variant, or -1 when unset
 int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
 

@@ -169,7 +169,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   if (ph.arena_bytes >= (1ull << 32)) { why_not = "model state of 4 GiB or more per block"; return false; }
   const CompDesc* comp = plan.comps();
   // LDS plan for the wave's region: H first, then ICM/ISSE side tables while they fit
-  if (waves != 4 && waves != 8) { why_not = "unsupported workgroup shape"; return false; }
+  if (waves != 4 && waves != 8 && waves != 12 && waves != 16) { why_not = "unsupported workgroup shape"; return false; }
   const int wave_lds = spec_wave_lds_bytes(waves);
   int lds_used = 0, h_lds = -1;
   const int h_bytes = (int)(4u * (ph.hmask + 1));
