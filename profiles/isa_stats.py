@@ -39,7 +39,7 @@ def main():
         asm = open(os.path.join(td, "k-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     print(f"method {xm}\nkey {key}  blocks/workgroup {waves}")
     meta = asm[asm.index("amdhsa.kernels:"):]
-    for entry in meta.split("\n  - ")[1:]:
+    for entry in [e for e in meta.split("\n  - ")[1:] if ".name:" in e]:
         grab = lambda k: (re.search(rf"\.{k}:\s+(\S+)", entry) or [None, "?"])[1]
         if grab("name").startswith("zpq_spec"):
             print(f"{grab('name')}: vgpr {grab('vgpr_count')} sgpr {grab('sgpr_count')} "

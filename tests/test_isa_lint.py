@@ -1,0 +1,73 @@
+"""CPU (-m "not gpu"): static checks on the gfx950 code hipcc generates for the specialised kernels (hipcc
+cross-compiles without a GPU).  They guard the properties the measured performance depends on and that no
+functional test sees: no scratch, no flat_* memory instructions (they would tie vmcnt to lgkmcnt), LDS within
+the 160 KiB of a workgroup, registers within the occupancy the shape needs, and the size of the unrolled byte
+loop (the path is issue / latency bound: instructions per bit are the figure of merit)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _compile(zlib_, header, waves, tmp_path):
+    from zpaq_amd import prebuild
+    old = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
+    os.environ["ZPAQ_AMD_SPEC_WAVES"] = str(waves)
+    try:
+        src, _ = prebuild.source_and_key(header)
+    finally:
+        if old is None:
+            del os.environ["ZPAQ_AMD_SPEC_WAVES"]
+        else:
+            os.environ["ZPAQ_AMD_SPEC_WAVES"] = old
+    d = tmp_path / f"w{waves}"
+    d.mkdir()
+    (d / "k.hip").write_text(src)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-mllvm",
+                    "-simplifycfg-sink-common=false", "-I", os.path.join(ROOT, "zpaq_amd", "csrc", "device"), "--genco",
+                    "k.hip", "-o", "k.hsaco", "-save-temps"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    asm = (d / "k-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    shutil.rmtree(d)
+    return asm
+
+
+def _kernels(asm):
+    meta = asm[asm.index("amdhsa.kernels:"):]
+    out = {}
+    for entry in [e for e in meta.split("\n  - ")[1:] if ".name:" in e]:
+        g = lambda k: re.search(rf"\.{k}:\s+(\S+)", entry).group(1)
+        out[g("name")] = {k: int(g(k)) for k in ("vgpr_count", "sgpr_count", "group_segment_fixed_size",
+                                                  "private_segment_fixed_size", "max_flat_workgroup_size")}
+    return out
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_m5_kernel_properties(zlib_, tmp_path, waves):
+    from zpaq_amd import corpus
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    asm = _compile(zlib_, header, waves, tmp_path)
+    ks = _kernels(asm)
+    assert set(ks) == {"zpq_spec_encode", "zpq_spec_decode"}
+    for name, k in ks.items():
+        assert k["private_segment_fixed_size"] == 0, (name, "spills to scratch")
+        assert k["group_segment_fixed_size"] <= 160 * 1024
+        assert k["max_flat_workgroup_size"] == 64 * waves
+        assert k["vgpr_count"] <= 512 // (waves // 4), (name, k["vgpr_count"])   # wavefronts per SIMD the shape needs
+    code = [l.split()[0] for l in asm.split("\n") if re.match(r"^\t[a-z_0-9]+(\s|$)", l)]
+    assert not [op for op in code if op.startswith(("flat_", "scratch_"))]
+    # the unrolled byte loop of the encoder, all paths: 4 234 instructions when this test was written
+    enc = asm[asm.index("zpq_spec_encode:"):]
+    enc = enc[:enc.index("s_endpgm")].split("\n")
+    start = next(i for i, l in enumerate(enc) if "Loop Header: Depth=1" in l and i > len(enc) // 4)
+    loop = [l for l in enc[start:] if re.match(r"^\t[a-z_0-9]+(\s|$)", l)]
+    assert 3000 < len(loop) < 4600, len(loop)
