@@ -18,14 +18,14 @@ from zpaq_amd import corpus  # noqa: E402
 DEEP_ISSE = "x0,0ci1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1m"
 
 
-def _check(oracle, header, datas, waves):
+def _check(oracle, header, datas, waves, dual=False):
     inputs = [b"\0" + bytes(d) for d in datas]
-    enc = emu.run(header, inputs, waves=waves)
+    enc = emu.run(header, inputs, waves=waves, dual=dual)
     for inp, (coded, status, consumed) in zip(inputs, enc):
         assert status == 0 and consumed == len(inp)
         assert coded == oracle.encode(header, inp)
     dec = emu.run(header, [c + b"\0\0\0\0" for c, _, _ in enc], decode=True, waves=waves,
-                  out_cap=max(len(x) for x in inputs))
+                  out_cap=max(len(x) for x in inputs), dual=dual)
     for inp, (c, _, _), (plain, status, consumed) in zip(inputs, enc, dec):
         # a block that fills its capacity exactly stops before the end-of-stream marker
         assert status == 0 and plain == inp[:len(plain)] and len(plain) == len(inp)
@@ -91,3 +91,19 @@ def test_experimental_shapes(zlib_, oracle, waves):
     blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
     header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
     _check(oracle, header, _ragged(500) + _ragged(300) + _ragged(200), waves)
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_two_blocks_per_wavefront_prototype(zlib_, oracle, golden, waves):
+    """EXPERIMENTAL kernel (spec_kernel_dual.h): lanes 0-31 code one block, lanes 32-63
+    another.  Never selected by the engine and never run on a GPU yet; it must already be exact here -- odd block
+    counts (padding job), ragged lengths (a finished block idles beside its partner), empty blocks, decode."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    for method in ("5", "4"):
+        header, _, _ = zlib_.method_to_header(zlib_.expand_method(method, blk))
+        _check(oracle, header, _ragged(600) + _ragged(250)[:2], waves, dual=True)
+    if waves == 4:
+        for e in [golden["config_cases"][0], golden["level_cases"][2]]:
+            header = bytes.fromhex(e["header"])
+            d = gen_input(e).tobytes()
+            _check(oracle, header, [d[:900], d[100:500], d[:300]], waves, dual=True)

@@ -54,7 +54,8 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   if (!p) fail(ZPQ_E_ARG, "null plan");
   std::string source, key, why;
   const int variant = spec_variant_forced() > 0 ? spec_variant_forced() : 0;   // ZPAQ_AMD_SPEC_WAVES selects the shape
-  if (!spec_source_and_key(*p, variant, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  const char* dual = getenv("ZPAQ_AMD_SPEC_DUAL");   // experimental two-blocks-per-wavefront kernel (tests/emu only)
+  if (!spec_source_and_key(*p, variant, source, key, why, dual && dual[0] == '1')) fail(ZPQ_E_UNSUPPORTED, why);
   if (len) *len = source.size();
   if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
   if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");

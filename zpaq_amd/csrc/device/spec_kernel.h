@@ -89,7 +89,7 @@ __device__ __forceinline__ unsigned sp_uni(unsigned v) { return (unsigned)__buil
 // HCOMP's condition flag: wave-uniform by construction; telling the compiler so keeps the VM's
 // branches scalar.  (The emulator runs HCOMP on one lane only -- no cross-lane traffic there.)
 __device__ __forceinline__ unsigned vm_flag(bool c) {
-#ifndef ZPQ_EMU
+#if !defined(ZPQ_EMU) && !defined(ZPQ_DUAL)   // two blocks per wavefront (spec_kernel_dual.h): the flag is per block
   return sp_uni(c ? 1u : 0u);
 #else
   return c ? 1u : 0u;

@@ -61,10 +61,12 @@ int spec_variant_forced() {
   return (w == 8 || w == 12 || w == 16) ? w / 4 - 1 : 0;
 }
 
-bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not) {
-  if (!generate_spec_source(plan, 4 * ((variant >= 0 && variant <= 3 ? variant : 0) + 1), source, why_not)) return false;
-  std::string h1, h2;
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not,
+                         bool dual) {
+  if (!generate_spec_source(plan, 4 * ((variant >= 0 && variant <= 3 ? variant : 0) + 1), source, why_not, dual)) return false;
+  std::string h1, h2, h3;
   const std::string inc = spec_include_dir();
+  if (dual && !read_file(inc + "/spec_kernel_dual.h", h3)) { why_not = "spec_kernel_dual.h not found under " + inc; return false; }
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2)) {
     why_not = "kernel template headers not found under " + inc;
     return false;
@@ -73,6 +75,7 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
   s.update(source.data(), source.size());
   s.update(h1.data(), h1.size());
   s.update(h2.data(), h2.size());
+  s.update(h3.data(), h3.size());
   if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));   // e.g. -DZPQ_PROF
   key = hex20(s.result());
   return true;

@@ -30,7 +30,9 @@ int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
 
 // Source text + cache key (with the template-header digest) for prebuilding.
-bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
+// dual = true: the experimental two-blocks-per-wavefront kernel (never requested by the engine)
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not,
+                         bool dual = false);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
 size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log);
 std::string spec_include_dir();
