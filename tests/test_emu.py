@@ -107,3 +107,26 @@ def test_two_blocks_per_wavefront_prototype(zlib_, oracle, golden, waves):
             header = bytes.fromhex(e["header"])
             d = gen_input(e).tobytes()
             _check(oracle, header, [d[:900], d[100:500], d[:300]], waves, dual=True)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle, dual):
+    """Decoder::decode's error rules and Decompresser::decompress(n)'s "first n bytes": a truncated stream ends with
+    status 6 (EOF) or 2 (corrupt), never with output past what was coded; a capacity smaller than the block returns
+    exactly that prefix with consumed = 0; garbage does not crash and does not reproduce the data.  In the
+    two-blocks-per-wavefront prototype a failing block must not disturb its partner."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    d = b"\0" + corpus.block("text", 1500, 77).tobytes()
+    c = oracle.encode(header, d)
+    good = c + b"\0\0\0\0"
+    rng = np.random.default_rng(5)
+    garbage = rng.integers(0, 256, 400, dtype=np.uint8).tobytes()
+    res = emu.run(header, [c[:len(c) // 2], good, garbage, good], decode=True, waves=4, out_cap=len(d) + 8, dual=dual)
+    (t_out, t_st, _), (g_out, g_st, g_used), (x_out, x_st, _), (g2_out, g2_st, _) = res
+    assert t_st in (6, 2) and d.startswith(t_out[:len(t_out) - 1] if t_out else b"")
+    assert g_st == 0 and g_out == d and g_used == len(c) + 4
+    assert x_st in (0, 2, 6) and x_out != d
+    assert g2_st == 0 and g2_out == d
+    (p_out, p_st, p_used), = emu.run(header, [good], decode=True, waves=4, out_cap=701, dual=dual)
+    assert p_st == 0 and p_used == 0 and p_out == d[:701]
