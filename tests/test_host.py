@@ -4,6 +4,7 @@ import ctypes
 import hashlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -47,6 +48,20 @@ def test_sha1(zlib_):
     for n in [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 1000, 70000]:
         d = corpus.lcg_bytes(n, 3)
         assert zlib_.sha1(d) == hashlib.sha1(d.tobytes()).digest()
+
+
+def test_sha1_portable_path():
+    """sha1.cpp picks the x86 SHA-extension compression function at run time; the portable one must agree."""
+    import subprocess
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import zpaq_amd as z\n"
+            "from zpaq_amd import corpus\n"
+            "assert all(z.sha1(corpus.lcg_bytes(n, 9)) == hashlib.sha1(corpus.lcg_bytes(n, 9).tobytes()).digest()\n"
+            "           for n in (0, 1, 55, 56, 63, 64, 65, 127, 128, 1000, 70001))\n"
+            "print('same')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ZPAQ_AMD_NO_SHANI="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-1500:]
 
 
 def test_tables_match_oracle_and_checksums(zlib_, oracle):
