@@ -35,6 +35,14 @@ def main():
             for h in headers:
                 src, key = prebuild.source_and_key(h)
                 print(defs or "(default)", "waves", w, *prebuild.compile_one((src, key, cache, inc)))
+    # the experimental two-blocks-per-wavefront kernel, 4 and 8 wavefronts per workgroup (8 / 16 blocks)
+    os.environ.pop("ZPAQ_AMD_SPEC_DEFS", None)
+    os.environ["ZPAQ_AMD_SPEC_DUAL"] = "1"
+    for w in ("4", "8"):
+        os.environ["ZPAQ_AMD_SPEC_WAVES"] = w
+        for h in headers:
+            src, key = prebuild.source_and_key(h)
+            print("dual", "waves", w, *prebuild.compile_one((src, key, cache, inc)))
 
 
 if __name__ == "__main__":

@@ -14,6 +14,18 @@ except Exception as e:
     print('%-58s %5d x %-8d FAILED %s' % ('$1', $2, $3, l[-200:]))
 "
 }
+rund() {  # dual-wavefronts  blocks  bytes : the experimental two-blocks-per-wavefront kernel (bench.py --dual)
+  timeout 150 python bench.py --dual $1 --blocks $2 --block-bytes $3 --cpu-seconds 0 --warmup 0 2>&1 | tail -1 | python -c "
+import sys, json
+l = sys.stdin.read().strip()
+try:
+    j = json.loads(l)
+    ms = j['kernel_ms']['code']
+    print('%-58s %5d x %-8d code_ms=%9.1f  kernel MB/s=%7.2f  ok=%s verified=%s' % ('--dual $1', $2, $3, ms, $2 * $3 / 1e3 / ms, j['all_status_ok'], j['roundtrip_verified_blocks']))
+except Exception as e:
+    print('%-58s %5d x %-8d FAILED %s' % ('--dual $1', $2, $3, l[-300:]))
+"
+}
 T="ZPAQ_AMD_SPEC_DEFS=-DZPQ_TOUCH2=1"
 for size in 65536 1048576; do
   run "ZPAQ_AMD_SPEC_WAVES=4" 1024 $size
@@ -25,5 +37,8 @@ for size in 65536 1048576; do
     # so the 12-block shape cannot be filled completely (204 of 256 workgroup slots) and the 16-block shape not at all
     run "ZPAQ_AMD_SPEC_WAVES=12" 2448 $size
     run "ZPAQ_AMD_SPEC_WAVES=12 $T" 2448 $size
+    rund 4 2048 $size      # 8 blocks per CU, one wavefront per SIMD
+    rund 8 2048 $size      # 8 blocks per CU on half the CUs ... and
+    rund 8 2400 $size      # ... as many as HBM holds
   fi
 done

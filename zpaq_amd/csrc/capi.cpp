@@ -173,6 +173,17 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
   ZPQ_CATCH
 }
 
+int zpq_code_device_dual(int decode, zpq_plan* plan, int waves, const void* d_in, const uint64_t* in_off,
+                         const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
+                         const uint32_t* cap, zpq_block_result* d_res, int timed) {
+  ZPQ_TRY
+  if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
+  engine_code_device_dual(decode != 0, plan, waves, d_in, in_off, in_len, nblocks, d_out, out_off, cap, (BlockResult*)d_res,
+                          timed != 0);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks) {
   Timing t = engine_last_timing();
   if (init_ms) *init_ms = t.init_ms;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 #include <vector>
 
@@ -170,6 +171,48 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   plan->spec[variant] = k;
   plan->spec_state[variant] = 1;
   plan->spec_note = origin;
+  return k;
+}
+
+// EXPERIMENTAL: the two-blocks-per-wavefront kernel of a plan (device/spec_kernel_dual.h).  Kept apart from
+// spec_kernel_for on purpose -- nothing the engine does by default goes through here.  Loaded kernels live
+// until the process ends.
+SpecKernel* spec_kernel_dual_for(zpq_plan* plan, int waves, std::string& note) {
+  static std::map<std::pair<zpq_plan*, int>, SpecKernel*> loaded;
+  const auto it = loaded.find({plan, waves});
+  if (it != loaded.end()) return it->second;
+  std::string source, key, why;
+  const int variant = waves / 4 - 1;
+  if (waves % 4 || variant < 0 || variant > 3 || !spec_source_and_key(*plan, variant, source, key, why, true)) {
+    note = why.empty() ? "unsupported workgroup shape" : why;
+    return nullptr;
+  }
+  std::vector<char> code;
+  std::string blob, origin;
+  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
+  if (read_file(path, blob) && !blob.empty()) {
+    code.assign(blob.begin(), blob.end());
+    origin = "cache:" + key;
+  } else {
+    std::string log;
+    if (!compile_hiprtc(source, code, log)) { note = "hipRTC compile failed: " + log.substr(0, 2000); return nullptr; }
+    origin = "hiprtc";
+  }
+  SpecKernel* k = new SpecKernel;
+  hipFunction_t marker = nullptr;
+  if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&k->encode, k->module, "zpq_spec_encode") != hipSuccess ||
+      hipModuleGetFunction(&k->decode, k->module, "zpq_spec_decode") != hipSuccess ||
+      hipModuleGetFunction(&marker, k->module, "zpq_spec_two_blocks_per_wavefront") != hipSuccess) {
+    note = "hipModuleLoadData failed for " + origin;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    return nullptr;
+  }
+  k->waves = waves;
+  k->origin = origin;
+  note = origin;
+  loaded[{plan, waves}] = k;
   return k;
 }
 

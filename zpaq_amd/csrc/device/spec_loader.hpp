@@ -28,6 +28,9 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, 
 // ZPAQ_AMD_SPEC_WAVES=4|8|12|16 forces one workgroup shape (tests, experiments, prebuild): its variant, or -1 when unset
 int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
+// EXPERIMENTAL two-blocks-per-wavefront kernel (spec_kernel_dual.h), `waves` wavefronts per workgroup; nullptr + note
+// when unavailable.  Only engine_code_device_dual uses it.
+SpecKernel* spec_kernel_dual_for(zpq_plan* plan, int waves, std::string& note);
 
 // Source text + cache key (with the template-header digest) for prebuilding.
 // dual = true: the experimental two-blocks-per-wavefront kernel (never requested by the engine)
