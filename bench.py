@@ -125,9 +125,6 @@ def main():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
                     help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
-    ap.add_argument("--dual", type=int, default=0,
-                    help="EXPERIMENTAL: code with the two-blocks-per-wavefront kernel, this many wavefronts per workgroup "
-                         "(one plan only; the round-trip check still decodes with the regular kernel)")
     ap.add_argument("--distribute", action="store_true",
                     help="N>1: rank 0 generates the whole corpus and scatters it over RCCL; coded blocks are gathered back "
                          "(timed separately as dist_ms; the hot path itself has no collective)")
@@ -188,7 +185,7 @@ def main():
     host_in[:, 1:bs + 1] = blocks
     d_in = torch.from_numpy(host_in).to(dev)
     d_out = torch.empty((nb, stride_out), dtype=torch.uint8, device=dev)
-    d_res = torch.zeros((nb + 1, 4), dtype=torch.int32, device=dev)   # +1: padding job of the experimental --dual path
+    d_res = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
     L = z.lib()
 
     # one plan pointer per block: the engine groups blocks by plan and runs the groups concurrently
@@ -205,20 +202,8 @@ def main():
                                         C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_int]
 
-    L.zpq_code_device_dual.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64),
-                                       C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
-                                       C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
-    if a.dual:
-        assert len(groups) == 1, "--dual codes one plan"
 
     def step():
-        if a.dual:
-            rc = L.zpq_code_device_dual(0, plan_of[0]._h, a.dual, C.c_void_p(d_in.data_ptr()), IO, IL, nb,
-                                        C.c_void_p(d_out.data_ptr()), OO, OC, C.c_void_p(d_res.data_ptr()), 1)
-            if rc:
-                raise RuntimeError(L.zpq_last_error().decode())
-            t = z.last_timing()
-            return t[0], t[1]
         rc = L.zpq_code_device_multi(0, PA, C.c_void_p(d_in.data_ptr()), IO, IL, nb, C.c_void_p(d_out.data_ptr()),
                                      OO, OC, C.c_void_p(d_res.data_ptr()), None, 1)
         if rc:

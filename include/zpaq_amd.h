@@ -148,13 +148,6 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
                           const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks,
                           void* d_out, const uint64_t* out_off, const uint32_t* cap,
                           zpq_block_result* d_res, void* stream, int timed);
-/* EXPERIMENTAL: the same for ONE plan with the two-blocks-per-wavefront kernel
- * (`waves` wavefronts = 2 * waves blocks per workgroup; chains of at most 32 components).  d_res needs
- * nblocks + 1 slots.  Always runs on the engine's own stream and returns when the batch is done.  Not used by any
- * other entry point; its results must be identical to zpq_encode_device / zpq_decode_device. */
-int zpq_code_device_dual(int decode, zpq_plan* plan, int waves, const void* d_in, const uint64_t* in_off,
-                         const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                         const uint32_t* out_cap, zpq_block_result* d_res, int timed);
 /* Durations (ms, hipEvent) of the last timed call on this process: Predictor
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);

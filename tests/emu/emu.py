@@ -16,7 +16,7 @@ EMU = os.path.join(ROOT, "tests", "emu")
 BUILD = os.path.join(ROOT, "build", "emu")
 
 
-def kernel_source(header: bytes, waves: int, dual: bool = False) -> str:
+def kernel_source(header: bytes, waves: int) -> str:
     import zpaq_amd as z
     L = z.lib()
     L.zpq_plan_spec_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
@@ -24,9 +24,8 @@ def kernel_source(header: bytes, waves: int, dual: bool = False) -> str:
     buf = C.create_string_buffer(4 << 20)
     ln = C.c_size_t(0)
     key = C.create_string_buffer(41)
-    old = {k: os.environ.get(k) for k in ("ZPAQ_AMD_SPEC_WAVES", "ZPAQ_AMD_SPEC_DUAL")}
+    old = {k: os.environ.get(k) for k in ("ZPAQ_AMD_SPEC_WAVES",)}
     os.environ["ZPAQ_AMD_SPEC_WAVES"] = str(waves)
-    os.environ["ZPAQ_AMD_SPEC_DUAL"] = "1" if dual else "0"
     try:
         rc = L.zpq_plan_spec_source(plan._h, buf, len(buf), C.byref(ln), key)
     finally:
@@ -40,12 +39,11 @@ def kernel_source(header: bytes, waves: int, dual: bool = False) -> str:
     return buf.value.decode()
 
 
-def build(header: bytes, waves: int, extra_flags: Sequence[str] = (), dual: bool = False) -> str:
+def build(header: bytes, waves: int, extra_flags: Sequence[str] = ()) -> str:
     """Compile the emulator executable for this header/shape (cached under build/emu); returns its path."""
     import zpaq_amd as z
-    src = kernel_source(header, waves, dual)
+    src = kernel_source(header, waves)
     deps = b"".join(open(p, "rb").read() for p in (
-        os.path.join(ROOT, "zpaq_amd", "csrc", "device", "spec_kernel_dual.h"),
         os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "emu_main.cpp"),
         os.path.join(ROOT, "zpaq_amd", "csrc", "device", "spec_kernel.h"),
         os.path.join(ROOT, "zpaq_amd", "csrc", "device", "layout.h")))
@@ -69,11 +67,9 @@ def build(header: bytes, waves: int, extra_flags: Sequence[str] = (), dual: bool
     return exe
 
 
-def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int = 4, out_cap: int | None = None,
-        dual: bool = False):
-    """Code every input as one block (one wavefront each, or two per wavefront with dual=True -- the experimental
-    kernel).  Returns [(bytes, status, consumed)]."""
-    exe = build(header, waves, dual=dual)
+def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int = 4, out_cap: int | None = None):
+    """Code every input as one block (one wavefront each).  Returns [(bytes, status, consumed)]."""
+    exe = build(header, waves)
     cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
     with tempfile.TemporaryDirectory(dir=BUILD) as td:
         hp = os.path.join(td, "h.bin")
@@ -83,7 +79,7 @@ def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int
             p = os.path.join(td, f"in{i}")
             open(p, "wb").write(bytes(d))
             paths.append(p)
-        r = subprocess.run([exe, "dec" if decode else "enc", str(waves) + ("d" if dual else ""), hp, str(cap), os.path.join(td, "out"), *paths],
+        r = subprocess.run([exe, "dec" if decode else "enc", str(waves), hp, str(cap), os.path.join(td, "out"), *paths],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
             raise RuntimeError(f"emulator failed ({r.returncode}): {r.stderr[-2000:]}")

@@ -1,10 +1,8 @@
 // TEST INFRASTRUCTURE -- driver of the host-side wavefront emulator (see wave_emu.h).
 //
-//   emu_run enc|dec <waves>[d] <header.bin> <out_cap> <out_prefix> <input> [<input> ...]
+//   emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input> [<input> ...]
 //
-// <waves> = wavefronts per workgroup the kernel was generated for; a trailing "d" says it is the experimental
-// two-blocks-per-wavefront kernel (spec_kernel_dual.h): then the job array is padded to an even number of
-// entries with an empty job that has an arena and a result slot of its own.
+// <waves> = wavefronts (= blocks) per workgroup the kernel was generated for.
 //
 // Runs the generated specialised kernel (compiled into this executable from the text
 // zpq_plan_spec_source returns) over the given inputs, one ZPAQ block per wavefront,
@@ -77,7 +75,6 @@ int main(int argc, char** argv) {
   if (argc < 7) { fprintf(stderr, "usage: emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
   const bool dec = !strcmp(argv[1], "dec");
   const unsigned waves = (unsigned)atoi(argv[2]);
-  const bool dual = strchr(argv[2], 'd') != nullptr;
   const std::vector<uint8_t> header = slurp(argv[3]);
   const uint32_t out_cap = (uint32_t)strtoul(argv[4], nullptr, 10);
   const std::string prefix = argv[5];
@@ -97,7 +94,7 @@ int main(int argc, char** argv) {
       !zpq_table(7, tb.sse_row, sizeof tb.sse_row)) { fprintf(stderr, "tables unavailable\n"); return 2; }
   memcpy(tb.dt2k, dt2k, sizeof dt2k);
 
-  const unsigned njobs = dual ? (nb + 1) & ~1u : nb;     // padded job count
+  const unsigned njobs = nb;
   std::vector<std::vector<uint8_t>> ins(njobs), outs(njobs);
   std::vector<zpq::BlockJob> jobs(njobs);
   std::vector<zpq::BlockResult> res(njobs);
@@ -119,7 +116,7 @@ int main(int argc, char** argv) {
     res[b] = zpq::BlockResult{0, 0, -1, 0};
   }
   Launch l{dec, jobs.data(), res.data(), nb, &tb};
-  const unsigned per_wg = dual ? 2 * waves : waves;      // blocks per workgroup
+  const unsigned per_wg = waves;      // blocks per workgroup
   for (unsigned wg = 0; wg < (nb + per_wg - 1) / per_wg; ++wg) emu::run_workgroup(kernel_thunk, &l, 64 * waves, wg);
   for (unsigned b = 0; b < nb; ++b) {
     // guard bytes past the capacity must be untouched

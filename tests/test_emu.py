@@ -18,14 +18,14 @@ from zpaq_amd import corpus  # noqa: E402
 DEEP_ISSE = "x0,0ci1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1m"
 
 
-def _check(oracle, header, datas, waves, dual=False):
+def _check(oracle, header, datas, waves):
     inputs = [b"\0" + bytes(d) for d in datas]
-    enc = emu.run(header, inputs, waves=waves, dual=dual)
+    enc = emu.run(header, inputs, waves=waves)
     for inp, (coded, status, consumed) in zip(inputs, enc):
         assert status == 0 and consumed == len(inp)
         assert coded == oracle.encode(header, inp)
     dec = emu.run(header, [c + b"\0\0\0\0" for c, _, _ in enc], decode=True, waves=waves,
-                  out_cap=max(len(x) for x in inputs), dual=dual)
+                  out_cap=max(len(x) for x in inputs))
     for inp, (c, _, _), (plain, status, consumed) in zip(inputs, enc, dec):
         # a block that fills its capacity exactly stops before the end-of-stream marker
         assert status == 0 and plain == inp[:len(plain)] and len(plain) == len(inp)
@@ -84,37 +84,10 @@ def test_every_golden_chain(zlib_, oracle, golden):
     assert len(seen) >= 8
 
 
-@pytest.mark.parametrize("waves", [12, 16])
-def test_experimental_shapes(zlib_, oracle, waves):
-    """12 / 16 blocks per workgroup (3 / 4 wavefronts per SIMD, 10 / 7.5 KiB of LDS per block): generated for
-    experiments through ZPAQ_AMD_SPEC_WAVES, never chosen by the engine on its own; they must still be exact."""
-    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
-    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
-    _check(oracle, header, _ragged(500) + _ragged(300) + _ragged(200), waves)
-
-
-@pytest.mark.parametrize("waves", [4, 8])
-def test_two_blocks_per_wavefront_prototype(zlib_, oracle, golden, waves):
-    """EXPERIMENTAL kernel (spec_kernel_dual.h): lanes 0-31 code one block, lanes 32-63
-    another.  Never selected by the engine and never run on a GPU yet; it must already be exact here -- odd block
-    counts (padding job), ragged lengths (a finished block idles beside its partner), empty blocks, decode."""
-    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
-    for method in ("5", "4"):
-        header, _, _ = zlib_.method_to_header(zlib_.expand_method(method, blk))
-        _check(oracle, header, _ragged(600) + _ragged(250)[:2], waves, dual=True)
-    if waves == 4:
-        for e in [golden["config_cases"][0], golden["level_cases"][2]]:
-            header = bytes.fromhex(e["header"])
-            d = gen_input(e).tobytes()
-            _check(oracle, header, [d[:900], d[100:500], d[:300]], waves, dual=True)
-
-
-@pytest.mark.parametrize("dual", [False, True])
-def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle, dual):
+def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle):
     """Decoder::decode's error rules and Decompresser::decompress(n)'s "first n bytes": a truncated stream ends with
     status 6 (EOF) or 2 (corrupt), never with output past what was coded; a capacity smaller than the block returns
-    exactly that prefix with consumed = 0; garbage does not crash and does not reproduce the data.  In the
-    two-blocks-per-wavefront prototype a failing block must not disturb its partner."""
+    exactly that prefix with consumed = 0; garbage does not crash and does not reproduce the data."""
     blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
     header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
     d = b"\0" + corpus.block("text", 1500, 77).tobytes()
@@ -122,11 +95,11 @@ def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle, dual):
     good = c + b"\0\0\0\0"
     rng = np.random.default_rng(5)
     garbage = rng.integers(0, 256, 400, dtype=np.uint8).tobytes()
-    res = emu.run(header, [c[:len(c) // 2], good, garbage, good], decode=True, waves=4, out_cap=len(d) + 8, dual=dual)
+    res = emu.run(header, [c[:len(c) // 2], good, garbage, good], decode=True, waves=4, out_cap=len(d) + 8)
     (t_out, t_st, _), (g_out, g_st, g_used), (x_out, x_st, _), (g2_out, g2_st, _) = res
     assert t_st in (6, 2) and d.startswith(t_out[:len(t_out) - 1] if t_out else b"")
     assert g_st == 0 and g_out == d and g_used == len(c) + 4
     assert x_st in (0, 2, 6) and x_out != d
     assert g2_st == 0 and g2_out == d
-    (p_out, p_st, p_used), = emu.run(header, [good], decode=True, waves=4, out_cap=701, dual=dual)
+    (p_out, p_st, p_used), = emu.run(header, [good], decode=True, waves=4, out_cap=701)
     assert p_st == 0 and p_used == 0 and p_out == d[:701]

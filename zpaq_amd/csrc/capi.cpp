@@ -54,8 +54,7 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   if (!p) fail(ZPQ_E_ARG, "null plan");
   std::string source, key, why;
   const int variant = spec_variant_forced() > 0 ? spec_variant_forced() : 0;   // ZPAQ_AMD_SPEC_WAVES selects the shape
-  const char* dual = getenv("ZPAQ_AMD_SPEC_DUAL");   // experimental two-blocks-per-wavefront kernel (tests/emu only)
-  if (!spec_source_and_key(*p, variant, source, key, why, dual && dual[0] == '1')) fail(ZPQ_E_UNSUPPORTED, why);
+  if (!spec_source_and_key(*p, variant, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
   if (len) *len = source.size();
   if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
   if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
@@ -169,17 +168,6 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
     if (!plans[b] || plans[b]->hdr().n == 0) fail(ZPQ_E_ARG, "needs modelled plans");
   engine_code_device(decode != 0, plans, false, d_in, in_off, in_len, nblocks, d_out, out_off, cap, (BlockResult*)d_res,
                      stream, timed != 0);
-  return ZPQ_OK;
-  ZPQ_CATCH
-}
-
-int zpq_code_device_dual(int decode, zpq_plan* plan, int waves, const void* d_in, const uint64_t* in_off,
-                         const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                         const uint32_t* cap, zpq_block_result* d_res, int timed) {
-  ZPQ_TRY
-  if (!plan || plan->hdr().n == 0) fail(ZPQ_E_ARG, "needs a modelled plan");
-  engine_code_device_dual(decode != 0, plan, waves, d_in, in_off, in_len, nblocks, d_out, out_off, cap, (BlockResult*)d_res,
-                          timed != 0);
   return ZPQ_OK;
   ZPQ_CATCH
 }

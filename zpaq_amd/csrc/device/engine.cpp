@@ -422,74 +422,6 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed);
 }
 
-// EXPERIMENTAL: one plan, two blocks per wavefront.  A separate entry on purpose: nothing
-// above was changed for it.  d_res must have nblocks + 1 slots (the last one belongs to the padding job of an
-// odd batch).  Partner blocks get neighbouring arenas, which the kernel addresses relative to the first one.
-void engine_code_device_dual(bool decode, zpq_plan* plan, int waves, const void* d_in, const uint64_t* in_off,
-                             const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                             const uint32_t* out_cap, BlockResult* d_res, bool timed) {
-  Engine& e = eng();
-  std::lock_guard<std::mutex> g(e.mu);
-  require_ready(e);
-  HIP_CHECK(hipSetDevice(e.device));
-  std::string note;
-  SpecKernel* k = spec_kernel_dual_for(plan, waves, note);
-  if (!k) fail(ZPQ_E_UNSUPPORTED, "two-blocks-per-wavefront kernel unavailable: " + note);
-  const uint64_t arena_bytes = plan->hdr().arena_bytes;
-  if (arena_bytes >= (1ull << 31)) fail(ZPQ_E_UNSUPPORTED, "model state of 2 GiB or more per block");
-  const uint32_t njobs = (nblocks + 1) & ~1u;
-  const uint64_t need = (uint64_t)njobs * arena_bytes;
-  if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
-  e.arena.ensure(need);
-  e.jobs.ensure((size_t)njobs * sizeof(BlockJob));
-  std::vector<BlockJob> jobs(njobs);
-  for (uint32_t b = 0; b < njobs; ++b) {
-    BlockJob& j = jobs[b];
-    memset(&j, 0, sizeof(j));
-    j.plan = plan_on_device(e, plan);
-    j.arena = (uint8_t*)e.arena.p + (uint64_t)b * arena_bytes;
-    const bool real = b < nblocks;
-    j.in = (const uint8_t*)d_in + (real ? in_off[b] : 0);
-    j.out = (uint8_t*)d_out + (real ? out_off[b] : 0);
-    j.in_len = real ? in_len[b] : 0;
-    j.out_cap = real ? out_cap[b] : 0;
-    j.res_slot = b;
-  }
-  hipStream_t st = e.stream;
-  HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), (size_t)njobs * sizeof(BlockJob), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  if (timed) for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
-  uint64_t per = arena_bytes / (256 * 16 * 8) + 1;
-  uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), 64);
-  if ((uint64_t)chunks * njobs > 16384) chunks = (uint32_t)std::max<uint64_t>(1, 16384 / njobs);
-  if (timed) HIP_CHECK(hipEventRecord(ev[0], st));
-  HIP_CHECK(launch_init_arena((const BlockJob*)e.jobs.p, njobs, e.d_tables, chunks, st));
-  if (timed) HIP_CHECK(hipEventRecord(ev[1], st));
-  const BlockJob* d_jobs = (const BlockJob*)e.jobs.p;
-  const DeviceTables* d_tb = e.d_tables;
-  uint32_t n = njobs;
-  void* args[4] = {(void*)&d_jobs, (void*)&d_res, (void*)&n, (void*)&d_tb};
-  const uint32_t per_wg = 2u * (uint32_t)waves;
-  HIP_CHECK(hipModuleLaunchKernel(decode ? k->decode : k->encode, (njobs + per_wg - 1) / per_wg, 1, 1, 64u * (uint32_t)waves, 1,
-                                  1, 0, st, args, nullptr));
-  e.last = Timing{};
-  e.last_kind = 3;
-  if (timed) {
-    HIP_CHECK(hipEventRecord(ev[2], st));
-    HIP_CHECK(hipEventSynchronize(ev[2]));
-    float a = 0, b = 0;
-    HIP_CHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
-    HIP_CHECK(hipEventElapsedTime(&b, ev[1], ev[2]));
-    e.last.init_ms = a;
-    e.last.code_ms = b;
-    e.last.blocks = nblocks;
-    for (auto& x : ev) (void)hipEventDestroy(x);
-  } else {
-    HIP_CHECK(hipStreamSynchronize(st));
-  }
-}
-
 int engine_selftest(int32_t out[8]) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);

@@ -39,10 +39,6 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
 
 // Device-resident batch; plans[0] for every block when one_plan, else plans[b] per block.  Results
 // land in the device array d_res in the caller's block order.
-// EXPERIMENTAL, see engine.cpp
-void engine_code_device_dual(bool decode, zpq_plan* plan, int waves, const void* d_in, const uint64_t* in_off,
-                             const uint32_t* in_len, uint32_t nblocks, void* d_out, const uint64_t* out_off,
-                             const uint32_t* out_cap, BlockResult* d_res, bool timed);
 void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan, const void* d_in,
                         const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks, void* d_out,
                         const uint64_t* out_off, const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed);

@@ -13,11 +13,10 @@ struct zpq_plan {
   void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
   int d_device = -1;
   // per-header specialised kernels (device/spec_loader.hpp), one per workgroup shape:
-  // [v] = 4 (v + 1) blocks per workgroup: [0] 4 (all side tables in LDS, one wavefront per SIMD), [1] 8 (two
-  // per SIMD); the engine chooses between these two.  [2] 12 and [3] 16 exist for experiments
-  // (ZPAQ_AMD_SPEC_WAVES) and are not selected automatically.
-  void* spec[4] = {nullptr, nullptr, nullptr, nullptr};   // SpecKernel*
-  int spec_state[4] = {0, 0, 0, 0};                       // 0 not tried, 1 loaded, -1 unavailable
+  // [0] 4 blocks per workgroup (all side tables in LDS, one wavefront per SIMD), [1] 8 (two per SIMD); the
+  // engine chooses per launch.  (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
+  void* spec[2] = {nullptr, nullptr};   // SpecKernel*
+  int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
   std::string spec_note;                // where the last kernel came from / why it is unavailable
   const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
   const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }

@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned sp_uni(unsigned v) { return (unsigned)__buil
 // HCOMP's condition flag: wave-uniform by construction; telling the compiler so keeps the VM's
 // branches scalar.  (The emulator runs HCOMP on one lane only -- no cross-lane traffic there.)
 __device__ __forceinline__ unsigned vm_flag(bool c) {
-#if !defined(ZPQ_EMU) && !defined(ZPQ_DUAL)   // two blocks per wavefront (spec_kernel_dual.h): the flag is per block
+#if !defined(ZPQ_EMU) && !defined(ZPQ_LANE_VM)   // ZPQ_LANE_VM: one HCOMP machine per lane (pipe_kernel.h), the flag is per lane
   return sp_uni(c ? 1u : 0u);
 #else
   return c ? 1u : 0u;
@@ -463,19 +463,6 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   int pdv[N];                  // MIX2: p[j] - p[k] of this bit (wave-uniform), read in predict, reused by update
 #pragma unroll
   for (int k = 0; k < N; ++k) pdv[k] = 0;
-  // EXPERIMENT (lead 1; off unless built with -DZPQ_TOUCH2=1): lines of the bit AFTER next.
-  // There are four candidates per table; they are only touched (pulled towards L2), nothing is kept.
-#ifndef ZPQ_TOUCH2
-#define ZPQ_TOUCH2 0
-#endif
-#if ZPQ_TOUCH2
-  unsigned tg[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
-  unsigned tm[NMIX][4], ts[NSSE][4];
-#pragma unroll
-  for (int k = 0; k < NMIX; ++k) { tm[k][0] = tm[k][1] = tm[k][2] = tm[k][3] = 0; }
-#pragma unroll
-  for (int k = 0; k < NSSE; ++k) { ts[k][0] = ts[k][1] = ts[k][2] = ts[k][3] = 0; }
-#endif
   bool pf_valid = false;       // candidates fetched during the previous bit are usable (uniform)
   int ylast = 0;
 
@@ -647,35 +634,6 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       gwc0 = G32(goff + 4u * ia);
       gwc1 = G32(goff + 4u * ib);
     }
-#if ZPQ_TOUCH2
-    if constexpr (B >= 0 && B <= 5) {
-      // the four (c8, hmap4) pairs two bits from now; the second step ends a nibble when B == 2
-      ZPQ_KEEP4(tg[0], tg[1], tg[2], tg[3]);
-      static_for<0, 4>([&](auto vc) __attribute__((always_inline)) {
-        constexpr int v = decltype(vc)::value;
-        const int c8v = c8 * 4 + v;
-        const int hm1 = (v >> 1) ? hm4b : hm4a;
-        const int y2 = v & 1;
-        const int hm2 = B == 2 ? ((hm1 & 0xf) << 5 | y2 << 4 | 1) : ((hm1 & 0x1f0) | (((hm1 & 0xf) * 2 + y2) & 0xf));
-        tg[v] = G32(goff + 4u * (g_index(c8v, hm2) & m_pf));
-        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-          constexpr CompK c = Chain::comp[decltype(ic)::value];
-          if constexpr (c.type == C_MIX && mix_pf(c) && c.mask0 >= 4095u) {      // small MIX tables live in L2 anyway
-            if constexpr (v == 0) ZPQ_KEEP4(tm[c.slot][0], tm[c.slot][1], tm[c.slot][2], tm[c.slot][3]);
-            tm[c.slot][v] = G32(mixbase[c.slot] + 4u * (((hmix[c.slot] + (unsigned)(c8v & 255)) & c.mask0) * c.a3));
-          } else if constexpr (c.type == C_SSE && sse_pf(c)) {
-            if constexpr (v == 0) ZPQ_KEEP4(ts[c.slot][0], ts[c.slot][1], ts[c.slot][2], ts[c.slot][3]);
-            ts[c.slot][v] = G32(ssebase[c.slot] + 4u * (((hsse[c.slot] + (unsigned)c8v) * 32u) & c.mask0));
-          }
-        });
-        if constexpr (B == 2) {                                                  // the next nibble's row: four lines
-          if constexpr (v == 0) ZPQ_KEEP4(tr[0], tr[1], tr[2], tr[3]);
-          const unsigned cxv = h + 16u * (unsigned)c8v;
-          tr[v] = G32(roff + ((cxv * 16u) & (rmask - 15u)));
-        }
-      });
-    }
-#endif
     gw = sp_blend(m_res, rw, gw);
 #ifdef ZPQ_PROF
     const unsigned long long pb2 = __builtin_readcyclecounter();

@@ -59,15 +59,13 @@ int spec_variant_forced() {
   const char* e = getenv("ZPAQ_AMD_SPEC_WAVES");
   if (!e || !e[0]) return -1;
   const int w = atoi(e);
-  return (w == 8 || w == 12 || w == 16) ? w / 4 - 1 : 0;
+  return w == 8 ? 1 : 0;
 }
 
-bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not,
-                         bool dual) {
-  if (!generate_spec_source(plan, 4 * ((variant >= 0 && variant <= 3 ? variant : 0) + 1), source, why_not, dual)) return false;
-  std::string h1, h2, h3;
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_spec_source(plan, variant == 1 ? 8 : 4, source, why_not)) return false;
+  std::string h1, h2;
   const std::string inc = spec_include_dir();
-  if (dual && !read_file(inc + "/spec_kernel_dual.h", h3)) { why_not = "spec_kernel_dual.h not found under " + inc; return false; }
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2)) {
     why_not = "kernel template headers not found under " + inc;
     return false;
@@ -76,7 +74,6 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
   s.update(source.data(), source.size());
   s.update(h1.data(), h1.size());
   s.update(h2.data(), h2.size());
-  s.update(h3.data(), h3.size());
   if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));   // e.g. -DZPQ_PROF
   key = hex20(s.result());
   return true;
@@ -119,7 +116,7 @@ size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log
 }
 
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* jit_deferred, bool* did_jit) {
-  if (variant < 0 || variant > 3) variant = 0;
+  if (variant < 0 || variant > 1) variant = 0;
   if (plan->spec_state[variant] > 0) return (SpecKernel*)plan->spec[variant];
   if (plan->spec_state[variant] < 0) return nullptr;
   plan->spec_state[variant] = -1;
@@ -174,50 +171,8 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   return k;
 }
 
-// EXPERIMENTAL: the two-blocks-per-wavefront kernel of a plan (device/spec_kernel_dual.h).  Kept apart from
-// spec_kernel_for on purpose -- nothing the engine does by default goes through here.  Loaded kernels live
-// until the process ends.
-SpecKernel* spec_kernel_dual_for(zpq_plan* plan, int waves, std::string& note) {
-  static std::map<std::pair<zpq_plan*, int>, SpecKernel*> loaded;
-  const auto it = loaded.find({plan, waves});
-  if (it != loaded.end()) return it->second;
-  std::string source, key, why;
-  const int variant = waves / 4 - 1;
-  if (waves % 4 || variant < 0 || variant > 3 || !spec_source_and_key(*plan, variant, source, key, why, true)) {
-    note = why.empty() ? "unsupported workgroup shape" : why;
-    return nullptr;
-  }
-  std::vector<char> code;
-  std::string blob, origin;
-  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
-  if (read_file(path, blob) && !blob.empty()) {
-    code.assign(blob.begin(), blob.end());
-    origin = "cache:" + key;
-  } else {
-    std::string log;
-    if (!compile_hiprtc(source, code, log)) { note = "hipRTC compile failed: " + log.substr(0, 2000); return nullptr; }
-    origin = "hiprtc";
-  }
-  SpecKernel* k = new SpecKernel;
-  hipFunction_t marker = nullptr;
-  if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
-      hipModuleGetFunction(&k->encode, k->module, "zpq_spec_encode") != hipSuccess ||
-      hipModuleGetFunction(&k->decode, k->module, "zpq_spec_decode") != hipSuccess ||
-      hipModuleGetFunction(&marker, k->module, "zpq_spec_two_blocks_per_wavefront") != hipSuccess) {
-    note = "hipModuleLoadData failed for " + origin;
-    if (k->module) (void)hipModuleUnload(k->module);
-    delete k;
-    return nullptr;
-  }
-  k->waves = waves;
-  k->origin = origin;
-  note = origin;
-  loaded[{plan, waves}] = k;
-  return k;
-}
-
 void spec_kernel_release(zpq_plan* plan) {
-  for (int v = 0; plan && v < 4; ++v) {
+  for (int v = 0; plan && v < 2; ++v) {
     if (!plan->spec[v]) continue;
     SpecKernel* k = (SpecKernel*)plan->spec[v];
     if (k->module) (void)hipModuleUnload(k->module);

@@ -22,20 +22,15 @@ struct SpecKernel {
 // code object back into the cache directory when that is writable.
 // allow_jit = false: only the in-tree cache is consulted; a miss leaves the plan untried (a later call may
 // compile it) and *jit_deferred is set.
-// variant v: 4 (v + 1) blocks per workgroup, v = 0..3 (see zpq_plan::spec)
+// variant 0: 4 blocks per workgroup, variant 1: 8 (see zpq_plan::spec)
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, bool* jit_deferred = nullptr,
                             bool* did_jit = nullptr);
-// ZPAQ_AMD_SPEC_WAVES=4|8|12|16 forces one workgroup shape (tests, experiments, prebuild): its variant, or -1 when unset
+// ZPAQ_AMD_SPEC_WAVES=4|8 forces one workgroup shape (tests, experiments, prebuild): its variant, or -1 when unset
 int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
-// EXPERIMENTAL two-blocks-per-wavefront kernel (spec_kernel_dual.h), `waves` wavefronts per workgroup; nullptr + note
-// when unavailable.  Only engine_code_device_dual uses it.
-SpecKernel* spec_kernel_dual_for(zpq_plan* plan, int waves, std::string& note);
 
 // Source text + cache key (with the template-header digest) for prebuilding.
-// dual = true: the experimental two-blocks-per-wavefront kernel (never requested by the engine)
-bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not,
-                         bool dual = false);
+bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
 size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log);
 std::string spec_include_dir();

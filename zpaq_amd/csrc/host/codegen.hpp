@@ -13,8 +13,7 @@ static const int kCodegenVersion = 3;
 // untranslatable HCOMP): such plans run on the generic kernels.
 // `waves` = blocks per workgroup the kernel is laid out for (4: every side table that fits 30 KiB in LDS,
 // one workgroup per CU; 8: half the LDS per block, two wavefronts per SIMD)
-// dual = true: the experimental two-blocks-per-wavefront kernel (device/spec_kernel_dual.h; n <= 32 only)
-bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, bool dual = false);
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not);
 
 // Cache key of a generated source: SHA-1 over the text (which embeds the codegen
 // version) -- the loader extends it with a digest of the kernel template headers.
