@@ -313,7 +313,8 @@ def main():
     # which kernel coded the blocks (3 = per-header specialised, 2 = generic wave, 1 = generic one-lane)
     note = C.create_string_buffer(512)
     kinds = sorted({int(L.zpq_plan_kernel_kind(pl._h, note, 512)) for pl, _ in groups})
-    kname = {3: "zpq_spec_" + "encode", 2: "code_wave_kernel<encode>", 1: "code_serial_kernel<encode>"}.get(kinds[-1], "?")
+    kname = {4: "zpq_pipe_" + "mix", 3: "zpq_spec_" + "encode", 2: "code_wave_kernel<encode>",
+             1: "code_serial_kernel<encode>"}.get(kinds[-1], "?")
     # HBM traffic per launch from the committed rocprofv3 PMC passes, when this exact workload was profiled
     traffic = None
     try:

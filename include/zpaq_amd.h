@@ -52,9 +52,10 @@ void zpq_shutdown(void);
 /* Cap on device bytes the engine may hold for model state (default: 85% of
  * free HBM at init).  Batches needing more are run in several residency waves. */
 int zpq_set_state_budget(uint64_t bytes);
-/* Select the coding kernel: 0 = auto (best available for each plan),
- * 1 = generic one-lane kernel, 2 = generic wave-parallel kernel, 3 = per-header
- * specialised kernel (fails with ZPQ_E_UNSUPPORTED when it cannot be built). */
+/* Select the coding kernel: 0 = auto (best available for each plan: the pipelined encoder for compression, the
+ * per-header specialised wavefront kernel for decompression), 1 = generic one-lane kernel, 2 = generic
+ * wave-parallel kernel, 3 = per-header specialised wavefront kernel in both directions, 4 = pipelined encoder
+ * (decompression as with 3).  3 and 4 fail with ZPQ_E_UNSUPPORTED when the kernel cannot be built. */
 int zpq_set_kernel(int which);
 
 /* ---- model plan: a parsed block header + device arena layout ---- */
@@ -80,16 +81,25 @@ double zpq_plan_algo_bytes_per_byte(const zpq_plan*);
  * precompile it to <cache dir>/<key>.hsaco; at run time the engine loads that
  * file or falls back to hipRTC.  Needs no GPU. */
 int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
+/* The same for the pipelined ENCODER of this header (device/pipe_kernel.h: one lane per block and component,
+ * components connected by streams in HBM; used for compression whenever the chain supports it), and its
+ * dataflow plan: out[0] bytes of stream buffer per group of blocks, [1] ring slots, [2] chunk bytes,
+ * [3] units in the light kernel, [4] ICM maps, [5] ISSE maps, [6] MIX wavefronts per group, [7] blocks per HCOMP
+ * workgroup, [8] highest dataflow level (a batch of L-byte blocks takes ceil(L / chunk) + out[8] steps),
+ * [9] blocks per group (= threads per workgroup of every kernel but hcomp, which has 64), [10] ROW units. */
+int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
+int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
 /* Introspection for tools and tests: the plan as the kernels see it (device/layout.h: PlanHeader,
  * CompDesc[n], Segment[nseg], HCOMP bytes).  The pointer stays valid until zpq_plan_destroy. */
 const uint8_t* zpq_plan_blob(const zpq_plan*, size_t* len);
-/* Which kernel will code this plan on the current device: 3 specialised,
+/* Which kernel will code this plan on the current device: 4 pipelined encoder (compression only), 3 specialised,
  * 2 generic wave, 1 generic one-lane.  note (optional) receives where the
  * specialised kernel came from ("cache:<key>" / "hiprtc") or why it is not used. */
-int zpq_plan_kernel_kind(zpq_plan*, char* note, size_t cap);
+int zpq_plan_kernel_kind(zpq_plan*, char* note, size_t cap);            /* compression */
+int zpq_plan_kernel_kind2(zpq_plan*, int decode, char* note, size_t cap);
 /* Directories used by the specialisation cache / hipRTC include path. */
 const char* zpq_spec_cache_dir(void);
 const char* zpq_spec_include_dir(void);
@@ -191,7 +201,8 @@ int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hc
 /* Host copies of the predictor's constant tables (for tests): which = 0 squash
  * u16[4096], 1 stretch i16[32768], 2 dt i32[1024], 3 dt2k i32[256], 4 state
  * table u8[1024], 5 ICM initial side table u32[256], 6 ISSE initial side table
- * u32[512], 7 SSE initial row u32[32] (Predictor::init, libzpaq.cpp:1776-1846).
+ * u32[512], 7 SSE initial row u32[32] (Predictor::init, libzpaq.cpp:1776-1846), 8 / 9 the compact form of
+ * stretch the pipelined encoder keeps in LDS (u32[2016] groups of 8 + i16[256] top end).
  * Returns bytes written. */
 size_t zpq_table(int which, void* out, size_t cap);
 

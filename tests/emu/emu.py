@@ -89,3 +89,92 @@ def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int
             status, consumed = int(line[3]), int(line[7])
             res.append((open(os.path.join(td, f"out.{i}"), "rb").read(), status, consumed))
         return res
+
+
+# ---- the pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h) ----
+def pipe_source(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None) -> str:
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_pipe_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    plan = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group):
+        rc = L.zpq_plan_pipe_source(plan._h, buf, len(buf), C.byref(ln), key)
+    if rc != 0:
+        raise RuntimeError(L.zpq_last_error().decode())
+    return buf.value.decode()
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = {k: (None if v is None else str(v)) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def pipe_build(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None) -> str:
+    import zpaq_amd as z
+    src = pipe_source(header, chunk, mix_lanes, group)
+    dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
+    deps = b"".join(open(p, "rb").read() for p in (
+        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"),
+        os.path.join(dev, "pipe_kernel.h"), os.path.join(dev, "spec_kernel.h"), os.path.join(dev, "layout.h")))
+    key = hashlib.sha1(src.encode() + deps).hexdigest()[:20]
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, f"pipe_{key}")
+    if os.path.exists(exe):
+        return exe
+    gen = os.path.join(BUILD, f"pgen_{key}.cpp")
+    with open(gen, "w") as fh:
+        fh.write('#include "wave_emu.h"\n' + src)
+    libdir = os.path.dirname(z.library_path())
+    cmd = ["g++", "-O1", "-std=c++17", "-w", "-I", EMU, "-I", dev, "-I", os.path.join(ROOT, "include"), gen,
+           os.path.join(EMU, "pipe_emu_main.cpp"), os.path.join(EMU, "wave_emu.cpp"),
+           "-L", libdir, "-lzpaq_amd", f"-Wl,-rpath,{libdir}", "-o", exe + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    os.remove(gen)
+    if r.returncode != 0:
+        raise RuntimeError("pipe emulator build failed:\n" + r.stdout[-6000:])
+    os.replace(exe + ".tmp", exe)
+    return exe
+
+
+def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, mix_lanes: int | None = None,
+             out_cap: int | None = None, group: int | None = None):
+    """Encode every input as one block with the pipelined encoder.  Returns [(bytes, status, consumed)]."""
+    exe = pipe_build(header, chunk, mix_lanes, group)
+    cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
+    with tempfile.TemporaryDirectory(dir=BUILD) as td:
+        hp = os.path.join(td, "h.bin")
+        open(hp, "wb").write(header)
+        paths = []
+        for i, d in enumerate(inputs):
+            p = os.path.join(td, f"in{i}")
+            open(p, "wb").write(bytes(d))
+            paths.append(p)
+        with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group):
+            r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), *paths],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+        if r.returncode != 0:
+            raise RuntimeError(f"pipe emulator failed ({r.returncode}): {r.stderr[-2000:]}")
+        res = []
+        for i in range(len(inputs)):
+            line = [l for l in r.stdout.splitlines() if l.startswith(f"block {i} ")][0].split()
+            status, consumed = int(line[3]), int(line[7])
+            res.append((open(os.path.join(td, f"out.{i}"), "rb").read(), status, consumed))
+        return res

@@ -91,7 +91,8 @@ int main(int argc, char** argv) {
   if (!zpq_table(1, tb.stretch, sizeof tb.stretch) || !zpq_table(0, tb.squash, sizeof tb.squash) ||
       !zpq_table(2, tb.dt, sizeof tb.dt) || !zpq_table(3, dt2k, sizeof dt2k) || !zpq_table(4, tb.ns, sizeof tb.ns) ||
       !zpq_table(5, tb.icm_init, sizeof tb.icm_init) || !zpq_table(6, tb.isse_init, sizeof tb.isse_init) ||
-      !zpq_table(7, tb.sse_row, sizeof tb.sse_row)) { fprintf(stderr, "tables unavailable\n"); return 2; }
+      !zpq_table(7, tb.sse_row, sizeof tb.sse_row) || !zpq_table(8, tb.stretch_cb, sizeof tb.stretch_cb) ||
+      !zpq_table(9, tb.stretch_top, sizeof tb.stretch_top)) { fprintf(stderr, "tables unavailable\n"); return 2; }
   memcpy(tb.dt2k, dt2k, sizeof dt2k);
 
   const unsigned njobs = nb;

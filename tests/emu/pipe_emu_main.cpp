@@ -1,0 +1,149 @@
+// TEST INFRASTRUCTURE -- host-side run of the PIPELINED ENCODER (zpaq_amd/csrc/device/pipe_kernel.h) under the
+// wavefront emulator (wave_emu.h).
+//
+//   pipe_emu_run <header.bin> <out_cap> <out_prefix> <input> [<input> ...]
+//
+// Runs the six generated kernels step by step over the inputs (one ZPAQ block each) exactly as the engine
+// launches them on the GPU -- same grids, same stream buffer, same arenas -- except that inside a step the
+// workgroups run in REVERSE dataflow order (consumers before producers): a unit that wrongly depended on data
+// produced in the same step would read a stale slot here and fail the comparison with the oracle.
+#include "wave_emu.h"
+
+#include <string>
+#include <vector>
+
+#include "layout.h"
+#include "zpaq_amd.h"
+
+extern "C" void zpq_pipe_hcomp(zpq::PipeArgs a);
+extern "C" void zpq_pipe_rows(zpq::PipeArgs a);
+extern "C" void zpq_pipe_light(zpq::PipeArgs a);
+extern "C" void zpq_pipe_icm(zpq::PipeArgs a);
+extern "C" void zpq_pipe_isse(zpq::PipeArgs a);
+extern "C" void zpq_pipe_mix(zpq::PipeArgs a);
+
+namespace {
+
+std::vector<uint8_t> slurp(const char* path) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+  fclose(f);
+  return v;
+}
+
+struct Launch { int which; zpq::PipeArgs a; };
+void kernel_thunk(void* p) {
+  Launch* l = (Launch*)p;
+  switch (l->which) {
+    case 0: zpq_pipe_hcomp(l->a); break;
+    case 1: zpq_pipe_rows(l->a); break;
+    case 2: zpq_pipe_light(l->a); break;
+    case 3: zpq_pipe_icm(l->a); break;
+    case 4: zpq_pipe_isse(l->a); break;
+    default: zpq_pipe_mix(l->a); break;
+  }
+}
+
+void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb) {
+  const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
+  const zpq::Segment* segs = (const zpq::Segment*)(blob + ph->off_seg);
+  for (uint32_t s = 0; s < ph->nseg; ++s) {
+    const zpq::Segment& sg = segs[s];
+    uint32_t* dst = (uint32_t*)(arena + sg.off);
+    const uint64_t n = sg.bytes / 4;
+    switch (sg.kind) {
+      case zpq::F_ZERO: break;
+      case zpq::F_U32: for (uint64_t i = 0; i < n; ++i) dst[i] = sg.value; break;
+      case zpq::F_SSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.sse_row[i & 31] | sg.value; break;
+      case zpq::F_ICM: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.icm_init[i]; break;
+      case zpq::F_ISSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.isse_init[i]; break;
+      case zpq::F_MATCHBUF: dst[0] = 1; break;
+      default: fprintf(stderr, "pipe_emu_run: unknown segment kind %u\n", sg.kind); exit(2);
+    }
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: pipe_emu_run <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
+  const std::vector<uint8_t> header = slurp(argv[1]);
+  const uint32_t out_cap = (uint32_t)strtoul(argv[2], nullptr, 10);
+  const std::string prefix = argv[3];
+  const unsigned nb = (unsigned)(argc - 4);
+
+  zpq_plan* plan = nullptr;
+  if (zpq_plan_create(header.data(), header.size(), &plan) != 0) { fprintf(stderr, "plan: %s\n", zpq_last_error()); return 2; }
+  size_t blob_len = 0;
+  const uint8_t* blob = zpq_plan_blob(plan, &blob_len);
+  const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
+  uint64_t lay[16];
+  if (zpq_plan_pipe_layout(plan, lay) != 0) { fprintf(stderr, "layout: %s\n", zpq_last_error()); return 2; }
+  const uint64_t group_bytes = lay[0];
+  const unsigned C = (unsigned)lay[2], nlight = (unsigned)lay[3], nicm = (unsigned)lay[4], nisse = (unsigned)lay[5],
+                 mixw = (unsigned)lay[6], hl = (unsigned)lay[7], maxlevel = (unsigned)lay[8], G = (unsigned)lay[9], nrows = (unsigned)lay[10];
+
+  static zpq::DeviceTables tb;
+  int32_t dt2k[256];
+  if (!zpq_table(1, tb.stretch, sizeof tb.stretch) || !zpq_table(0, tb.squash, sizeof tb.squash) ||
+      !zpq_table(2, tb.dt, sizeof tb.dt) || !zpq_table(3, dt2k, sizeof dt2k) || !zpq_table(4, tb.ns, sizeof tb.ns) ||
+      !zpq_table(5, tb.icm_init, sizeof tb.icm_init) || !zpq_table(6, tb.isse_init, sizeof tb.isse_init) ||
+      !zpq_table(7, tb.sse_row, sizeof tb.sse_row) || !zpq_table(8, tb.stretch_cb, sizeof tb.stretch_cb) ||
+      !zpq_table(9, tb.stretch_top, sizeof tb.stretch_top)) { fprintf(stderr, "tables unavailable\n"); return 2; }
+  memcpy(tb.dt2k, dt2k, sizeof dt2k);
+
+  std::vector<std::vector<uint8_t>> ins(nb), outs(nb);
+  std::vector<zpq::BlockJob> jobs(nb);
+  std::vector<zpq::BlockResult> res(nb);
+  uint8_t* pool = (uint8_t*)calloc((size_t)nb, ph->arena_bytes);
+  const unsigned ngroups = (nb + G - 1) / G;
+  // 0xA5 everywhere: a unit reading a stream slot nobody wrote gets garbage, not zeros
+  uint8_t* pipe = (uint8_t*)malloc((size_t)ngroups * group_bytes);
+  if (!pool || !pipe) { fprintf(stderr, "out of memory\n"); return 2; }
+  memset(pipe, 0xA5, (size_t)ngroups * group_bytes);
+  unsigned maxlen = 0;
+  for (unsigned b = 0; b < nb; ++b) {
+    ins[b] = slurp(argv[4 + b]);
+    outs[b].assign((size_t)out_cap + 64, 0xEE);
+    init_arena(pool + (size_t)b * ph->arena_bytes, blob, tb);
+    memset(&jobs[b], 0, sizeof(jobs[b]));
+    jobs[b].plan = blob;
+    jobs[b].arena = pool + (size_t)b * ph->arena_bytes;
+    jobs[b].in = ins[b].data();
+    jobs[b].out = outs[b].data();
+    jobs[b].in_len = (uint32_t)ins[b].size();
+    jobs[b].out_cap = out_cap;
+    jobs[b].res_slot = b;
+    res[b] = zpq::BlockResult{0, 0, -1, 0};
+    if (ins[b].size() > maxlen) maxlen = (unsigned)ins[b].size();
+  }
+  const unsigned nchunks = maxlen ? (maxlen + C - 1) / C : 1;
+  const unsigned grids[6] = {(nb + hl - 1) / hl, nrows * ngroups, nlight * ngroups, nicm * ngroups, nisse * ngroups, mixw * ngroups};
+  for (unsigned step = 0; step < nchunks + maxlevel; ++step) {
+    Launch l{0, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, (int)step, 0u}};
+    for (int which = 5; which >= 0; --which) {
+      l.which = which;
+      for (unsigned wg = grids[which]; wg-- > 0;) emu::run_workgroup(kernel_thunk, &l, which == 0 ? 64 : G, wg);
+    }
+  }
+  for (unsigned b = 0; b < nb; ++b) {
+    for (unsigned k = 0; k < 64; ++k)
+      if (outs[b][(size_t)out_cap + k] != 0xEE) { fprintf(stderr, "block %u wrote past its output capacity\n", b); return 3; }
+    const std::string path = prefix + "." + std::to_string(b);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { perror(path.c_str()); return 2; }
+    const uint32_t n = res[b].out_len < out_cap ? res[b].out_len : out_cap;
+    fwrite(outs[b].data(), 1, n, f);
+    fclose(f);
+    printf("block %u status %d out_len %u consumed %u steps %u\n", b, res[b].status, res[b].out_len, res[b].consumed,
+           res[b].steps);
+  }
+  free(pool);
+  free(pipe);
+  zpq_plan_destroy(plan);
+  return 0;
+}

@@ -39,6 +39,7 @@ using ::uint8_t; using ::uint16_t; using ::uint32_t; using ::uint64_t;
 
 struct uint4 { unsigned x, y, z, w; };
 struct int2 { int x, y; };
+struct uint2 { unsigned x, y; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
@@ -72,6 +73,15 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu::wave_
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu::wave_exchange(v)[0]; }   // all lanes active here
 static inline int __shfl(int v, int src) { return emu::wave_exchange(v)[src & 63]; }
 static inline unsigned __shfl(unsigned v, int src) { return (unsigned)emu::wave_exchange((int)v)[src & 63]; }
+namespace emu {
+static inline bool wave_any(bool x) {        // true if x holds in any lane that reaches this point
+  const int* v = wave_exchange(x ? 1 : 0);
+  // lanes that already left the kernel keep a stale slot; they published 0 or 1 at an earlier exchange --
+  // the pipe kernels call this before any lane can exit, so all 64 slots are current
+  for (int i = 0; i < 64; ++i) if (v[i]) return true;
+  return false;
+}
+}  // namespace emu
 static inline int __mul24(int a, int b) {
   const int x = (int)((unsigned)a << 8) >> 8, y = (int)((unsigned)b << 8) >> 8;
   return (int)((unsigned)x * (unsigned)y);
@@ -90,6 +100,12 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   } else if (ctrl >= 0x101 && ctrl <= 0x10F) {                              // row_shl:n
     const int n = ctrl - 0x100;
     if (in_row + n < 16) from = lane + n;
+  } else if (ctrl >= 0 && ctrl <= 0xFF) {                                   // quad_perm:[a,b,c,d]
+    from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  } else if (ctrl == 0x140) {                                               // row_mirror
+    from = (lane & ~15) | (15 - in_row);
+  } else if (ctrl == 0x141) {                                               // row_half_mirror
+    from = (lane & ~7) | (7 - (lane & 7));
   } else if (ctrl == 0x138) {                                               // wave_shr:1
     if (lane >= 1) from = lane - 1;
   } else if (ctrl == 0x130) {                                               // wave_shl:1

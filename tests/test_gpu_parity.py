@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [3, 2, 1]   # per-header specialised, generic wave-parallel, generic one-lane
-SIZE_LIMIT = {3: 262144, 2: 20000, 1: 2000}   # the generic kernels are fallbacks: keep their cases short
+# 4 = pipelined encoder (decodes with 3), 3 = per-header specialised wavefront kernel, 2 = generic wave-parallel, 1 = generic one-lane
+KERNELS = [4, 3, 2, 1]
+SIZE_LIMIT = {4: 262144, 3: 262144, 2: 20000, 1: 2000}   # the generic kernels are fallbacks: keep their cases short
 
 
 def test_cross_lane_selftest(gpu):
@@ -138,23 +139,32 @@ def test_specialised_kernel_is_the_one_running(gpu, golden, oracle):
     d = corpus.block("text", 1 << 20, corpus.BASE_SEED)
     h, _, _ = gpu.method_to_header(gpu.expand_method("5", d))
     plan = gpu.Plan(h)
-    assert L.zpq_plan_kernel_kind(plan._h, note, 4096) == 3, note.value
+    # compression runs on the pipelined encoder (4), decompression on the per-header wavefront kernel (3)
+    assert L.zpq_plan_kernel_kind(plan._h, note, 4096) == 4, note.value
+    assert note.value.startswith(b"cache:"), note.value
+    assert L.zpq_plan_kernel_kind2(plan._h, 1, note, 4096) == 3, note.value
     assert note.value.startswith(b"cache:"), note.value
     d = corpus.block("records", 30000, 77)          # period detection -> a chain nobody prebuilt
     h2, _, _ = gpu.method_to_header(gpu.expand_method("5", d))
     assert h2 != h
     plan2 = gpu.Plan(h2)
-    kind = L.zpq_plan_kernel_kind(plan2._h, note, 4096)
-    assert kind == 3, note.value
-    assert note.value.startswith(b"hiprtc") or note.value.startswith(b"cache:")
+    for dec, want in ((0, 4), (1, 3)):
+        kind = L.zpq_plan_kernel_kind2(plan2._h, dec, note, 4096)
+        assert kind == want, note.value
+        assert note.value.startswith(b"hiprtc") or note.value.startswith(b"cache:")
     # a header that certainly was not prebuilt (no build step knows this chain): must come out of hipRTC, and
-    # code correctly
+    # code correctly in both directions
     h3, _, _ = gpu.method_to_header("x0,0ci2,1,1c0,3m16s")
     plan3 = gpu.Plan(h3)
-    assert L.zpq_plan_kernel_kind(plan3._h, note, 4096) == 3, note.value
+    assert L.zpq_plan_kernel_kind(plan3._h, note, 4096) == 4, note.value
+    assert note.value.startswith(b"hiprtc"), note.value
+    assert L.zpq_plan_kernel_kind2(plan3._h, 1, note, 4096) == 3, note.value
     assert note.value.startswith(b"hiprtc"), note.value
     d3 = b"\0" + corpus.block("text", 50000, 4242).tobytes()
-    assert gpu.encode_batch([plan3], [d3])[0] == oracle.encode(h3, d3)
+    c3 = gpu.encode_batch([plan3], [d3])[0]
+    assert c3 == oracle.encode(h3, d3)
+    (back, used), = gpu.decode_batch([plan3], [c3 + b"\0\0\0\0"], [len(d3) + 8])
+    assert back == d3 and used == len(c3) + 4
 
 
 def test_decoder_status_codes(gpu, golden):

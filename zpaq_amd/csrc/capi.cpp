@@ -7,6 +7,7 @@
 #include "device/engine.hpp"
 #include "device/plan.hpp"
 #include "device/spec_loader.hpp"
+#include "host/codegen.hpp"
 #include "host/common.hpp"
 #include "host/blocks.hpp"
 #include "host/container.hpp"
@@ -34,7 +35,7 @@ int zpq_init(int device) { ZPQ_TRY engine_init(device); return ZPQ_OK; ZPQ_CATCH
 int zpq_device_count(void) { return engine_device_count(); }
 void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
 int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
-int zpq_set_kernel(int which) { if (which < 0 || which > 3) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
+int zpq_set_kernel(int which) { if (which < 0 || which > 4) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
 
 int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out) {
   ZPQ_TRY
@@ -63,10 +64,12 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   ZPQ_CATCH
 }
 
-int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) {
+int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) { return zpq_plan_kernel_kind2(p, 0, note, cap); }
+
+int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) {
   try {
     std::string n;
-    const int k = engine_plan_kernel_kind(p, n);
+    const int k = engine_plan_kernel_kind(p, n, decode != 0);
     if (note && cap) { strncpy(note, n.c_str(), cap - 1); note[cap - 1] = 0; }
     return k;
   } catch (const Failure& f) { set_last_error(f.what()); return -f.code; }
@@ -88,6 +91,33 @@ size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
 const uint8_t* zpq_plan_blob(const zpq_plan* p, size_t* len) {
   if (len) *len = p ? p->blob.size() : 0;
   return p ? p->blob.data() : nullptr;
+}
+
+int zpq_plan_pipe_source(const zpq_plan* p, char* src, size_t cap, size_t* len, char key41[41]) {
+  ZPQ_TRY
+  if (!p) fail(ZPQ_E_ARG, "null plan");
+  std::string source, key, why;
+  if (!pipe_source_and_key(*p, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (len) *len = source.size();
+  if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
+  if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
+  memcpy(src, source.c_str(), source.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_plan_pipe_layout(const zpq_plan* p, uint64_t out[16]) {
+  ZPQ_TRY
+  if (!p || !out) fail(ZPQ_E_ARG, "null argument");
+  PipeLayout L;
+  std::string why;
+  if (!pipe_layout(*p, L, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  memset(out, 0, 16 * sizeof(uint64_t));
+  out[0] = L.group_bytes; out[1] = (uint64_t)L.S; out[2] = (uint64_t)L.C; out[3] = L.light.size();
+  out[4] = L.icm.size(); out[5] = L.isse.size(); out[6] = (uint64_t)L.mix_waves_per_group();
+  out[7] = (uint64_t)L.hcomp_lanes; out[8] = (uint64_t)L.coder_level; out[9] = (uint64_t)L.G; out[10] = L.rows.size();
+  return ZPQ_OK;
+  ZPQ_CATCH
 }
 
 const char* zpq_spec_cache_dir(void) { static std::string s; s = spec_cache_dir(); return s.c_str(); }
@@ -272,6 +302,8 @@ size_t zpq_table(int which, void* out, size_t cap) {
       case 5: src = t.icm_init; n = sizeof(t.icm_init); break;
       case 6: src = t.isse_init; n = sizeof(t.isse_init); break;
       case 7: src = t.sse_row; n = sizeof(t.sse_row); break;
+      case 8: src = t.stretch_cb; n = sizeof(t.stretch_cb); break;
+      case 9: src = t.stretch_top; n = sizeof(t.stretch_top); break;
       default: return 0;
     }
     if (n > cap) return 0;

@@ -6,9 +6,12 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 
+#include "../host/codegen.hpp"
 #include "kernels.h"
 #include "spec_loader.hpp"
 
@@ -38,6 +41,18 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// hipEvent_t that cannot leak when a HIP_CHECK throws between create and destroy
+struct Event {
+  hipEvent_t ev = nullptr;
+  explicit Event(bool timing = false) {
+    HIP_CHECK(hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming));
+  }
+  ~Event() { if (ev) (void)hipEventDestroy(ev); }
+  Event(const Event&) = delete;
+  Event& operator=(const Event&) = delete;
+  operator hipEvent_t() const { return ev; }
+};
+
 struct Engine {
   std::mutex mu;
   bool ready = false;
@@ -47,11 +62,14 @@ struct Engine {
   uint64_t budget = 0;
   int kernel_choice = 0;
   DevBuf arena, io_in, io_out, jobs, results;
+  DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
+  hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
   int last_kind = 0;
   int jit_left = 0;                    // hipRTC compilations still allowed in the current call
   int cus = 256;                       // compute units of the device
+  hipEvent_t busy = nullptr;           // recorded after the last launch of a call that returned with work in flight
 };
 
 Engine& eng() {
@@ -101,6 +119,8 @@ void engine_init_locked(int device) {
   memcpy(host_tb.icm_init, t.icm_init, sizeof(host_tb.icm_init));
   memcpy(host_tb.isse_init, t.isse_init, sizeof(host_tb.isse_init));
   memcpy(host_tb.sse_row, t.sse_row, sizeof(host_tb.sse_row));
+  memcpy(host_tb.stretch_cb, t.stretch_cb, sizeof(host_tb.stretch_cb));
+  memcpy(host_tb.stretch_top, t.stretch_top, sizeof(host_tb.stretch_top));
   if (!e.d_tables) HIP_CHECK(hipMalloc((void**)&e.d_tables, sizeof(DeviceTables)));
   HIP_CHECK(hipMemcpy(e.d_tables, &host_tb, sizeof(DeviceTables), hipMemcpyHostToDevice));
   size_t free_b = 0, total_b = 0;
@@ -127,7 +147,9 @@ void engine_shutdown() {
   if (!e.ready) return;
   (void)hipSetDevice(e.device);
   (void)hipStreamSynchronize(e.stream);
-  e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release();
+  e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release();
+  for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
+  if (e.busy) { (void)hipEventDestroy(e.busy); e.busy = nullptr; }
   if (e.d_tables) (void)hipFree(e.d_tables);
   e.d_tables = nullptr;
   if (e.stream) (void)hipStreamDestroy(e.stream);
@@ -155,25 +177,35 @@ void engine_plan_release(zpq_plan* p) {
   spec_kernel_release(p);
 }
 
-// Which kernel codes a plan: 3 = per-header specialised kernel, 2 = generic
-// wave kernel, 1 = generic one-lane kernel.  kernel_choice 0 picks the best
-// available; 1/2/3 force one (3 fails loudly if specialisation is unavailable).
+// Which kernel codes a plan: 4 = pipelined encoder (compression only, device/pipe_kernel.h), 3 = per-header
+// specialised wavefront kernel, 2 = generic wave kernel, 1 = generic one-lane kernel.  kernel_choice 0 picks the
+// best available; 1..4 force one (3 / 4 fail loudly if the kernel is unavailable; 4 still decodes with 3).
 // `dense` = the launch holds more blocks than one wavefront per SIMD can take (4 x CUs): then the
 // 8-blocks-per-workgroup shape (two wavefronts per SIMD, half the side tables in LDS) has the higher
 // throughput; below that the 4-block shape (everything in LDS, one workgroup per CU) is faster.
-static int kernel_kind(Engine& e, const zpq_plan* plan, bool dense, SpecKernel** spec_out = nullptr) {
+struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe = nullptr; };
+
+static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
-  if (spec_out) *spec_out = nullptr;
+  KernelPick r;
   const int want = e.kernel_choice;
-  if (want == 1) return 1;
+  if (want == 1) { r.kind = 1; return r; }
   if (!plan->hdr().wave_ok) {
     if (want >= 2) fail(ZPQ_E_UNSUPPORTED, "wave kernels need n <= 64 components");
-    return 1;
+    r.kind = 1;
+    return r;
   }
-  if (want == 2) return 2;
-  // Each unseen header costs a ~2-4 s hipRTC compile.  A batch whose blocks all carry different
+  if (want == 2) { r.kind = 2; return r; }
+  // Each unseen header costs a hipRTC compile of several seconds.  A batch whose blocks all carry different
   // (data-dependent) chains must not spend minutes compiling: a few per call, the rest run on the
   // generic wave kernel this time and are picked up by later calls.
+  if (!decode && (want == 0 || want == 4)) {
+    bool did = false;
+    PipeKernel* k = pipe_kernel_for(p, want == 4 || e.jit_left > 0, &did);
+    if (did && e.jit_left > 0) --e.jit_left;
+    if (k) { r.kind = 4; r.pipe = k; return r; }
+    if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->pipe_note);
+  }
   const int forced = spec_variant_forced();
   const int first = forced >= 0 ? forced : (dense ? 1 : 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -181,26 +213,48 @@ static int kernel_kind(Engine& e, const zpq_plan* plan, bool dense, SpecKernel**
     const int variant = attempt == 0 ? first : 1 - first;
     if (attempt == 1 && p->spec_state[variant] <= 0) break;                     // fall back only to a shape already loaded
     bool did = false;
-    SpecKernel* k = spec_kernel_for(p, variant, want == 3 || e.jit_left > 0, nullptr, &did);
+    SpecKernel* k = spec_kernel_for(p, variant, want >= 3 || e.jit_left > 0, nullptr, &did);
     if (did && e.jit_left > 0) --e.jit_left;
-    if (k) { if (spec_out) *spec_out = k; return 3; }
+    if (k) { r.kind = 3; r.spec = k; return r; }
   }
-  if (want == 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
-  return 2;
+  if (want >= 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
+  r.kind = 2;
+  return r;
 }
 
-int engine_plan_kernel_kind(zpq_plan* p, std::string& note) {
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
   e.jit_left = jit_budget();
-  const int k = kernel_kind(e, p, false);
-  note = p->spec_note;
-  return k;
+  const KernelPick k = kernel_kind(e, p, false, decode);
+  note = k.kind == 4 ? p->pipe_note : p->spec_note;
+  return k.kind;
 }
 
-struct LaunchGroup { int kind; SpecKernel* spec; uint32_t first, count; };
+// One launch group = consecutive jobs coded by the same kernel (and, for the per-header kernels, the same plan).
+struct LaunchGroup {
+  KernelPick pick;
+  const zpq_plan* plan;
+  uint32_t first, count;
+  uint32_t max_len;          // longest input of the group (the pipelined encoder's step count)
+};
+
+static bool same_group(const LaunchGroup& g, const KernelPick& k, const zpq_plan* plan) {
+  if (g.pick.kind != k.kind) return false;
+  if (k.kind == 4) return g.pick.pipe == k.pipe && g.plan == plan;
+  if (k.kind == 3) return g.pick.spec == k.spec;
+  return true;
+}
+
+// bytes of stream buffer the pipelined encoder needs for `count` blocks of `plan`
+static uint64_t pipe_bytes(const zpq_plan* plan, uint32_t count) {
+  PipeLayout L;
+  std::string why;
+  if (!pipe_layout(*plan, L, why)) return 0;
+  return (uint64_t)((count + (uint32_t)L.G - 1) / (uint32_t)L.G) * L.group_bytes;
+}
 
 static hipError_t launch_spec(SpecKernel* k, bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t n,
                               const DeviceTables* d_tb, hipStream_t st) {
@@ -209,62 +263,214 @@ static hipError_t launch_spec(SpecKernel* k, bool decode, const BlockJob* d_jobs
   return hipModuleLaunchKernel(decode ? k->decode : k->encode, (n + w - 1) / w, 1, 1, 64 * w, 1, 1, 0, st, args, nullptr);
 }
 
+// The pipelined encoder: every step launches the six kernels of every pipe group on six streams (they are
+// independent inside a step; they are separate kernels only because their static LDS needs differ), then joins the streams -- the step boundary is the only producer/consumer barrier.
+struct PipeRun {
+  PipeKernel* k;
+  PipeArgs args;
+  uint32_t grid[6];
+  uint32_t nsteps;
+  uint32_t ngroups;
+  uint32_t threads;          // lanes per workgroup of every kernel but hcomp (= blocks per group)
+};
+
+// ZPAQ_AMD_PIPE_PROFILE=1: run every unit type of every step alone on one stream between two events and print the
+// average time of each (stderr).  A measuring aid: the step's real duration is the slowest unit, not the sum.
+static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
+  struct Rec { int kernel; uint32_t role; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  for (auto& r : runs) {
+    for (uint32_t step = 0; step < r.nsteps; ++step) {
+      r.args.step = (int32_t)step;
+      for (int k = 0; k < 6; ++k) {
+        if (!r.grid[k]) continue;
+        const uint32_t per = k == 0 ? r.grid[0] : r.ngroups;      // workgroups of one unit type
+        for (uint32_t w0 = 0; w0 < r.grid[k]; w0 += per) {
+          r.args.wg0 = w0;
+          void* args[1] = {(void*)&r.args};
+          Rec rec{k, w0 / per, nullptr, nullptr};
+          HIP_CHECK(hipEventCreate(&rec.a));
+          HIP_CHECK(hipEventCreate(&rec.b));
+          HIP_CHECK(hipEventRecord(rec.a, st));
+          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : r.threads, 1, 1, 0, st, args, nullptr));
+          HIP_CHECK(hipEventRecord(rec.b, st));
+          recs.push_back(rec);
+        }
+      }
+      r.args.wg0 = 0;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  static const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
+  std::map<std::pair<int, uint32_t>, std::pair<double, int>> acc;
+  for (auto& rec : recs) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, rec.a, rec.b);
+    auto& x = acc[{rec.kernel, rec.role}];
+    x.first += ms; x.second += 1;
+    (void)hipEventDestroy(rec.a); (void)hipEventDestroy(rec.b);
+  }
+  for (auto& kv : acc)
+    fprintf(stderr, "[zpq pipe profile] %-5s unit %2u: %8.3f ms per step (%d launches)\n", names[kv.first.first], kv.first.second,
+            kv.second.first / kv.second.second, kv.second.second);
+}
+
+static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
+  if (runs.empty()) return;
+  if (getenv("ZPAQ_AMD_PIPE_PROFILE")) { launch_pipe_profiled(e, runs, st); return; }
+  for (auto& ps : e.pstream)
+    if (!ps) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  uint32_t nsteps = 0;
+  for (auto& r : runs) nsteps = std::max(nsteps, r.nsteps);
+  Event fork, join;
+  Event done[6];
+  HIP_CHECK(hipEventRecord(fork, st));
+  for (int k = 0; k < 6; ++k) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], fork, 0));
+  for (uint32_t step = 0; step < nsteps; ++step) {
+    for (auto& r : runs) {
+      if (step >= r.nsteps) continue;
+      r.args.step = (int32_t)step;
+      void* args[1] = {(void*)&r.args};
+      for (int k = 0; k < 6; ++k)
+        if (r.grid[k])
+          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : r.threads, 1, 1, 0, e.pstream[k], args, nullptr));
+    }
+    // join: stream 0 waits for 1..4, then 1..4 wait for stream 0
+    for (int k = 1; k < 6; ++k) {
+      HIP_CHECK(hipEventRecord(done[k], e.pstream[k]));
+      HIP_CHECK(hipStreamWaitEvent(e.pstream[0], done[k], 0));
+    }
+    HIP_CHECK(hipEventRecord(join, e.pstream[0]));
+    if (step + 1 < nsteps)
+      for (int k = 1; k < 6; ++k) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], join, 0));
+  }
+  HIP_CHECK(hipStreamWaitEvent(st, join, 0));
+}
+
 // Launch init + coding kernels for jobs already resident on the device, grouped
-// so that each group is one launch.
+// so that each group is one launch (or one launch sequence).
 static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res,
                        const std::vector<LaunchGroup>& groups, uint32_t nb, uint64_t max_arena, hipStream_t st,
                        bool timed) {
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (timed) for (auto& x : ev) HIP_CHECK(hipEventCreate(&x));
+  Event ev0(true), ev1(true), ev2(true), ev3(true);
   // enough 256-thread groups per block to stream the arena at HBM rate
   uint64_t per = max_arena / (256 * 16 * 8) + 1;
   uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), 64);
   if ((uint64_t)chunks * nb > 16384) chunks = (uint32_t)std::max<uint64_t>(1, 16384 / nb);
-  if (timed) HIP_CHECK(hipEventRecord(ev[0], st));
-  HIP_CHECK(launch_init_arena(d_jobs, nb, e.d_tables, chunks, st));
-  if (timed) HIP_CHECK(hipEventRecord(ev[1], st));
-  if (timed) HIP_CHECK(hipEventRecord(ev[2], st));
-  // Groups (one per kernel kind / plan) are independent: fan them out over side streams so a
+  if (timed) HIP_CHECK(hipEventRecord(ev0, st));
+  for (uint32_t b0 = 0; b0 < nb; b0 += 65535u)        // gridDim.y carries the block index
+    HIP_CHECK(launch_init_arena(d_jobs + b0, std::min(nb - b0, 65535u), e.d_tables, chunks, st));
+  if (timed) HIP_CHECK(hipEventRecord(ev1, st));
+  if (timed) HIP_CHECK(hipEventRecord(ev2, st));
+  // stream buffers of the pipe groups
+  std::vector<PipeRun> runs;
+  uint64_t pipe_need = 0;
+  for (const LaunchGroup& g : groups)
+    if (g.pick.kind == 4) pipe_need += pipe_bytes(g.plan, g.count);
+  if (pipe_need) e.pipe.ensure(pipe_need);
+  uint64_t pipe_off = 0;
+  for (const LaunchGroup& g : groups) {
+    if (g.pick.kind != 4) continue;
+    PipeLayout L;
+    std::string why;
+    if (!pipe_layout(*g.plan, L, why)) fail(ZPQ_E_DEVICE, "pipe layout vanished: " + why);
+    PipeRun r;
+    r.k = g.pick.pipe;
+    r.args = PipeArgs{d_jobs + g.first, d_res, g.count, e.d_tables, (uint8_t*)e.pipe.p + pipe_off, 0, 0u};
+    const uint32_t ng = (g.count + (uint32_t)L.G - 1) / (uint32_t)L.G;
+    r.ngroups = ng;
+    r.threads = (uint32_t)L.G;
+    r.grid[0] = (g.count + (uint32_t)L.hcomp_lanes - 1) / (uint32_t)L.hcomp_lanes;
+    r.grid[1] = (uint32_t)L.rows.size() * ng;
+    r.grid[2] = (uint32_t)L.light.size() * ng;
+    r.grid[3] = (uint32_t)L.icm.size() * ng;
+    r.grid[4] = (uint32_t)L.isse.size() * ng;
+    r.grid[5] = (uint32_t)L.mix_waves_per_group() * ng;
+    const uint32_t nchunks = g.max_len ? (g.max_len + (uint32_t)L.C - 1) / (uint32_t)L.C : 1u;
+    r.nsteps = nchunks + (uint32_t)L.coder_level;
+    pipe_off += (uint64_t)ng * L.group_bytes;
+    runs.push_back(r);
+  }
+  // Groups (one per kernel kind / plan) are independent: fan the single-launch ones out over side streams so a
   // batch mixing several chains does not serialise one launch after the other.
-  const size_t nside = groups.size() > 1 ? std::min<size_t>(groups.size() - 1, 7) : 0;
+  size_t nsingle = 0;
+  for (const LaunchGroup& g : groups) nsingle += g.pick.kind != 4;
+  const size_t nside = nsingle > 1 ? std::min<size_t>(nsingle - 1, 7) : 0;
   while (e.side.size() < nside) {
     hipStream_t s2;
     HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     e.side.push_back(s2);
   }
-  hipEvent_t fork = nullptr;
-  if (nside) {
-    HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(fork, st));
-  }
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    const LaunchGroup& g = groups[gi];
+  Event fork;
+  if (nside) HIP_CHECK(hipEventRecord(fork, st));
+  size_t gi = 0;
+  for (const LaunchGroup& g : groups) {
+    if (g.pick.kind == 4) continue;
     hipStream_t gs = (nside && gi % (nside + 1)) ? e.side[gi % (nside + 1) - 1] : st;
     if (gs != st && gi <= nside) HIP_CHECK(hipStreamWaitEvent(gs, fork, 0));
     // every kernel writes res[job.res_slot] relative to the SAME results base
-    if (g.kind == 3) HIP_CHECK(launch_spec(g.spec, decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
-    else if (g.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
+    if (g.pick.kind == 3) HIP_CHECK(launch_spec(g.pick.spec, decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
+    else if (g.pick.kind == 2) HIP_CHECK(launch_code_wave(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
     else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
+    ++gi;
   }
+  launch_pipe(e, runs, st);
   for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
-    hipEvent_t done;
-    HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    Event done;
     HIP_CHECK(hipEventRecord(done, e.side[k]));
     HIP_CHECK(hipStreamWaitEvent(st, done, 0));
-    HIP_CHECK(hipEventDestroy(done));
   }
-  if (fork) HIP_CHECK(hipEventDestroy(fork));
   if (timed) {
-    HIP_CHECK(hipEventRecord(ev[3], st));
-    HIP_CHECK(hipEventSynchronize(ev[3]));
+    HIP_CHECK(hipEventRecord(ev3, st));
+    HIP_CHECK(hipEventSynchronize(ev3));
     float a = 0, b = 0;
-    HIP_CHECK(hipEventElapsedTime(&a, ev[0], ev[1]));
-    HIP_CHECK(hipEventElapsedTime(&b, ev[2], ev[3]));
+    HIP_CHECK(hipEventElapsedTime(&a, ev0, ev1));
+    HIP_CHECK(hipEventElapsedTime(&b, ev2, ev3));
     e.last.init_ms = a;
     e.last.code_ms = b;
     e.last.blocks = nb;
-    for (auto& x : ev) (void)hipEventDestroy(x);
   }
+}
+
+// The engine's arena / job / stream buffers are shared by all calls: a call that returned with work still in flight
+// on the caller's stream (zpq_*_device with timed = 0) must have drained before they are touched again.
+static void wait_in_flight(Engine& e) {
+  if (e.busy) {
+    HIP_CHECK(hipEventSynchronize(e.busy));
+  }
+}
+static void mark_in_flight(Engine& e, hipStream_t st) {
+  if (!e.busy) HIP_CHECK(hipEventCreateWithFlags(&e.busy, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(e.busy, st));
+}
+
+// Sort `order` so that every (kernel, plan) group is contiguous, and cut it into launch groups.
+template <class PlanOf, class LenOf>
+static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
+  const size_t cnt = order.size();
+  const bool dense = cnt > (size_t)4 * e.cus;
+  std::vector<KernelPick> pick(cnt);
+  for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode);
+  std::vector<uint32_t> idx(cnt);
+  for (size_t k = 0; k < cnt; ++k) idx[k] = (uint32_t)k;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+    if (pick[x].kind != pick[y].kind) return pick[x].kind > pick[y].kind;
+    if (pick[x].kind >= 3) return plan_of(order[x]) < plan_of(order[y]);
+    return false;
+  });
+  std::vector<uint32_t> sorted(cnt);
+  std::vector<LaunchGroup> groups;
+  for (size_t k = 0; k < cnt; ++k) {
+    const uint32_t b = order[idx[k]];
+    sorted[k] = b;
+    const KernelPick& pk = pick[idx[k]];
+    if (!groups.empty() && same_group(groups.back(), pk, plan_of(b))) {
+      ++groups.back().count;
+      groups.back().max_len = std::max(groups.back().max_len, len_of(b));
+    } else groups.push_back(LaunchGroup{pk, plan_of(b), (uint32_t)k, 1, len_of(b)});
+  }
+  order.swap(sorted);
+  return groups;
 }
 
 void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
@@ -272,54 +478,41 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
+  wait_in_flight(e);
   const size_t nb = blocks.size();
   e.jit_left = jit_budget();
   results.assign(nb, BlockResult{0, 0, 0, 0});
   size_t pos = 0;
   e.last = Timing{};
   while (pos < nb) {
-    // one residency wave: as many blocks as fit the state budget
+    // one residency wave: as many blocks as fit the state budget (model state + the encoder's stream buffers)
     uint64_t need = 0, in_bytes = 0, out_bytes = 0, max_arena = 0;
     size_t end = pos;
     while (end < nb) {
       const HostBlock& hb = blocks[end];
       uint64_t a = hb.plan->hdr().arena_bytes;
+      if (!decode && e.kernel_choice != 1 && e.kernel_choice != 2 && e.kernel_choice != 3) a += pipe_bytes(hb.plan, 64) / 64;   // share of a full group
       if (end > pos && need + a > e.budget) break;
       need += a;
-      max_arena = std::max(max_arena, a);
+      max_arena = std::max(max_arena, hb.plan->hdr().arena_bytes);
       in_bytes += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
       out_bytes += ((uint64_t)hb.out_cap + 63) & ~63ull;
       ++end;
     }
     if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: one block's model state exceeds the device budget");
     const size_t cnt = end - pos;
-    e.arena.ensure(need);
+    uint64_t arena_need = 0;
+    for (size_t i = pos; i < end; ++i) arena_need += blocks[i].plan->hdr().arena_bytes;
+    e.arena.ensure(arena_need);
     e.io_in.ensure(in_bytes + 64);
     e.io_out.ensure(out_bytes + 64);
     e.jobs.ensure(cnt * sizeof(BlockJob));
     e.results.ensure(cnt * sizeof(BlockResult));
-    // order jobs so that every (kernel kind, plan) group is one contiguous launch
-    std::vector<size_t> order;
-    order.reserve(cnt);
-    for (size_t i = pos; i < end; ++i) order.push_back(i);
-    std::vector<int> kind_of(nb, 0);
-    std::vector<SpecKernel*> spec_of(nb, nullptr);
-    const bool dense = cnt > (size_t)4 * e.cus;
-    for (size_t i = pos; i < end; ++i) kind_of[i] = kernel_kind(e, blocks[i].plan, dense, &spec_of[i]);
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-      if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
-      if (kind_of[x] == 3) return blocks[x].plan < blocks[y].plan;
-      return false;
-    });
-    std::vector<LaunchGroup> groups;
-    for (size_t k = 0; k < cnt; ++k) {
-      const zpq_plan* pl = blocks[order[k]].plan;
-      const int kd = kind_of[order[k]];
-      SpecKernel* sk = spec_of[order[k]];
-      (void)pl;
-      if (!groups.empty() && groups.back().kind == kd && groups.back().spec == sk) ++groups.back().count;
-      else groups.push_back(LaunchGroup{kd, sk, (uint32_t)k, 1});
-    }
+    std::vector<uint32_t> order(cnt);
+    for (size_t i = 0; i < cnt; ++i) order[i] = (uint32_t)(pos + i);
+    std::vector<LaunchGroup> groups = make_groups(
+        e, decode, order, [&](uint32_t b) { return blocks[b].plan; },
+        [&](uint32_t b) { return blocks[b].in_len + blocks[b].prefix_len; });
     std::vector<BlockJob> jobs(cnt);
     std::vector<uint8_t> stage(in_bytes + 64);
     std::vector<uint64_t> out_off(cnt);
@@ -345,6 +538,7 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
     HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
     Timing before = e.last;
+    e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
                e.stream, true);
     e.last.init_ms += before.init_ms;
@@ -372,6 +566,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   HIP_CHECK(hipSetDevice(e.device));
+  wait_in_flight(e);
   hipStream_t st = stream ? (hipStream_t)stream : e.stream;
   e.jit_left = jit_budget();
   auto plan_of = [&](uint32_t b) { return one_plan ? plans[0] : plans[b]; };
@@ -381,22 +576,17 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
     need += a;
     max_arena = std::max(max_arena, a);
   }
-  if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
+  // group blocks by (kernel, plan); results keep the caller's block order through res_slot
+  std::vector<uint32_t> order(nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) order[b] = b;
+  std::vector<LaunchGroup> groups = make_groups(e, decode, order, plan_of, [&](uint32_t b) { return in_len[b]; });
+  uint64_t pipe_need = 0;
+  for (const LaunchGroup& gr : groups)
+    if (gr.pick.kind == 4) pipe_need += pipe_bytes(gr.plan, gr.count);
+  if (need + pipe_need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
   e.arena.ensure(need);
   e.jobs.ensure((size_t)nblocks * sizeof(BlockJob));
-  // group blocks by (kernel kind, plan); results keep the caller's block order through res_slot
-  std::vector<uint32_t> order(nblocks);
-  std::vector<int> kind_of(nblocks);
-  std::vector<SpecKernel*> spec_of(nblocks, nullptr);
-  const bool dense = nblocks > 4u * (uint32_t)e.cus;
-  for (uint32_t b = 0; b < nblocks; ++b) { order[b] = b; kind_of[b] = kernel_kind(e, plan_of(b), dense, &spec_of[b]); }
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-    if (kind_of[x] != kind_of[y]) return kind_of[x] > kind_of[y];
-    if (kind_of[x] == 3) return plan_of(x) < plan_of(y);
-    return false;
-  });
   std::vector<BlockJob> jobs(nblocks);
-  std::vector<LaunchGroup> groups;
   uint64_t a_off = 0;
   for (uint32_t k = 0; k < nblocks; ++k) {
     const uint32_t b = order[k];
@@ -411,15 +601,13 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
     j.out_cap = out_cap[b];
     j.res_slot = b;
     a_off += pl->hdr().arena_bytes;
-    SpecKernel* sk = spec_of[b];
-    if (!groups.empty() && groups.back().kind == kind_of[b] && groups.back().spec == sk) ++groups.back().count;
-    else groups.push_back(LaunchGroup{kind_of[b], sk, k, 1});
   }
   HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), (size_t)nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));   // jobs vector goes out of scope below
   e.last = Timing{};
-  e.last_kind = groups.empty() ? 0 : groups[0].kind;
+  e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
   launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed);
+  if (!timed) mark_in_flight(e, st);
 }
 
 int engine_selftest(int32_t out[8]) {

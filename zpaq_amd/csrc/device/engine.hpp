@@ -31,8 +31,8 @@ void engine_set_budget(uint64_t bytes);
 void engine_set_kernel(int which);
 Timing engine_last_timing();
 void engine_plan_release(zpq_plan* p);
-// 3 specialised / 2 generic wave / 1 generic one-lane; note = origin of the specialised kernel or why not
-int engine_plan_kernel_kind(zpq_plan* p, std::string& note);
+// 4 pipelined encoder (compression only) / 3 specialised / 2 generic wave / 1 generic one-lane; note = origin of the specialised kernel or why not
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false);
 
 // Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.
 void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);

@@ -102,6 +102,19 @@ struct DeviceTables {
   uint32_t icm_init[256];
   uint32_t isse_init[512];
   uint32_t sse_row[32];
+  uint32_t stretch_cb[2016];   // compact stretch (host/common.hpp Tables)
+  int16_t stretch_top[256];
+};
+
+// Argument block of the pipelined encoder's kernels (device/pipe_kernel.h), passed by value.
+struct PipeArgs {
+  const BlockJob* jobs;     // the blocks of one plan, consecutive; 64 consecutive blocks form a group
+  BlockResult* res;
+  uint32_t nblocks;
+  const DeviceTables* tb;
+  uint8_t* pipe;            // stream + state buffer, PIPE_GROUP_BYTES per group
+  int32_t step;             // a unit of dataflow level L works on chunk step - L
+  uint32_t wg0;             // added to blockIdx.x: lets a launch cover a sub-range of a kernel's units
 };
 
 // LDS plan of the specialised kernel (spec_kernel.h), known to the host code

@@ -1,0 +1,897 @@
+// Pipelined ENCODER: the kernel templates a GENERATED translation unit instantiates for ONE block header
+// (host/codegen.cpp, generate_pipe_source).  Replaces Encoder::compress + Predictor::predict0/update0 +
+// ZPAQL::run (libzpaq.cpp:2419-2447, 1854-2066, 1027-1262) on the compression side only.
+//
+// Why a second design.  spec_kernel.h maps one ZPAQ block to one wavefront and walks the whole COMP chain once
+// per coded bit: ~400 dependent instructions, 23 of 64 lanes busy, 3.1 k cycles per bit, and every lever on that
+// design was measured out in round 2 (profiles/r02_ab_matrix.txt).  The decoder has to work that way -- it
+// learns each bit from the final probability.  The ENCODER does not: it knows every bit in advance, and
+// libzpaq's model is strictly feed-forward --
+//   * HCOMP contexts depend on input bytes only;
+//   * CM / ICM / MATCH train on (own table, y) only;
+//   * ISSE / AVG / MIX2 / MIX / SSE read predictions of EARLIER components and train on (own output, y);
+//   * nothing ever reads the final probability except the arithmetic coder.
+// So every component is an independent stream processor over the bit sequence, and the chain is a dataflow
+// graph.  Here each component of each block gets its own lane:
+//
+//     wave = 64 consecutive blocks x ONE component (lane = block)      [MIX: a few lanes per block]
+//
+// Lanes of a wave run identical code on different blocks (no divergence, no cross-lane traffic, all 64 lanes
+// busy), a lane's per-bit loop is 15-45 instructions instead of 400, and all table addresses of a byte are
+// known before its first bit (no speculation, one candidate instead of two).  Components talk through streams in
+// HBM, laid out [position][lane] so that every stream access of a wave is one contiguous 64 / 128 / 256-byte
+// transaction:
+//     ctx[slot][c][byte][lane]  u32      HCOMP's H[i] for the byte                       (producer: HCOMP unit)
+//     bh [slot][r][byte][lane]  2 x u32  the 8 bit histories of the byte's two nibbles   (producer: ROW unit of an ICM/ISSE)
+//     p  [slot][i][byte][lane]  8 x i16  stretch-domain predictions of component i       (producer: component i)
+// so one 4 / 8 / 16-byte access per lane and input byte moves a unit's whole input or output for that byte.
+// Time is cut into chunks of PIPE_C input bytes.  A unit of dataflow level L works on chunk (step - L) during
+// launch `step`; one launch = one step, the kernel boundary is the barrier between producers and consumers and
+// PIPE_S = maxlevel + 1 ring slots keep a chunk alive until its last consumer has run.  All units of a step are
+// independent, so the step's six kernels (they differ only in their static LDS needs) run concurrently.
+//
+//   unit          level                   per-lane state between chunks
+//   HCOMP         0                       VM registers (H, M, R live in the arena as before; H is staged in LDS)
+//   ROW(i)        1                       none  (bit-history row probed, used for 4 bits, written back per nibble)
+//   CONS/CM/MATCH 1                       MATCH: len/offset/pos/predicted byte
+//   ICM map       2                       side table, staged in LDS [entry][lane] during the chunk
+//   ISSE map      max(2, level(j)+1)      same (two words per entry)
+//   AVG/MIX2/SSE  max(inputs)+1           none
+//   MIX           max(inputs)+1           none; MIX_QL lanes per block, DPP reduction inside the lane group
+//   CODER         level(n-1)+1            low, high, bytes written
+//
+// A lane's loop is a serial chain, so what it waits for decides the speed.  Every unit therefore (a) fetches the
+// stream inputs of byte k+1 before it works on byte k (nothing it stores can alias them), (b) fetches all table
+// words of a byte together before the byte's first bit (legal when the byte's 8 addresses are distinct, a
+// compile-time property of the component), and (c) touches the table lines of byte k+1 one byte early so that
+// (b) finds them in L2.  The ROW unit loads the candidate rows of both nibbles up front and forwards the row the
+// first nibble rewrote; the ISSE/ICM maps read the next bit's LDS entry early and forward the entry just trained.
+//
+// Integer arithmetic is the reference's, statement for statement; the parity tests compare the
+// coded bytes with the oracle and with the reference.  The same source runs in tests/emu on the host.
+#pragma once
+#ifndef ZPQ_LANE_VM
+#define ZPQ_LANE_VM 1          // one HCOMP machine per lane: its condition flag is per-lane data
+#endif
+#include "spec_kernel.h"       // CompK, address-space typedefs, clamps, static_for
+
+namespace zpq {
+
+typedef __attribute__((address_space(1))) short g_i16;
+typedef __attribute__((address_space(1))) unsigned short g_u16;
+
+enum PipeKind : int { PK_ROW = 1, PK_CONS, PK_CM, PK_MATCH, PK_AVG, PK_MIX2, PK_SSE, PK_CODER };
+
+__device__ __forceinline__ bool pipe_any(bool x) {
+#ifdef ZPQ_EMU
+  return emu::wave_any(x);
+#else
+  return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#endif
+}
+
+typedef __attribute__((address_space(1))) uint2 g_u64v;
+
+// One lane's view of its block, its chunk and the group's streams.
+template <class Chain>
+struct PipeLane {
+  static constexpr int N = Chain::N, C = Chain::PIPE_C, S = Chain::PIPE_S;
+  static constexpr unsigned G = Chain::PIPE_G;     // blocks per group = active lanes of a wavefront
+  unsigned gl;              // lane index inside the group (= position in every stream row)
+  bool live;                // block exists
+  g_u8* arena;
+  const g_u8* in;
+  g_u8* out;
+  unsigned len, out_cap, rslot;
+  g_u8* gb;                 // group base in the pipe buffer
+  int chunk;                // chunk this unit works on in this step
+  unsigned slot;            // chunk % S
+  unsigned k0, nb;          // first input byte of the chunk, bytes of this lane in it
+
+  __device__ __forceinline__ void open(const PipeArgs& a, unsigned blk, int level) {
+    live = blk < a.nblocks;
+    const BlockJob job = a.jobs[live ? blk : 0];
+    arena = (g_u8*)job.arena;
+    in = (const g_u8*)job.in;
+    out = (g_u8*)job.out;
+    len = live ? job.in_len : 0u;
+    out_cap = job.out_cap;
+    rslot = job.res_slot;
+    gl = blk % G;
+    gb = (g_u8*)a.pipe + (unsigned long long)(blk / G) * Chain::PIPE_GROUP_BYTES;
+    chunk = a.step - level;
+    slot = chunk >= 0 ? (unsigned)chunk % (unsigned)S : 0u;
+    k0 = chunk >= 0 ? (unsigned)chunk * (unsigned)C : 0u;
+    nb = (chunk >= 0 && len > k0) ? min(len - k0, (unsigned)C) : 0u;
+  }
+  // streams (byte offsets fit 32 bits: a group's buffer is far below 4 GiB)
+  __device__ __forceinline__ g_u32& ctx(int ci, unsigned k) const {
+    return *(g_u32*)(gb + (unsigned)Chain::PIPE_OFF_CTX + ((((slot * Chain::PIPE_NCTX + ci) * C + k) * G + gl) << 2));
+  }
+  __device__ __forceinline__ g_u64v& bh(int ri, unsigned k) const {
+    return *(g_u64v*)(gb + (unsigned)Chain::PIPE_OFF_BH + ((((slot * Chain::PIPE_NROW + ri) * C + k) * G + gl) << 3));
+  }
+  __device__ __forceinline__ g_u128& p(int i, unsigned k) const {
+    return *(g_u128*)(gb + (unsigned)Chain::PIPE_OFF_P + ((((slot * N + i) * C + k) * G + gl) << 4));
+  }
+  __device__ __forceinline__ g_u32& state(int w) const {
+    return *(g_u32*)(gb + (unsigned)Chain::PIPE_OFF_STATE + (((unsigned)w * G + gl) << 2));
+  }
+  __device__ __forceinline__ g_u32& A32(unsigned off) const { return *(g_u32*)(arena + off); }
+  __device__ __forceinline__ g_u8& A8(unsigned off) const { return *(g_u8*)(arena + off); }
+  __device__ __forceinline__ g_u128& A128(unsigned off) const { return *(g_u128*)(arena + off); }
+  __device__ __forceinline__ unsigned byte_at(unsigned k) const { return in[k0 + k]; }
+  __device__ __forceinline__ unsigned next(unsigned k) const { return min(k + 1u, nb - 1u); }   // index to prefetch
+};
+
+// 8 predictions of a byte in one 16-byte stream element: bit B in half-word B
+__device__ __forceinline__ int pipe_p_get(const uint4& v, int B) {
+  const unsigned w = B < 2 ? v.x : (B < 4 ? v.y : (B < 6 ? v.z : v.w));
+  return (int)(short)(unsigned short)(w >> (16 * (B & 1)));
+}
+struct PipeP8 {
+  unsigned w[4] = {0, 0, 0, 0};
+  __device__ __forceinline__ void set(int B, int v) { w[B >> 1] |= ((unsigned)v & 0xFFFFu) << (16 * (B & 1)); }
+  __device__ __forceinline__ uint4 get() const { return make_uint4(w[0], w[1], w[2], w[3]); }
+};
+
+// position-in-byte helpers: everything below is a pure function of the input byte (the encoder knows it)
+__device__ __forceinline__ int pipe_y(unsigned byte, int B) { return (int)((byte >> (7 - B)) & 1u); }
+__device__ __forceinline__ unsigned pipe_c8(unsigned byte, int B) { return (1u << B) | (byte >> (8 - B)); }     // libzpaq.cpp:2055
+__device__ __forceinline__ unsigned pipe_hmap4(unsigned byte, int B) {                                          // libzpaq.cpp:2057-2065
+  const unsigned hi = byte >> 4, lo = byte & 15u;
+  return B < 4 ? ((1u << B) | (hi >> (4 - B))) : (256u + 16u * hi + ((1u << (B - 4)) | (lo >> (8 - B))));
+}
+
+// stretch from 8.5 KB of LDS: groups of 8 as (value at the group's start | seven 1-bit increments << 16) for
+// x in [16384, 32512), the steep top end direct, the lower half by stretch(x) = -stretch(32767 - x)
+struct PipeStretch {
+  unsigned cb[2016];
+  short top[256];
+  __device__ __forceinline__ void load(const DeviceTables* tb, int lane) {
+    for (int i = lane; i < 2016; i += (int)blockDim.x) cb[i] = tb->stretch_cb[i];
+    for (int i = lane; i < 256; i += (int)blockDim.x) top[i] = tb->stretch_top[i];
+  }
+  __device__ __forceinline__ int operator()(unsigned x) const {   // x in 0..32767
+    const bool lo = x < 16384u;
+    const unsigned y = lo ? 32767u - x : x;
+    const unsigned e = cb[min((y - 16384u) >> 3, 2015u)];
+    const int mid = (int)(short)(unsigned short)e + __builtin_popcount((e >> 16) & ((1u << (y & 7u)) - 1u));
+    const int hi = top[y >= 32512u ? y - 32512u : 0u];
+    const int v = y >= 32512u ? hi : mid;
+    return lo ? -v : v;
+  }
+};
+
+// squash through the 1344 non-trivial entries held in LDS
+struct PipeSquash {
+  unsigned short mid[1344];
+  __device__ __forceinline__ void load(const DeviceTables* tb, int lane) {
+    for (int i = lane; i < 1344; i += (int)blockDim.x) mid[i] = tb->squash[1376 + i];
+  }
+  __device__ __forceinline__ int operator()(int p) const {   // p in -2048..2047
+    const int i = p + 2048 - 1376;
+    const int v = mid[min(max(i, 0), 1343)];
+    return i < 0 ? 0 : (i > 1343 ? 32767 : v);
+  }
+};
+
+// Predictor::train (libzpaq.h:1151-1157)
+__device__ __forceinline__ unsigned pipe_train(unsigned v, int y, unsigned dtv, unsigned limit) {
+  const unsigned count = v & 0x3ffu;
+  const int err = y * 32767 - (int)(v >> 17);
+  return v + ((unsigned)__mul24(err, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+}
+
+// =====================================================================================================
+// HCOMP unit: HL lanes per workgroup, H staged in LDS as [index][lane] when it fits.
+template <class Chain>
+struct PipeHLds {
+  unsigned* base;
+  int lane;
+  __device__ __forceinline__ unsigned& operator[](unsigned i) const { return base[i * Chain::HCOMP_LANES + lane]; }
+};
+
+template <class Chain>
+__device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
+  constexpr int HL = Chain::HCOMP_LANES;
+  constexpr bool HLDS = Chain::HCOMP_H_LDS;
+  constexpr unsigned HW = Chain::HMASK + 1u;
+  __shared__ unsigned Hs[HLDS ? HW * HL : 1];
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane < HL;
+  PipeLane<Chain> L;
+  L.open(a, (blockIdx.x + a.wg0) * HL + (mine ? lane : 0), 0);
+  if (!mine) { L.live = false; L.nb = 0; }
+  if (L.live && L.chunk == 0) L.state(Chain::HCOMP_STATE + 4) = 0u;      // status word, read by the coder at the end
+  unsigned st = L.live && L.chunk > 0 ? (unsigned)L.state(Chain::HCOMP_STATE + 4) : 0u;
+  if (st) L.nb = 0;
+  if (!pipe_any(L.nb > 0)) return;
+  unsigned vb = 0, vc = 0, vd = 0, vf = 0;
+  if (L.nb && L.chunk > 0) {
+    vb = L.state(Chain::HCOMP_STATE + 0); vc = L.state(Chain::HCOMP_STATE + 1);
+    vd = L.state(Chain::HCOMP_STATE + 2); vf = L.state(Chain::HCOMP_STATE + 3);
+  }
+  g_u8* const vm_M = L.arena + Chain::OFF_M;
+  g_u32* const vm_R = (g_u32*)(L.arena + Chain::OFF_R);
+  g_u32* const Hg = (g_u32*)(L.arena + Chain::OFF_H);
+  PipeHLds<Chain> Hl{Hs, lane};
+  if constexpr (HLDS) {
+    if (L.nb) for (unsigned i = 0; i < HW; ++i) Hl[i] = Hg[i];
+  }
+  unsigned ch = L.nb ? L.byte_at(0) : 0u;
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned chn = L.byte_at(L.next(k));
+    // contexts of byte k = H as left by the bytes before it (Predictor::update0, libzpaq.cpp:2049-2054)
+    static_for<0, Chain::N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (Chain::P_CTX[i] >= 0) {
+        unsigned hv;
+        if constexpr (HLDS) hv = Hl[(unsigned)i & Chain::HMASK]; else hv = Hg[(unsigned)i & Chain::HMASK];
+        L.ctx(Chain::P_CTX[i], k) = hv;
+      }
+    });
+    int e;
+    if constexpr (HLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hl, vm_R);
+    else e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hg, vm_R);
+    if (e) { st = (unsigned)e; break; }
+    ch = chn;
+  }
+  if (L.nb) {
+    if constexpr (HLDS) for (unsigned i = 0; i < HW; ++i) Hg[i] = Hl[i];
+    L.state(Chain::HCOMP_STATE + 0) = vb; L.state(Chain::HCOMP_STATE + 1) = vc;
+    L.state(Chain::HCOMP_STATE + 2) = vd; L.state(Chain::HCOMP_STATE + 3) = vf;
+    L.state(Chain::HCOMP_STATE + 4) = st;
+  }
+}
+
+// =====================================================================================================
+// ROW unit of ICM / ISSE component I: Predictor::find (libzpaq.cpp:2072-2088) once per nibble, the row's
+// bit histories in registers for the nibble's 4 bits, next-state by table, row written back.
+struct PipeRow { unsigned off, w0, w1, w2, w3; };
+
+__device__ __forceinline__ PipeRow pipe_find(const uint4& r0, const uint4& r1, const uint4& r2, unsigned chk, unsigned h0) {
+  const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+  const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+  const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
+  const bool hit = m0 || m1 || m2;
+  const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
+  PipeRow r;
+  r.off = h0 ^ (unsigned)(pick << 4);
+  r.w0 = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
+  r.w1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
+  r.w2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
+  r.w3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
+  return r;
+}
+
+// the nibble's 4 bits: slots 1, 2..3, 4..7, 8..15 (hmap4 & 15) = bytes 1..3 of w0, then w1, then w2 / w3;
+// returns the 4 bit histories the predictor sees, lowest byte first
+template <class NS>
+__device__ __forceinline__ unsigned pipe_row_bits(PipeRow& r, unsigned bits, const NS& ns) {
+  unsigned outw;
+  {
+    const unsigned s = (r.w0 >> 8) & 255u;
+    outw = s;
+    r.w0 = (r.w0 & 0xFFFF00FFu) | ((unsigned)ns[s * 4u + ((bits >> 3) & 1u)] << 8);
+  }
+  {
+    const unsigned sh = 16u + 8u * ((bits >> 3) & 1u);
+    const unsigned s = (r.w0 >> sh) & 255u;
+    outw |= s << 8;
+    r.w0 = (r.w0 & ~(255u << sh)) | ((unsigned)ns[s * 4u + ((bits >> 2) & 1u)] << sh);
+  }
+  {
+    const unsigned sh = 8u * ((bits >> 2) & 3u);
+    const unsigned s = (r.w1 >> sh) & 255u;
+    outw |= s << 16;
+    r.w1 = (r.w1 & ~(255u << sh)) | ((unsigned)ns[s * 4u + ((bits >> 1) & 1u)] << sh);
+  }
+  {
+    const unsigned idx = (bits >> 1) & 7u, sh = 8u * (idx & 3u);
+    const unsigned wsel = (idx & 4u) ? r.w3 : r.w2;
+    const unsigned s = (wsel >> sh) & 255u;
+    outw |= s << 24;
+    const unsigned nw = (wsel & ~(255u << sh)) | ((unsigned)ns[s * 4u + (bits & 1u)] << sh);
+    r.w2 = (idx & 4u) ? r.w2 : nw;
+    r.w3 = (idx & 4u) ? nw : r.w3;
+  }
+  return outw;
+}
+
+template <class Chain, int I, class NS>
+__device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
+  constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I];
+  constexpr bool touch = rmask >= (1u << 18) - 1u;       // tables of 256 KiB and more: pull the next byte's lines early
+  if (!L.nb) return;
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  unsigned ta = 0, tb2 = 0;
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
+    // candidate rows of both nibbles (c8 = 1, c8 = 16 + high nibble), three per 64-byte line
+    const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
+    const unsigned ha = (cxa * 16u) & (rmask - 15u), hb = (cxb * 16u) & (rmask - 15u);
+    const uint4 a0 = L.A128(ht + ha), a1 = L.A128(ht + (ha ^ 16u)), a2 = L.A128(ht + (ha ^ 32u));
+    uint4 b0 = L.A128(ht + hb), b1 = L.A128(ht + (hb ^ 16u)), b2 = L.A128(ht + (hb ^ 32u));
+    if constexpr (touch) {
+      ZPQ_KEEP2(ta, tb2);
+      ta = L.A32(ht + (((hn + 16u) * 16u) & (rmask - 15u)));
+      tb2 = L.A32(ht + (((hn + 16u * (16u + (byten >> 4))) * 16u) & (rmask - 15u)));
+    }
+    PipeRow ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
+    uint2 o;
+    o.x = pipe_row_bits(ra, byte >> 4, ns);
+    const uint4 na = make_uint4(ra.w0, ra.w1, ra.w2, ra.w3);
+    L.A128(ht + ra.off) = na;
+    // the second nibble's candidates were fetched before that store: forward the row it rewrote
+    if (ra.off == hb) b0 = na;
+    if (ra.off == (hb ^ 16u)) b1 = na;
+    if (ra.off == (hb ^ 32u)) b2 = na;
+    PipeRow rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
+    o.y = pipe_row_bits(rb, byte & 15u, ns);
+    L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
+    L.bh(ri, k) = o;
+    h = hn; byte = byten;
+  }
+  if constexpr (touch) ZPQ_KEEP2(ta, tb2);
+}
+
+// CONS: a constant stream, so that consumers need no special case
+template <class Chain, int I>
+__device__ __forceinline__ void pipe_cons(PipeLane<Chain>& L) {
+  constexpr unsigned v = (unsigned)(((int)Chain::comp[I].a1 - 128) * 4) & 0xFFFFu;
+  for (unsigned k = 0; k < L.nb; ++k) L.p(I, k) = make_uint4(v | v << 16, v | v << 16, v | v << 16, v | v << 16);
+}
+
+// CM (Predictor::predict0/update0 case CM, libzpaq.cpp:1869-1873, 1969-1971)
+template <class Chain, int I, class DT>
+__device__ __forceinline__ void pipe_cm(PipeLane<Chain>& L, const PipeStretch& stretch, const DT& dt) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I];
+  constexpr bool batch = c.mask0 >= 511u;      // the 8 words of a byte are distinct: fetch them together
+  constexpr bool touch = c.mask0 >= (1u << 16) - 1u;
+  if (!L.nb) return;
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  unsigned ta = 0, tb2 = 0;
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
+    unsigned v[8];
+    if constexpr (batch) {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) v[B] = L.A32((unsigned)c.t0 + 4u * ((h ^ pipe_hmap4(byte, B)) & c.mask0));
+    }
+    if constexpr (touch) {
+      ZPQ_KEEP2(ta, tb2);
+      ta = L.A32((unsigned)c.t0 + 4u * ((hn ^ 1u) & c.mask0));
+      tb2 = L.A32((unsigned)c.t0 + 4u * ((hn ^ pipe_hmap4(byten, 4)) & c.mask0));
+    }
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned off = (unsigned)c.t0 + 4u * ((h ^ pipe_hmap4(byte, B)) & c.mask0);
+      if constexpr (!batch) v[B] = L.A32(off);
+      out.set(B, stretch(v[B] >> 17));
+      L.A32(off) = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+    }
+    L.p(I, k) = out.get();
+    h = hn; byte = byten;
+  }
+  if constexpr (touch) ZPQ_KEEP2(ta, tb2);
+}
+
+// MATCH (libzpaq.cpp:1883-1892, 1985-2008): length / offset / position live in registers, the predicted byte is
+// fetched once per byte.  State words: len, offset, pos, predicted byte, 2048/len, last predicted bit.
+template <class Chain, int I, class DT2K>
+__device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch& stretch, const DT2K& dt2k) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I], sw = Chain::P_STATE[I];
+  constexpr unsigned off0 = (unsigned)c.t0, off1 = (unsigned)c.t1, mask = c.mask1;
+  if (!L.nb) return;
+  unsigned ra = 0, rb = 0, rlimit = 0, mpred = 0, mdd = 0, rc = 0;
+  if (L.chunk > 0) {
+    ra = L.state(sw + 0); rb = L.state(sw + 1); rlimit = L.state(sw + 2);
+    mpred = L.state(sw + 3); mdd = L.state(sw + 4); rc = L.state(sw + 5);
+  }
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  unsigned tch = 0;
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
+    // the index entry of this byte's context is only read at the end of the byte and nobody else writes it:
+    // fetch it now, and pull the next byte's entry towards L2
+    const unsigned eo = off0 + 4u * (h & c.mask0);
+    const unsigned cmv = L.A32(eo);
+    ZPQ_KEEP2(tch, tch);
+    tch = L.A32(off0 + 4u * (hn & c.mask0));
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const bool on = ra != 0;
+      rc = on ? ((mpred >> (7 - B)) & 1u) : rc;
+      const unsigned sx = on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;     // stretch(16384) = 0: "p[i]=0"
+      out.set(B, stretch(sx));
+      ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
+    }
+    L.p(I, k) = out.get();
+    L.A8(off1 + (rlimit & mask)) = (unsigned char)byte;
+    rlimit = (rlimit + 1) & mask;
+    if (ra == 0) {
+      rb = rlimit - cmv;
+      if (rb & mask)
+        while (ra < 255 && L.A8(off1 + ((rlimit - ra - 1) & mask)) == L.A8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+    } else ra += ra < 255;
+    L.A32(eo) = rlimit;
+    if (ra != 0) { mpred = L.A8(off1 + ((rlimit - rb) & mask)); mdd = dt2k[ra]; }
+    h = hn; byte = byten;
+  }
+  ZPQ_KEEP2(tch, tch);
+  L.state(sw + 0) = ra; L.state(sw + 1) = rb; L.state(sw + 2) = rlimit;
+  L.state(sw + 3) = mpred; L.state(sw + 4) = mdd; L.state(sw + 5) = rc;
+}
+
+// AVG (libzpaq.cpp:1894-1896)
+template <class Chain, int I>
+__device__ __forceinline__ void pipe_avg(PipeLane<Chain>& L) {
+  constexpr CompK c = Chain::comp[I];
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const uint4 vj = L.p((int)c.a1, k), vk = L.p((int)c.a2, k);
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) out.set(B, (pipe_p_get(vj, B) * (int)c.a3 + pipe_p_get(vk, B) * (256 - (int)c.a3)) >> 8);
+    L.p(I, k) = out.get();
+  }
+}
+
+// MIX2 (libzpaq.cpp:1898-1908, 2010-2021).  Device layout: one weight per dword.
+template <class Chain, int I>
+__device__ __forceinline__ void pipe_mix2(PipeLane<Chain>& L, const PipeSquash& squash) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I];
+  constexpr bool single = c.mask0 == 0u;                          // one weight: it stays in a register
+  constexpr bool batch = !single && c.a5 == 255u && c.mask0 >= 255u;
+  if (!L.nb) return;
+  unsigned wreg = 0;
+  if constexpr (single) wreg = L.A32((unsigned)c.t0);
+  unsigned h = single ? 0u : (unsigned)L.ctx(ci, 0), byte = L.byte_at(0);
+  uint4 vj = L.p((int)c.a2, 0), vk = L.p((int)c.a3, 0);
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned hn = single ? 0u : (unsigned)L.ctx(ci, kn), byten = L.byte_at(kn);
+    const uint4 vjn = L.p((int)c.a2, kn), vkn = L.p((int)c.a3, kn);
+    unsigned v[8];
+    if constexpr (batch) {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) v[B] = L.A32((unsigned)c.t0 + 4u * ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0));
+    }
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned off = (unsigned)c.t0 + 4u * ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0);
+      const int w = (int)(single ? wreg : (batch ? v[B] : (unsigned)L.A32(off)));
+      const int pj = pipe_p_get(vj, B), pk = pipe_p_get(vk, B);
+      const int pr = (w * pj + (65536 - w) * pk) >> 16;
+      out.set(B, pr);
+      const int err = ((pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr))) * (int)c.a4) >> 5;
+      const int nw = min(max(w + ((err * (pj - pk) + (1 << 12)) >> 13), 0), 65535);
+      if constexpr (single) wreg = (unsigned)nw; else L.A32(off) = (unsigned)nw;
+    }
+    L.p(I, k) = out.get();
+    h = hn; byte = byten; vj = vjn; vk = vkn;
+  }
+  if constexpr (single) L.A32((unsigned)c.t0) = wreg;
+}
+
+// SSE (libzpaq.cpp:1933-1944, 2041-2044)
+template <class Chain, int I, class DT>
+__device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& stretch, const DT& dt) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I];
+  constexpr bool batch = c.mask0 >= 32u * 256u - 1u;               // the 8 rows of a byte are distinct
+  constexpr bool touch = batch && c.mask0 >= (1u << 16) - 1u;
+  if (!L.nb) return;
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  uint4 vj = L.p((int)c.a2, 0);
+  unsigned tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
+    const uint4 vjn = L.p((int)c.a2, kn);
+    unsigned e0[8], e1[8], ix[8];
+    int wt[8];
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      int pq = pipe_p_get(vj, B) + 992;
+      pq = min(max(pq, 0), 1983);
+      wt[B] = pq & 63;
+      ix[B] = ((((h + pipe_c8(byte, B)) * 32u) & c.mask0) + (unsigned)(pq >> 6));
+      if constexpr (batch) {
+        e0[B] = L.A32((unsigned)c.t0 + 4u * (ix[B] & c.mask0));
+        e1[B] = L.A32((unsigned)c.t0 + 4u * ((ix[B] + 1u) & c.mask0));
+      }
+    }
+    if constexpr (touch) {
+      ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]);
+      ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]);
+#pragma unroll
+      for (int B = 0; B < 8; ++B) tc[B] = L.A32((unsigned)c.t0 + 4u * ((((hn + pipe_c8(byten, B)) * 32u) & c.mask0) + 16u));
+    }
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      if constexpr (!batch) {
+        e0[B] = L.A32((unsigned)c.t0 + 4u * (ix[B] & c.mask0));
+        e1[B] = L.A32((unsigned)c.t0 + 4u * ((ix[B] + 1u) & c.mask0));
+      }
+      const int w = wt[B];
+      out.set(B, stretch(((e0[B] >> 10) * (unsigned)(64 - w) + (e1[B] >> 10) * (unsigned)w) >> 13));
+      const unsigned tv = (w >> 5) ? e1[B] : e0[B];
+      const unsigned ti = (ix[B] + (unsigned)(w >> 5)) & c.mask0;
+      L.A32((unsigned)c.t0 + 4u * ti) = pipe_train(tv, pipe_y(byte, B), (unsigned)dt[tv & 0x3ffu], c.limit);
+    }
+    L.p(I, k) = out.get();
+    h = hn; byte = byten; vj = vjn;
+  }
+  if constexpr (touch) { ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]); ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]); }
+}
+
+// CODER: Encoder::compress / encode (libzpaq.cpp:2402-2447) fed by the last component's stream.
+template <class Chain>
+__device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a, const PipeSquash& squash) {
+  constexpr int sw = Chain::CODER_STATE;
+  const unsigned nchunks = max((L.len + (unsigned)Chain::PIPE_C - 1u) / (unsigned)Chain::PIPE_C, 1u);
+  const bool active = L.live && L.chunk >= 0 && (unsigned)L.chunk < nchunks;
+  if (!active) return;
+  unsigned low = 1, high = 0xFFFFFFFFu, n = 0;
+  if (L.chunk > 0) { low = L.state(sw + 0); high = L.state(sw + 1); n = L.state(sw + 2); }
+  auto encode = [&](int y, unsigned pr) __attribute__((always_inline)) {
+    const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
+    if (y) high = mid; else low = mid + 1;
+    while ((high ^ low) < 0x1000000u) {
+      if (n < L.out_cap) L.out[n] = (unsigned char)(high >> 24);
+      ++n;
+      high = high << 8 | 255u;
+      low = low << 8;
+      low += (low == 0);
+    }
+  };
+  if (L.nb) {
+    unsigned byte = L.byte_at(0);
+    uint4 v = L.p(Chain::N - 1, 0);
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint4 vn = L.p(Chain::N - 1, kn);
+      encode(0, 0);
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const int pr = squash(sp_clamp2k(pipe_p_get(v, B)));
+        encode(pipe_y(byte, B), (unsigned)pr * 2u + 1u);
+      }
+      byte = byten; v = vn;
+    }
+  }
+  if ((unsigned)L.chunk == nchunks - 1u) {
+    int status = (int)(unsigned)L.state(Chain::HCOMP_STATE + 4);
+    if (!status) encode(1, 0);
+    if (!status && n > L.out_cap) status = 3;
+    BlockResult r;
+    r.out_len = n; r.consumed = L.len; r.status = status; r.steps = 8u * L.len;
+    a.res[L.rslot] = r;
+  } else {
+    L.state(sw + 0) = low; L.state(sw + 1) = high; L.state(sw + 2) = n;
+  }
+}
+
+// =====================================================================================================
+// Rows kernel: the ROW unit of every ICM / ISSE (1 KB of LDS: the state table).  One wavefront per (unit, group).
+template <class Chain>
+__device__ __forceinline__ void pipe_rows_body(const PipeArgs& a) {
+  __shared__ unsigned char ns[1024];
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  for (int i = lane; i < 256; i += (int)blockDim.x) ((unsigned*)ns)[i] = ((const unsigned*)a.tb->ns)[i];
+  __syncthreads();
+  static_for<0, Chain::NROWU>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + (unsigned)lane, 1);
+    if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+    pipe_row<Chain, Chain::ROW_COMP[r]>(L, ns);
+  });
+}
+
+// Light kernel: every other unit that needs no big LDS table (CONS, CM, MATCH, AVG, MIX2, SSE, CODER); the small
+// shared tables (dt, dt2k, squash, compact stretch: 16 KB) are loaded by the units that use them.
+template <class Chain>
+__device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
+  __shared__ int dt[1024];
+  __shared__ unsigned short dt2k[256];
+  __shared__ PipeSquash squash;
+  __shared__ PipeStretch stretch;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  static_for<0, Chain::NLIGHT>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    constexpr int kind = Chain::LIGHT_KIND[r], I = Chain::LIGHT_COMP[r];
+    constexpr int level = kind == PK_CODER ? Chain::CODER_LEVEL : Chain::P_LEVEL[I];
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + (unsigned)lane, level);
+    if (L.chunk < 0) return;
+    if constexpr (kind != PK_CODER) { if (!pipe_any(L.nb > 0)) return; }
+    if constexpr (kind == PK_CONS) {
+      pipe_cons<Chain, I>(L);
+    } else if constexpr (kind == PK_CM) {
+      for (int i = lane; i < 1024; i += (int)blockDim.x) dt[i] = a.tb->dt[i];
+      stretch.load(a.tb, lane);
+      __syncthreads();
+      pipe_cm<Chain, I>(L, stretch, dt);
+    } else if constexpr (kind == PK_MATCH) {
+      for (int i = lane; i < 256; i += (int)blockDim.x) dt2k[i] = (unsigned short)a.tb->dt2k[i];
+      stretch.load(a.tb, lane);
+      __syncthreads();
+      pipe_match<Chain, I>(L, stretch, dt2k);
+    } else if constexpr (kind == PK_AVG) {
+      pipe_avg<Chain, I>(L);
+    } else if constexpr (kind == PK_MIX2) {
+      squash.load(a.tb, lane);
+      __syncthreads();
+      pipe_mix2<Chain, I>(L, squash);
+    } else if constexpr (kind == PK_SSE) {
+      for (int i = lane; i < 1024; i += (int)blockDim.x) dt[i] = a.tb->dt[i];
+      stretch.load(a.tb, lane);
+      __syncthreads();
+      pipe_sse<Chain, I>(L, stretch, dt);
+    } else if constexpr (kind == PK_CODER) {
+      squash.load(a.tb, lane);
+      __syncthreads();
+      pipe_coder<Chain>(L, a, squash);
+    }
+  });
+}
+
+// the 8 bit histories of a byte out of a bh stream element
+__device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return ((B < 4 ? w.x : w.y) >> (8 * (B & 3))) & 255u; }
+
+// =====================================================================================================
+// ICM map (libzpaq.cpp:1875-1881, 1973-1977): side table cm[256] of 64 blocks in LDS as [entry][lane].
+// The entry of the NEXT bit is read before this bit's entry is written and patched when they coincide, so the
+// LDS round trip is off the lane's serial chain.
+template <class Chain>
+__device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
+  constexpr unsigned G = Chain::PIPE_G;
+  __shared__ unsigned tab[256 * G];
+  __shared__ PipeStretch stretch;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  static_for<0, Chain::NICM>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    constexpr int I = Chain::ICM_COMP[r];
+    constexpr CompK c = Chain::comp[I];
+    constexpr int ri = Chain::P_ROW[I];
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + (unsigned)lane, Chain::P_LEVEL[I]);
+    if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+    stretch.load(a.tb, lane);
+    __syncthreads();
+    if (!L.nb) return;
+    for (int e = 0; e < 256; e += 4) {
+      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+    }
+    unsigned byte = L.byte_at(0);
+    uint2 w = L.bh(ri, 0);
+    unsigned s = pipe_bh_get(w, 0);
+    unsigned v = tab[s * G + lane];
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint2 wn = L.bh(ri, kn);
+      PipeP8 out;
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
+        const unsigned vn = tab[sn * G + lane];
+        out.set(B, stretch(v >> 8));
+        const unsigned nv = v + (unsigned)((int)((unsigned)(pipe_y(byte, B) * 32767) - (v >> 8)) >> 2);
+        tab[s * G + lane] = nv;
+        v = sn == s ? nv : vn;
+        s = sn;
+      }
+      L.p(I, k) = out.get();
+      byte = byten; w = wn;
+    }
+    for (int e = 0; e < 256; e += 4)
+      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+  });
+}
+
+// ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
+template <class Chain>
+__device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
+  constexpr unsigned G = Chain::PIPE_G;
+  __shared__ unsigned tab[512 * G];
+  __shared__ PipeSquash squash;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  static_for<0, Chain::NISSE>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    constexpr int I = Chain::ISSE_COMP[r];
+    constexpr CompK c = Chain::comp[I];
+    constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + (unsigned)lane, Chain::P_LEVEL[I]);
+    if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+    squash.load(a.tb, lane);
+    if (L.nb)
+      for (int e = 0; e < 512; e += 4) {
+        const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+        tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+      }
+    __syncthreads();
+    if (!L.nb) return;
+    unsigned byte = L.byte_at(0);
+    uint2 w = L.bh(ri, 0);
+    uint4 vj = L.p(J, 0);
+    unsigned s = pipe_bh_get(w, 0);
+    int w0 = (int)tab[(2u * s) * G + lane], w1 = (int)tab[(2u * s + 1u) * G + lane];
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint2 wn = L.bh(ri, kn);
+      const uint4 vjn = L.p(J, kn);
+      PipeP8 out;
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
+        const int n0 = (int)tab[(2u * sn) * G + lane], n1 = (int)tab[(2u * sn + 1u) * G + lane];
+        const int pj = pipe_p_get(vj, B);
+        const int pr = sp_clamp2k((w0 * pj + w1 * 64) >> 16);
+        out.set(B, pr);
+        const int err = pipe_y(byte, B) * 32767 - squash(pr);
+        const int u0 = sp_clamp512k(w0 + ((err * pj + (1 << 12)) >> 13));
+        const int u1 = sp_clamp512k(w1 + ((err + 16) >> 5));
+        tab[(2u * s) * G + lane] = (unsigned)u0;
+        tab[(2u * s + 1u) * G + lane] = (unsigned)u1;
+        w0 = sn == s ? u0 : n0;
+        w1 = sn == s ? u1 : n1;
+        s = sn;
+      }
+      L.p(I, k) = out.get();
+      byte = byten; w = wn; vj = vjn;
+    }
+    for (int e = 0; e < 512; e += 4)
+      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+  });
+}
+
+// =====================================================================================================
+// MIX (libzpaq.cpp:1910-1921, 2023-2029): QL lanes per block, lane q owning weights 4q .. 4q+3 of the selected
+// row, so a row travels as ONE 16-byte access per lane (a row of m weights = ceil(m/4) lanes, rows are only 4-byte
+// aligned).  The dot product is reduced inside the lane group by DPP (quad_perm, row_half_mirror, row_mirror),
+// which leaves the sum in EVERY lane of the group, so each lane computes the error itself and trains its own
+// weights.
+typedef uint4 __attribute__((aligned(4))) pipe_u128a4;
+typedef __attribute__((address_space(1))) pipe_u128a4 g_u128a4;
+
+template <int QL>
+__device__ __forceinline__ int pipe_group_sum(int v) {
+  if constexpr (QL >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  if constexpr (QL >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  if constexpr (QL >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  if constexpr (QL >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return v;
+}
+
+template <class Chain>
+__device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
+  __shared__ PipeSquash squash;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  squash.load(a.tb, lane);
+  __syncthreads();
+  static_for<0, Chain::NMIXR>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r], first = Chain::MIX_FIRST[r];   // first = sum of QL of earlier roles
+    const unsigned per_group = (unsigned)QL;                                                  // wavefronts per group
+    if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + QL) * ngroups) return;
+    constexpr CompK c = Chain::comp[I];
+    constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
+    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL, TAIL = m % 4;
+    static_assert(BPW >= 1 && NQ <= QL, "MIX lane group");
+    constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
+    constexpr bool touch = batch && c.mask0 >= 4095u;            // small tables stay in L2 anyway
+    const unsigned wi = wg - (unsigned)first * ngroups;
+    const unsigned g = wi / per_group, sub = wi % per_group;
+    const unsigned bl = (unsigned)lane / QL, q = (unsigned)lane % QL;
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
+    if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+    if (!L.nb) return;
+    const bool act = q < (unsigned)NQ;                               // lanes that hold weights
+    const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+    const unsigned qoff = 16u * (act ? q : 0u);
+    bool have[4];
+    int tin[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int t = (int)q * 4 + x;
+      have[x] = t < m;
+      tin[x] = J + (have[x] ? t : 0);
+    }
+    auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
+      return (unsigned)c.t0 + 4u * (((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0) * (unsigned)m) + qoff;
+    };
+    unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+    uint4 pv[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) pv[x] = L.p(tin[x], 0);
+    unsigned tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
+      uint4 pvn[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) pvn[x] = L.p(tin[x], kn);
+      uint4 w[8];
+      if constexpr (batch) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + row_of(h, byte, B));
+      }
+      if constexpr (touch) {
+        ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]);
+        ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) tc[B] = L.A32(row_of(hn, byten, B));
+      }
+      PipeP8 out;
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const unsigned row = row_of(h, byte, B);
+        if constexpr (!batch) w[B] = *(g_u128a4*)(L.arena + row);
+        const int w0 = (int)w[B].x, w1 = (int)w[B].y, w2 = (int)w[B].z, w3 = (int)w[B].w;
+        const int p0 = have[0] ? pipe_p_get(pv[0], B) : 0, p1 = have[1] ? pipe_p_get(pv[1], B) : 0;
+        const int p2 = have[2] ? pipe_p_get(pv[2], B) : 0, p3 = have[3] ? pipe_p_get(pv[3], B) : 0;
+        const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
+        const int pr = sp_clamp2k(pipe_group_sum<QL>(act ? dot : 0) >> 8);
+        out.set(B, pr);
+        const int err = ((pipe_y(byte, B) * 32767 - squash(pr)) * (int)c.a4) >> 4;
+        const unsigned n0 = (unsigned)sp_clamp512k(w0 + ((err * p0 + (1 << 12)) >> 13));
+        const unsigned n1 = (unsigned)sp_clamp512k(w1 + ((err * p1 + (1 << 12)) >> 13));
+        const unsigned n2 = (unsigned)sp_clamp512k(w2 + ((err * p2 + (1 << 12)) >> 13));
+        const unsigned n3 = (unsigned)sp_clamp512k(w3 + ((err * p3 + (1 << 12)) >> 13));
+        if (act && !tail) *(g_u128a4*)(L.arena + row) = make_uint4(n0, n1, n2, n3);
+        if constexpr (TAIL != 0) {
+          if (tail) {
+            L.A32(row) = n0;
+            if constexpr (TAIL >= 2) L.A32(row + 4u) = n1;
+            if constexpr (TAIL >= 3) L.A32(row + 8u) = n2;
+          }
+        }
+      }
+      if (q == 0) L.p(I, k) = out.get();
+      h = hn; byte = byten;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) pv[x] = pvn[x];
+    }
+    if constexpr (touch) { ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]); ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]); }
+  });
+}
+
+}  // namespace zpq

@@ -17,6 +17,9 @@ struct zpq_plan {
   // engine chooses per launch.  (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
   void* spec[2] = {nullptr, nullptr};   // SpecKernel*
   int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
+  void* pipe = nullptr;                 // PipeKernel*: the pipelined encoder (device/pipe_kernel.h)
+  int pipe_state = 0;                   // 0 not tried, 1 loaded, -1 unavailable
+  std::string pipe_note;
   std::string spec_note;                // where the last kernel came from / why it is unavailable
   const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
   const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }

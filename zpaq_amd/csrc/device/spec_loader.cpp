@@ -79,6 +79,24 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
   return true;
 }
 
+bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_pipe_source(plan, source, why_not)) return false;
+  std::string h1, h2, h3;
+  const std::string inc = spec_include_dir();
+  if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) || !read_file(inc + "/pipe_kernel.h", h3)) {
+    why_not = "kernel template headers not found under " + inc;
+    return false;
+  }
+  Sha1 s;
+  s.update(source.data(), source.size());
+  s.update(h1.data(), h1.size());
+  s.update(h2.data(), h2.size());
+  s.update(h3.data(), h3.size());
+  if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));
+  key = hex20(s.result());
+  return true;
+}
+
 static bool compile_hiprtc(const std::string& source, std::vector<char>& code, std::string& log) {
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, source.c_str(), "zpq_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -171,7 +189,65 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   return k;
 }
 
+PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
+  if (plan->pipe_state > 0) return (PipeKernel*)plan->pipe;
+  if (plan->pipe_state < 0) return nullptr;
+  plan->pipe_state = -1;
+  if (getenv("ZPAQ_AMD_NO_PIPE")) { plan->pipe_note = "disabled by ZPAQ_AMD_NO_PIPE"; return nullptr; }
+  std::string source, key, why;
+  if (!pipe_source_and_key(*plan, source, key, why)) { plan->pipe_note = why; return nullptr; }
+  std::vector<char> code;
+  std::string origin, blob;
+  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
+  if (read_file(path, blob) && !blob.empty()) {
+    code.assign(blob.begin(), blob.end());
+    origin = "cache:" + key;
+  } else {
+    if (!allow_jit) {
+      plan->pipe_state = 0;
+      plan->pipe_note = "hipRTC compile deferred (JIT budget of this batch spent)";
+      return nullptr;
+    }
+    if (did_jit) *did_jit = true;
+    std::string log;
+    if (!compile_hiprtc(source, code, log)) {
+      plan->pipe_note = "hipRTC compile failed: " + log.substr(0, 2000);
+      return nullptr;
+    }
+    origin = "hiprtc";
+    ::mkdir(spec_cache_dir().c_str(), 0755);
+    std::ofstream f(path + ".tmp", std::ios::binary);
+    if (f) {
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      ::rename((path + ".tmp").c_str(), path.c_str());
+    }
+  }
+  PipeKernel* k = new PipeKernel;
+  static const char* names[6] = {"zpq_pipe_hcomp", "zpq_pipe_rows", "zpq_pipe_light", "zpq_pipe_icm", "zpq_pipe_isse", "zpq_pipe_mix"};
+  bool ok = hipModuleLoadData(&k->module, code.data()) == hipSuccess;
+  for (int i = 0; ok && i < 6; ++i) ok = hipModuleGetFunction(&k->fn[i], k->module, names[i]) == hipSuccess;
+  if (!ok) {
+    plan->pipe_note = "hipModuleLoadData failed for " + origin;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    return nullptr;
+  }
+  k->origin = origin;
+  plan->pipe = k;
+  plan->pipe_state = 1;
+  plan->pipe_note = origin;
+  return k;
+}
+
 void spec_kernel_release(zpq_plan* plan) {
+  if (plan && plan->pipe) {
+    PipeKernel* k = (PipeKernel*)plan->pipe;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    plan->pipe = nullptr;
+    plan->pipe_state = 0;
+  }
   for (int v = 0; plan && v < 2; ++v) {
     if (!plan->spec[v]) continue;
     SpecKernel* k = (SpecKernel*)plan->spec[v];

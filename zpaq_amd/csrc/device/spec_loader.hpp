@@ -29,6 +29,15 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, 
 int spec_variant_forced();
 void spec_kernel_release(zpq_plan* plan);
 
+// The pipelined encoder of a plan (device/pipe_kernel.h): six kernels of one module.
+struct PipeKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hcomp, rows, light, icm, isse, mix
+  std::string origin;
+};
+PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit = true, bool* did_jit = nullptr);
+bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
+
 // Source text + cache key (with the template-header digest) for prebuilding.
 bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.

@@ -16,6 +16,7 @@
 #include <map>
 #include <set>
 #include <sstream>
+#include <algorithm>
 
 namespace zpq {
 
@@ -219,6 +220,150 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
        "extern \"C\" __global__ __launch_bounds__(64 * zpq_gen::Chain::WAVES) void zpq_spec_decode(const zpq::BlockJob* jobs, "
        "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
        "  " << body << "<zpq_gen::Chain, true>(jobs, res, nblocks, tb);\n}\n";
+  source = o.str();
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined encoder: dataflow levels + buffer layout (see device/pipe_kernel.h for the design)
+bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
+  const PlanHeader& ph = plan.hdr();
+  const int n = (int)ph.n;
+  if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
+  if (ph.arena_bytes >= (1ull << 32)) { why_not = "model state of 4 GiB or more per block"; return false; }
+  const CompDesc* comp = plan.comps();
+  L = PipeLayout();
+  L.n = n;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_CHUNK")) {
+    const int c = atoi(e);
+    if (c >= 64 && c <= 8192 && (c & (c - 1)) == 0) L.C = c;
+  }
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_GROUP")) {
+    const int g = atoi(e);
+    if (g == 8 || g == 16 || g == 32 || g == 64) L.G = g;
+  }
+  int qforce = 0;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_LANES")) qforce = atoi(e);
+  enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
+  for (int i = 0; i < n; ++i) {
+    const CompDesc& c = comp[i];
+    L.ctx[i] = L.row[i] = L.state[i] = -1;
+    int lv = 1;
+    switch (c.type) {
+      case C_CONS: L.light.push_back({K_CONS, i}); break;
+      case C_CM: L.ctx[i] = L.nctx++; L.light.push_back({K_CM, i}); break;
+      case C_MATCH: L.ctx[i] = L.nctx++; L.state[i] = L.nstate; L.nstate += 8; L.light.push_back({K_MATCH, i}); break;
+      case C_ICM: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = 2; L.icm.push_back(i); break;
+      case C_ISSE: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = std::max(2, L.level[c.a2] + 1); L.isse.push_back(i); break;
+      case C_AVG: lv = std::max(L.level[c.a1], L.level[c.a2]) + 1; L.light.push_back({K_AVG, i}); break;
+      case C_MIX2: L.ctx[i] = L.nctx++; lv = std::max(L.level[c.a2], L.level[c.a3]) + 1; L.light.push_back({K_MIX2, i}); break;
+      case C_SSE: L.ctx[i] = L.nctx++; lv = L.level[c.a2] + 1; L.light.push_back({K_SSE, i}); break;
+      case C_MIX: {
+        if (c.a3 > 64) { why_not = "MIX with more than 64 inputs"; return false; }
+        L.ctx[i] = L.nctx++;
+        for (unsigned t = 0; t < c.a3; ++t) lv = std::max(lv, L.level[c.a2 + t] + 1);
+        const int m = (int)c.a3, nq = (m + 3) / 4;     // lanes that hold weights: 4 per lane, one 16-byte access
+        int ql = 1;
+        while (ql < nq) ql *= 2;
+        if (qforce > ql && (qforce == 2 || qforce == 4 || qforce == 8 || qforce == 16)) ql = qforce;
+        if (ql > L.G) { why_not = "MIX lane group wider than the block group"; return false; }
+        L.mix.push_back(i);
+        L.mix_ql.push_back(ql);
+        break;
+      }
+      default: why_not = "unknown component type"; return false;
+    }
+    L.level[i] = lv;
+  }
+  // ROW units (level 1) have a kernel of their own; the light kernel: the components in COMP order, then the coder
+  for (int i = 0; i < n; ++i) if (L.row[i] >= 0) L.rows.push_back(i);
+  L.light.push_back({K_CODER, n - 1});
+  L.coder_level = L.level[n - 1] + 1;
+  L.S = L.coder_level + 1;
+  L.hcomp_state = L.nstate; L.nstate += 8;
+  L.coder_state = L.nstate; L.nstate += 4;
+  const uint64_t hbytes = 4ull * (ph.hmask + 1);
+  L.hcomp_h_lds = hbytes <= 8192;
+  L.hcomp_lanes = 64;
+  if (L.hcomp_h_lds) while (L.hcomp_lanes > 8 && hbytes * L.hcomp_lanes > 65536) L.hcomp_lanes /= 2;
+  const uint64_t C = (uint64_t)L.C, S = (uint64_t)L.S, G = (uint64_t)L.G;
+  uint64_t off = 0;
+  L.off_ctx = off;   off += S * (uint64_t)std::max(L.nctx, 1) * C * G * 4;
+  L.off_bh = off;    off += S * (uint64_t)std::max(L.nrow, 1) * C * G * 8;
+  L.off_p = off;     off += S * (uint64_t)n * C * G * 16;
+  L.off_state = off; off += (uint64_t)L.nstate * G * 4;
+  L.group_bytes = (off + 4095) & ~4095ull;
+  if (L.group_bytes >= (1ull << 32)) { why_not = "stream buffer of a block group exceeds 4 GiB (lower ZPAQ_AMD_PIPE_CHUNK)"; return false; }
+  return true;
+}
+
+bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string& why_not) {
+  PipeLayout L;
+  if (!pipe_layout(plan, L, why_not)) return false;
+  const PlanHeader& ph = plan.hdr();
+  const int n = L.n;
+  const CompDesc* comp = plan.comps();
+  std::ostringstream o;
+  o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " (pipelined encoder) -- do not edit\n"
+       "#include \"pipe_kernel.h\"\n"
+       "namespace zpq_gen {\n"
+       "struct Chain {\n";
+  int nmix = 0, nsse = 0;
+  std::ostringstream comps;
+  for (int i = 0; i < n; ++i) {
+    const CompDesc& c = comp[i];
+    int slot = -1;
+    if (c.type == C_MIX) slot = nmix++;
+    if (c.type == C_SSE) slot = nsse++;
+    comps << "    {" << c.type << "u," << c.a1 << "u," << c.a2 << "u," << c.a3 << "u," << c.a4 << "u," << c.a5 << "u, "
+          << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, -1," << slot << "},\n";
+  }
+  auto arr = [&](const char* name, const int* v, int cnt) {
+    o << "  static constexpr int " << name << "[" << std::max(cnt, 1) << "] = {";
+    for (int i = 0; i < std::max(cnt, 1); ++i) o << (i ? "," : "") << (i < cnt ? v[i] : 0);
+    o << "};\n";
+  };
+  o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ";\n"
+    << "  static constexpr unsigned HMASK = " << ph.hmask << "u, MMASK = " << ph.mmask << "u;\n"
+    << "  static constexpr unsigned long long OFF_RUN = " << ph.off_run << "ull;\n"
+    << "  static constexpr unsigned long long OFF_H = " << ph.off_H << "ull, OFF_M = " << ph.off_M
+    << "ull, OFF_R = " << ph.off_R << "ull;\n"
+    << "  static constexpr zpq::CompK comp[N] = {\n" << comps.str() << "  };\n"
+    << "  static constexpr unsigned PIPE_G = " << L.G << "u;\n"
+    << "  static constexpr int PIPE_C = " << L.C << ", PIPE_S = " << L.S << ", PIPE_NCTX = " << std::max(L.nctx, 1)
+    << ", PIPE_NROW = " << std::max(L.nrow, 1) << ";\n"
+    << "  static constexpr unsigned long long PIPE_OFF_CTX = " << L.off_ctx << "ull, PIPE_OFF_BH = " << L.off_bh
+    << "ull, PIPE_OFF_P = " << L.off_p << "ull, PIPE_OFF_STATE = " << L.off_state << "ull, PIPE_GROUP_BYTES = "
+    << L.group_bytes << "ull;\n"
+    << "  static constexpr int CODER_LEVEL = " << L.coder_level << ", CODER_STATE = " << L.coder_state
+    << ", HCOMP_STATE = " << L.hcomp_state << ", HCOMP_LANES = " << L.hcomp_lanes << ";\n"
+    << "  static constexpr bool HCOMP_H_LDS = " << (L.hcomp_h_lds ? "true" : "false") << ";\n";
+  arr("P_LEVEL", L.level, n);
+  arr("P_CTX", L.ctx, n);
+  arr("P_ROW", L.row, n);
+  arr("P_STATE", L.state, n);
+  std::vector<int> lk, lc, mf;
+  for (auto& r : L.light) { lk.push_back(r.first); lc.push_back(r.second); }
+  int first = 0;
+  for (int q : L.mix_ql) { mf.push_back(first); first += q; }
+  o << "  static constexpr int NROWU = " << L.rows.size() << ", NLIGHT = " << L.light.size() << ", NICM = " << L.icm.size() << ", NISSE = " << L.isse.size()
+    << ", NMIXR = " << L.mix.size() << ";\n";
+  arr("LIGHT_KIND", lk.data(), (int)lk.size());
+  arr("LIGHT_COMP", lc.data(), (int)lc.size());
+  arr("ROW_COMP", L.rows.data(), (int)L.rows.size());
+  arr("ICM_COMP", L.icm.data(), (int)L.icm.size());
+  arr("ISSE_COMP", L.isse.data(), (int)L.isse.size());
+  arr("MIX_COMP", L.mix.data(), (int)L.mix.size());
+  arr("MIX_QL", L.mix_ql.data(), (int)L.mix_ql.size());
+  arr("MIX_FIRST", mf.data(), (int)mf.size());
+  const U8* prog = plan.blob.data() + ph.off_prog;
+  if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
+  o << "};\n"
+       "}  // namespace zpq_gen\n";
+  const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
+  for (const char* nm : names)
+    o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << nm << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp: 64)
+         "  zpq::pipe_" << nm << "_body<zpq_gen::Chain>(a);\n}\n";
   source = o.str();
   return true;
 }

@@ -1,5 +1,7 @@
 #pragma once
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../device/plan.hpp"
 #include "common.hpp"
@@ -14,6 +16,29 @@ static const int kCodegenVersion = 3;
 // `waves` = blocks per workgroup the kernel is laid out for (4: every side table that fits 30 KiB in LDS,
 // one workgroup per CU; 8: half the LDS per block, two wavefronts per SIMD)
 bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not);
+
+// ---- pipelined encoder (device/pipe_kernel.h) ----
+// Dataflow plan of a chain: the level of every unit, the stream/state layout of one group of 64 blocks and the
+// unit lists of the five kernels.  The generator prints it into the source as constants; the engine uses the
+// same numbers to size buffers and grids.
+struct PipeLayout {
+  int n = 0;
+  int C = 512;                 // chunk: input bytes per unit per step
+  int G = 64;                  // blocks per group = active lanes per wavefront (16 / 32 / 64)
+  int S = 0;                   // ring slots = highest level + 1
+  int nctx = 0, nrow = 0, nstate = 0;
+  int level[64], ctx[64], row[64], state[64];
+  int coder_level = 0, coder_state = 0, hcomp_state = 0;
+  int hcomp_lanes = 64;        // blocks per HCOMP workgroup
+  bool hcomp_h_lds = false;    // H staged in LDS
+  std::vector<std::pair<int, int>> light;   // (PipeKind, component): CONS, CM, MATCH, AVG, MIX2, SSE units and the coder
+  std::vector<int> rows, icm, isse, mix, mix_ql;
+  uint64_t off_ctx = 0, off_bh = 0, off_p = 0, off_state = 0, group_bytes = 0;
+  int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += q; return s; }
+};
+// false + reason when the chain cannot run on the pipelined encoder (then the per-wavefront kernels code it)
+bool pipe_layout(const zpq_plan& plan, PipeLayout& out, std::string& why_not);
+bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string& why_not);
 
 // Cache key of a generated source: SHA-1 over the text (which embeds the codegen
 // version) -- the loader extends it with a digest of the kernel template headers.

@@ -56,6 +56,10 @@ struct Tables {
   U32 isse_init[512];
   // SSE row pattern without the `start` count (1844): squash((j&31)*64-992)<<17
   U32 sse_row[32];
+  // compact stretch for LDS (device/pipe_kernel.h): x in [16384, 32512) in groups of 8 as value-at-group-start |
+  // 7 one-bit increments << 16; x >= 32512 direct; x < 16384 by the mirror rule stretch(x) = -stretch(32767 - x)
+  U32 stretch_cb[2016];
+  int16_t stretch_top[256];
 };
 // Built once from closed forms, verified against the reference's checksums
 // (libzpaq.cpp:1759-1760); throws Failure(ZPQ_E_DEVICE) if they do not hold.

@@ -84,6 +84,17 @@ Tables* build() {
     t->isse_init[s * 2] = 1 << 15;
     t->isse_init[s * 2 + 1] = (U32)clamp512k(t->stretch[cminit >> 8] * 1024);
   }
+  for (int e = 0; e < 2016; ++e) {
+    const int base = 16384 + 8 * e;
+    U32 bm = 0;
+    for (int i = 1; i < 8; ++i) {
+      const int d = t->stretch[base + i] - t->stretch[base + i - 1];
+      if (d < 0 || d > 1) fail(ZPQ_E_DEVICE, "stretch table is steeper than the compact form assumes");
+      bm |= (U32)d << (i - 1);
+    }
+    t->stretch_cb[e] = ((U32)(uint16_t)t->stretch[base]) | bm << 16;
+  }
+  for (int i = 0; i < 256; ++i) t->stretch_top[i] = t->stretch[32512 + i];
   for (int j = 0; j < 32; ++j) t->sse_row[j] = (U32)t->squash[j * 64 - 992 + 2048] << 17;
   return t;
 }

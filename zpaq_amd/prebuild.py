@@ -70,6 +70,21 @@ def source_and_key(header):
     return buf.value.decode(), key.value.decode()
 
 
+def pipe_source_and_key(header):
+    """The pipelined encoder of this header (device/pipe_kernel.h): source + cache key, or (None, reason)."""
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_pipe_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    p = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    rc = L.zpq_plan_pipe_source(p._h, buf, len(buf), C.byref(ln), key)
+    if rc != 0:
+        return None, L.zpq_last_error().decode()
+    return buf.value.decode(), key.value.decode()
+
+
 def compile_one(args):
     src, key, cache, inc = args
     out = os.path.join(cache, key + ".hsaco")
@@ -105,6 +120,10 @@ def main(verbose=True):
     # workgroup for batches of up to 4 x CUs blocks, 8 per workgroup (two wavefronts per SIMD) beyond that
     forced = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
     for h, why in standard_headers().items():
+        src, key = pipe_source_and_key(h)
+        if src is not None and key not in seen:
+            seen.add(key)
+            jobs.append((src, key, cache, inc))
         for waves in ("4", "8"):
             os.environ["ZPAQ_AMD_SPEC_WAVES"] = waves
             src, key = source_and_key(h)
