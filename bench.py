@@ -8,19 +8,30 @@ every bit) over one batch of B synthetic blocks per GPU, inputs already resident
 in HBM.  Default workload = BASELINE.json configs[2]: method "5" over 1024 x
 1 MiB "enwik-style" Zipf text blocks on one MI355X.  N > 1 (launched by
 torch.distributed.run, one rank per GPU): blocks are independent, so each rank
-codes its own B blocks with no data-path collective (weak scaling); ranks only
-barrier and max-reduce the time.
+codes its own blocks with no data-path collective; ranks only barrier and
+max-reduce the time.  --scaling weak (default): B blocks PER GPU (BASELINE
+configs[3] is 8 x 1024); --scaling strong: B blocks in total, split over the
+ranks.  Strong scaling of the 1024-block headline is limited by construction:
+the per-bit chain of a block is serial and one GPU already runs all 1024 blocks
+concurrently, so fewer blocks per GPU shorten the launch only as far as the
+units of the pipelined encoder stop contending for the memory pipeline
+(DESIGN.md section 6).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the coding kernel against HBM
-(achieved = algorithmic model-state bytes per launch / kernel time measured with
-hipEvents on the launch stream); `cpu_baseline` times the reference libzpaq
-(oracle/_ref, kind "reference") or, if that was not built, our C oracle (kind
-"port") on a bounded sample of the same blocks on this box's host cores.
+Prints ONE JSON line (rank 0).  `roofline` prices the coding launch sequence
+against HBM (achieved = algorithmic model-state bytes per step / its duration
+measured with hipEvents on the launch stream); `cpu_baseline` times the
+reference libzpaq (oracle/_ref, kind "reference") or, if that was not built,
+our C oracle (kind "port") on a bounded sample of the same blocks on this
+box's host cores, and every archive the reference produced is compared with
+ours by SHA-1; `api` is the same batch through the drop-in API on HOST buffers
+(method expansion + SHA-1 + H2D + kernels + D2H + framing), outside the timed
+region.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -41,9 +52,12 @@ def _gen_block(args):
 
 
 def make_corpus(kind, nblocks, block_bytes, first):
-    """[nblocks, block_bytes] uint8, block b = corpus.block(kind, block_bytes, 12345 + first + b)."""
+    """[nblocks, block_bytes] uint8, block b = corpus.block(kind, block_bytes, 12345 + first + b);
+    kind "mixed" = BASELINE configs[3]: text, text, LCG-random, records by (first + b) mod 4."""
     from zpaq_amd import corpus
-    jobs = [(kind, block_bytes, corpus.BASE_SEED + first + b) for b in range(nblocks)]
+    mix = ["text", "text", "lcg", "records"]
+    jobs = [(mix[(first + b) % 4] if kind == "mixed" else kind, block_bytes, corpus.BASE_SEED + first + b)
+            for b in range(nblocks)]
     out = np.empty((nblocks, block_bytes), np.uint8)
     nproc = min(len(jobs), os.cpu_count() or 1, 64)
     if nproc > 1 and nblocks * block_bytes >= (8 << 20):
@@ -80,7 +94,8 @@ def usable_cores():
 
 
 def cpu_baseline(blocks, method, budget_s):
-    """Reference libzpaq on this box's host cores over a bounded sample of the same blocks."""
+    """Reference libzpaq on this box's host cores over a bounded sample of the same blocks.
+    Returns (json object, reference archives: list with None for blocks not coded, or None)."""
     from oracle.oracle_py import Oracle, Ref, have_ref
     cores = usable_cores()
     nb, bs = blocks.shape
@@ -91,13 +106,13 @@ def cpu_baseline(blocks, method, budget_s):
         per_core = max(t1, 1e-3)
         sample = int(max(1, min(nb, (budget_s / per_core) * cores)))
         threads = min(cores, sample)
-        wall, lens = ref.compress_blocks_mt(blocks[:sample], method, threads, deadline_s=budget_s)
+        wall, lens, archives = ref.compress_blocks_mt(blocks[:sample], method, threads, deadline_s=budget_s, keep=True)
         done = [i for i, v in enumerate(lens) if v >= 0]
         return {"value": len(done) * bs / 1e6 / wall, "unit": "MB/s", "cores": threads, "kind": "reference",
                 "sample": f"{len(done)} x {bs} B blocks of the same corpus, libzpaq::compressBlock(\"{method}\") "
                           f"(reference built -O3 with its x86 JIT) from a {threads}-thread work queue "
                           f"(nproc={os.cpu_count()}, usable={cores}); 1 thread alone: {bs / 1e6 / t1:.3f} MB/s",
-                "single_thread_MBps": bs / 1e6 / t1}, lens
+                "single_thread_MBps": bs / 1e6 / t1}, archives
     # fallback: our scalar C port, single thread, a slice of one block
     import zpaq_amd as z
     orc = Oracle()
@@ -115,11 +130,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU (weak scaling) or in total (--scaling strong)")
     ap.add_argument("--block-bytes", type=int, default=1 << 20)
-    ap.add_argument("--kind", default="text")
+    ap.add_argument("--kind", default="text", help="text | lcg | zeros | records | pattern | mixed (configs[3])")
     ap.add_argument("--method", default="5")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--api-blocks", type=int, default=-1,
+                    help="blocks of the end-to-end API leg on host buffers (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
     ap.add_argument("--verify-bytes", type=int, default=32768)
     ap.add_argument("--kernel", type=int, default=0)
@@ -146,26 +164,34 @@ def main():
     z.init(local)
     z.set_kernel(a.kernel)
 
-    nb, bs = a.blocks, a.block_bytes
+    bs = a.block_bytes
+    if a.scaling == "strong":
+        lo, hi = a.blocks * rank // world, a.blocks * (rank + 1) // world   # contiguous ranges (zpaq_amd.dist.shard_range)
+        nb, first = hi - lo, lo
+        total_blocks = a.blocks
+    else:
+        nb, first = a.blocks, rank * a.blocks
+        total_blocks = a.blocks * world
     dist_ms = {}
     if a.distribute and world > 1:
         from zpaq_amd import dist as zd
-        full = make_corpus(a.kind, nb * world, bs, first=0) if rank == 0 else None
+        full = make_corpus(a.kind, total_blocks, bs, first=0) if rank == 0 else None
         zd.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        mine = zd.scatter_blocks(full, nb * world, bs)
+        mine = zd.scatter_blocks(full, total_blocks, bs)
         torch.cuda.synchronize(); zd.barrier()
         dist_ms["scatter"] = (time.perf_counter() - t0) * 1e3
         blocks = mine.cpu().numpy()
+        nb = blocks.shape[0]
         del full
     elif a.kind == "text":
         # same bytes as corpus.zipf_text, generated on this rank's GPU (seconds instead of minutes of host time)
         from zpaq_amd import corpus, corpus_torch
-        d_blocks = corpus_torch.text_blocks(nb, bs, corpus.BASE_SEED + rank * nb, dev)
+        d_blocks = corpus_torch.text_blocks(nb, bs, corpus.BASE_SEED + first, dev)
         blocks = d_blocks.cpu().numpy()
         del d_blocks
         torch.cuda.empty_cache()
     else:
-        blocks = make_corpus(a.kind, nb, bs, first=rank * nb)
+        blocks = make_corpus(a.kind, nb, bs, first=first)
 
     # one plan per distinct header; the headline text corpus has exactly one
     headers = {}
@@ -184,6 +210,7 @@ def main():
     host_in = np.zeros((nb, stride_in), np.uint8)
     host_in[:, 1:bs + 1] = blocks
     d_in = torch.from_numpy(host_in).to(dev)
+    del host_in
     d_out = torch.empty((nb, stride_out), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((nb, 4), dtype=torch.int32, device=dev)
     L = z.lib()
@@ -201,7 +228,6 @@ def main():
     L.zpq_code_device_multi.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_int]
-
 
     def step():
         rc = L.zpq_code_device_multi(0, PA, C.c_void_p(d_in.data_ptr()), IO, IL, nb, C.c_void_p(d_out.data_ptr()),
@@ -270,6 +296,7 @@ def main():
         dec_ok = bool((r2h[:, 2] == 0).all() and (r2h[:, 0] == bs + 1).all() and
                       bool((back[:, :bs + 1] == d_in[:, :bs + 1]).all()))
         dec_info = {"elapsed": delapsed, "code_ms": dcode_ms, "ok": dec_ok}
+        del back
     if a.distribute and world > 1:
         from zpaq_amd import dist as zd
         host_out = d_out.cpu().numpy()
@@ -279,7 +306,7 @@ def main():
         zd.barrier()
         dist_ms["gather"] = (time.perf_counter() - t0) * 1e3
         if rank == 0:
-            assert len(allc) == nb * world
+            assert len(allc) == total_blocks
     ok = bool((status == 0).all())
     coded_total = int(out_len.sum())
 
@@ -309,67 +336,98 @@ def main():
             good = r2h[k, 2] == 0 and r2h[k, 0] == vb and bool((back[k, :vb] == d_in[k, :vb]).all())
             verified += int(good)
             ok = ok and good
+        del back, coded
 
-    # which kernel coded the blocks (3 = per-header specialised, 2 = generic wave, 1 = generic one-lane)
+    # which kernel coded the blocks (4 pipelined encoder, 3 per-header wavefront kernel, 2 generic wave, 1 generic one-lane)
     note = C.create_string_buffer(512)
-    kinds = sorted({int(L.zpq_plan_kernel_kind(pl._h, note, 512)) for pl, _ in groups})
-    kname = {4: "zpq_pipe_" + "mix", 3: "zpq_spec_" + "encode", 2: "code_wave_kernel<encode>",
-             1: "code_serial_kernel<encode>"}.get(kinds[-1], "?")
-    # HBM traffic per launch from the committed rocprofv3 PMC passes, when this exact workload was profiled
+    dec = 1 if a.mode == "decode" else 0
+    kinds = sorted({int(L.zpq_plan_kernel_kind2(pl._h, dec, note, 512)) for pl, _ in groups})
+    kname = {4: "zpq_pipe_{hcomp,rows,light,icm,isse,mix}: one launch of each per step, concurrent",
+             3: "zpq_spec_" + ("decode" if dec else "encode"), 2: "code_wave_kernel", 1: "code_serial_kernel"}.get(kinds[-1], "?")
+    origin = note.value.decode(errors="replace")
+    # HBM traffic per launch from the committed rocprofv3 PMC passes -- only when THIS workload was profiled with THIS
+    # code object (the cache key is part of kernel_origin); a stale entry is refused
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = f"method {a.method} x {nb} x {bs} {a.kind}"
-        if key in tj and tj[key]["kernel"] == kname:
+        key = f"method {a.method} x {nb} x {bs} {a.kind} {a.mode}"
+        if key in tj and tj[key].get("kernel_origin") == origin:
             traffic = tj[key]["traffic_bytes"]
     except Exception:
         pass
-    total_bytes = float(nb) * bs * world * a.steps
+    total_bytes = float(total_blocks) * bs * a.steps
     if dec_info:
         elapsed, code_ms, ok = dec_info["elapsed"], dec_info["code_ms"], ok and dec_info["ok"]
-        kname = kname.replace("encode", "decode")
-        traffic = None
     value = total_bytes / 1e6 / elapsed
-    code_s = code_ms / 1e3 / max(a.steps, 1)          # coding-kernel time per step (this rank)
+    code_s = code_ms / 1e3 / max(a.steps, 1)          # coding time per step (this rank)
     achieved = algo_bytes / 1e9 / code_s if code_s > 0 else 0.0
     line = {
         "metric": ("compress" if a.mode == "encode" else "decompress") +
                   " MB/s + bit-identical ratio, -m5 over 1024x1 MiB blocks",
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"method \"{a.method}\" x {nb} blocks x {bs} B '{a.kind}' per GPU "
-                               f"(BASELINE configs[2] when 1024 x 1 MiB text)",
-                   "blocks_per_gpu": nb, "block_bytes": bs, "corpus": a.kind, "method": a.method,
-                   "plans": len(groups), "ncomp": [g[0].ncomp for g in groups], "parallelism": f"blocks/{world}gpu",
-                   "state_GiB_per_gpu": state_bytes / 2 ** 30},
+        "config": {"workload": f"method \"{a.method}\" x {nb} blocks x {bs} B '{a.kind}' per GPU, {total_blocks} in total "
+                               f"(BASELINE configs[2] when 1024 x 1 MiB text on one GPU; configs[3] when 'mixed' on 8 GPUs)",
+                   "blocks_per_gpu": nb, "blocks_total": total_blocks, "block_bytes": bs, "corpus": a.kind,
+                   "method": a.method, "plans": len(groups), "ncomp": [g[0].ncomp for g in groups],
+                   "parallelism": f"blocks/{world}gpu", "state_GiB_per_gpu": state_bytes / 2 ** 30},
         "ratio": coded_total / (float(nb) * bs) if nb else None,
         "all_status_ok": ok, "roundtrip_verified_blocks": verified,
         "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
         "dist_ms": dist_ms or None,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kname, "kernel_origin": note.value.decode(errors="replace"),
+                     "kernel": kname, "kernel_origin": origin,
                      "algo_bytes_per_launch": algo_bytes, "kernel_s_per_launch": code_s},
     }
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
-        base, ref_lens = cpu_baseline(blocks, a.method, a.cpu_seconds)
-        line["cpu_baseline"] = base
-        if ref_lens is not None:
-            # archive length = prologue + coded + 4 + 21 + 1; prologue is identical, so lengths must agree
-            from oracle.oracle_py import Ref, parse_block
-            k = len(ref_lens)
-            ref = Ref()
-            a0 = ref.compress_block(blocks[0], a.method)
-            overhead = parse_block(a0)["payload_start"] + 4 + 21 + 1
-            done = [i for i in range(k) if ref_lens[i] >= 0]
-            same = all(int(ref_lens[i]) == int(out_len[i]) + overhead for i in done)
-            ps = parse_block(a0)["payload_start"]
-            ours0 = d_out[0, :int(out_len[0])].cpu().numpy().tobytes()
-            same = same and a0[ps:ps + len(ours0)] == ours0
-            line["cpu_baseline"]["bit_identical_vs_reference"] = bool(same)
-            line["cpu_baseline"]["compared_blocks"] = len(done)
-        line["vs_cpu"] = value / base["value"] if base["value"] else None
+    if rank == 0 and world == 1:
+        # coded payloads of the timed run, for the identity check against the reference
+        ncmp = min(nb, 512)
+        host_out = d_out[:ncmp].cpu().numpy()
+        del d_out
+        torch.cuda.empty_cache()
+        # ---- end-to-end through the drop-in API on host buffers (SURVEY 8(d)'s metric), outside the timed region ----
+        api_archives = None
+        napi = nb if a.api_blocks < 0 else min(a.api_blocks, nb)
+        if napi and a.mode == "encode":
+            t0 = time.perf_counter()
+            api_archives = z.compress_blocks([blocks[i] for i in range(napi)], a.method)
+            wall = time.perf_counter() - t0
+            ph = (C.c_double * 8)()
+            L.zpq_last_api_timing(ph)
+            line["api"] = {"value": napi * bs / 1e6 / (ph[0] / 1e3) if ph[0] else None, "unit": "MB/s", "blocks": napi,
+                           "what": "zpq_compress_blocks on host buffers: SHA-1 + method expansion + header assembly, "
+                                   "staging + H2D, Predictor init + coding kernels, D2H, archive framing",
+                           "ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3],
+                                  "kernel_init": ph[4], "kernel_code": ph[5], "python_wall": wall * 1e3}}
+        if a.cpu_seconds > 0:
+            base, ref_arch = cpu_baseline(blocks, a.method, a.cpu_seconds)
+            line["cpu_baseline"] = base
+            if ref_arch is not None:
+                # every archive the reference produced against ours, by SHA-1: the whole archive where the API leg made
+                # one, and the coded payload of the TIMED device-resident run against the reference archive's payload
+                from oracle.oracle_py import parse_block
+                done = [i for i, x in enumerate(ref_arch) if x is not None]
+                whole = payload = 0
+                same = True
+                for i in done:
+                    if api_archives is not None and i < len(api_archives):
+                        same = same and hashlib.sha1(ref_arch[i]).digest() == hashlib.sha1(api_archives[i]).digest()
+                        whole += 1
+                    if i < ncmp:
+                        ps = parse_block(ref_arch[i])["payload_start"]
+                        n = int(out_len[i])
+                        same = same and (hashlib.sha1(ref_arch[i][ps:ps + n + 4]).digest() ==
+                                         hashlib.sha1(host_out[i, :n].tobytes() + b"\0\0\0\0").digest())
+                        payload += 1
+                line["cpu_baseline"]["bit_identical_vs_reference"] = bool(same)
+                line["cpu_baseline"]["compared_blocks"] = len(done)
+                line["cpu_baseline"]["compared_how"] = (f"SHA-1 of the whole archive (API leg): {whole} blocks; SHA-1 of the "
+                                                        f"coded payload + terminator of the timed run: {payload} blocks")
+            line["vs_cpu"] = value / base["value"] if base["value"] else None
+        else:
+            line["cpu_baseline"] = None
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

@@ -202,6 +202,7 @@ class Decompresser {
   size_t payload_end_;
   bool seg_decoded_;
   int segs_in_block_;
+  void* pp_;                 // PostProcessor of the current block (first segment carries the PP header)
   enum { BLOCK, FILENAME, COMMENT, DATA, SEGEND } state_;
 };
 
@@ -215,7 +216,7 @@ class Compressor {
   void startBlock(int level);                 // built-in models 1..3 (min/mid/max)
   void startBlock(const char* hcomp);         // stored header bytes
   void startBlock(const char* config, int* args, Writer* pcomp_cmd = 0);   // ZPAQL source
-  void setVerify(bool) {}
+  void setVerify(bool v) { verify_ = v; }     // endSegmentChecksum() then hashes the post-processed input
   void hcomp(Writer* out2);
   bool pcomp(Writer* out2);
   void startSegment(const char* filename = 0, const char* comment = 0);
@@ -237,6 +238,8 @@ class Compressor {
   std::vector<U8> pending_;   // PP header + segment bytes awaiting the device
   SHA1 seg_sha1_;
   char sha1result_[20];
+  bool verify_;
+  void* pp_;                  // verify mode: PostProcessor fed with what the decompresser will see
   int segs_;
   enum { INIT, BLOCK1, SEG1, BLOCK2, SEG2 } state_;
 };

@@ -161,6 +161,11 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
 /* Durations (ms, hipEvent) of the last timed call on this process: Predictor
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
+/* Wall-clock phases (ms) of this process's last zpq_compress_blocks call -- the end-to-end path through the
+ * drop-in API: out[0] total, [1] host front half (SHA-1, method expansion, header assembly), [2] device call
+ * (staging + H2D + kernels + D2H), [3] archive stitching, [4] / [5] the Predictor-init and coding kernels inside
+ * [2] (hipEvents), [6] blocks. */
+int zpq_last_api_timing(double out[8]);
 /* Runs a tiny kernel exercising the cross-lane idioms (DPP reduction, readlane,
  * bpermute); out8[0..5] must equal {2016, 21344, 123, 2016, 133, 13671}. */
 int zpq_selftest(int32_t out8[8]);

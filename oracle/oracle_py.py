@@ -149,16 +149,22 @@ class Ref:
         a = _bytes_arr(archive)
         return float(self.lib.ref_block_memory(_ptr(a), a.size))
 
-    def compress_blocks_mt(self, blocks: np.ndarray, method, nthreads: int, deadline_s: float = 0.0):
+    def compress_blocks_mt(self, blocks: np.ndarray, method, nthreads: int, deadline_s: float = 0.0, keep: bool = False):
         """blocks [nblocks, block_bytes] uint8 -> (wall seconds, archive sizes; -2 = not started
-        because deadline_s had passed)."""
+        because deadline_s had passed); keep=True also returns the archives (list of bytes / None)."""
         blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
         nb, bs = blocks.shape
         lens = (C.c_longlong * nb)()
+        out = stride = None
+        if keep:
+            stride = bs + bs // 2 + 4096
+            out = np.empty((nb, stride), np.uint8)
         s = self.lib.ref_compress_blocks_mt(_ptr(blocks), bs, nb, self._s(method), int(nthreads),
-                                            lens, None, 0, float(deadline_s))
+                                            lens, _ptr(out) if keep else None, stride or 0, float(deadline_s))
         if s < 0:
             raise self._err()
+        if keep:
+            return s, list(lens), [out[b, :lens[b]].tobytes() if 0 <= lens[b] <= stride else None for b in range(nb)]
         return s, list(lens)
 
 
@@ -237,6 +243,22 @@ class Oracle:
         if r > out.size:
             return self.decode(header, coded, int(r))
         return out[:r].tobytes(), used.value
+
+    def decode_outcome(self, header, coded, cap):
+        """Decoder::decompress on a possibly damaged stream -> (status, bytes): status 0 with the decoded bytes, or
+        2 ("archive corrupted", libzpaq.cpp:2108 / 2134) / 6 ("unexpected end of file", 2120) with b""."""
+        h = _bytes_arr(header)
+        c = _bytes_arr(coded)
+        out = np.empty(max(cap, 1), np.uint8)
+        used = C.c_size_t(0)
+        r = self.lib.zo_decode(_ptr(h), h.size, _ptr(c), c.size, _ptr(out), out.size, C.byref(used))
+        if r == -3:
+            return 2, b""
+        if r == -6:
+            return 6, b""
+        if r < 0:
+            raise RuntimeError(f"zo_decode failed: {r}")
+        return 0, out[:min(r, out.size)].tobytes()
 
     def hcomp_trace(self, header, data, ncomp) -> np.ndarray:
         h = _bytes_arr(header)

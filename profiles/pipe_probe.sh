@@ -12,13 +12,9 @@ except Exception as e:
 "
 }
 python profiles/pipe_probe.py
+run "X=1" 1024 65536
 run "ZPAQ_AMD_PIPE_GROUP=64" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=32" 1024 65536
 run "ZPAQ_AMD_PIPE_GROUP=16" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=32 ZPAQ_AMD_PIPE_CHUNK=256" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=32 ZPAQ_AMD_PIPE_CHUNK=1024" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=32" 2048 65536
-for G in 32; do
-ZPAQ_AMD_PIPE_GROUP=$G ZPAQ_AMD_PIPE_PROFILE=1 python bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --verify-blocks 0 2>&1 | grep "pipe profile" | awk -v G=$G '{k=$4; t[k]+=$7; n[k]+=1; if ($7>m[k]) m[k]=$7} END {for (k in t) printf "G=%s alone: %-6s units=%d avg=%.3f max=%.3f ms/step\n", G, k, n[k], t[k]/n[k], m[k]}'
-ZPAQ_AMD_PIPE_GROUP=$G ZPAQ_AMD_PIPE_PROFILE=1 python bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --verify-blocks 0 2>&1 | grep "pipe profile" | grep light
-done
+run "X=1" 2048 65536
+run "X=1" 1024 1048576
+ZPAQ_AMD_PIPE_PROFILE=1 python bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --verify-blocks 0 2>&1 | grep "pipe profile" | awk '{k=$4; t[k]+=$7; n[k]+=1; if ($7>m[k]) m[k]=$7} END {for (k in t) printf "alone: %-6s units=%d avg=%.3f max=%.3f ms/step\n", k, n[k], t[k]/n[k], m[k]}'

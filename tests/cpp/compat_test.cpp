@@ -1,11 +1,16 @@
 // Exercises the libzpaq-compatible C++ API (include/libzpaq.h) the way a libzpaq caller would.
-//   compat_test host   : only paths that need no GPU (stored blocks, container logic, SHA1, errors)
-//   compat_test gpu    : everything, including the modelled methods
+//   compat_test host [hdr1 hdr2 hdr3] : only paths that need no GPU (stored blocks, container logic, SHA1, errors);
+//                                       hdrN = expected header bytes (hex) of Compressor::startBlock(N)
+//   compat_test gpu                   : everything, including the modelled methods
+//   compat_test level N in out        : Compressor::startBlock(N) over file `in` (one segment, SHA-1) -> file `out`
+//   compat_test threads T method      : T threads, one libzpaq::compressBlock each, like zpaq.cpp's compressThread pool
 // Prints "COMPAT_OK <n checks>" on success.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "libzpaq.h"
@@ -37,9 +42,99 @@ static std::string roundtrip_stream(const std::string& data, const char* method)
   return std::string(out.c_str() ? out.c_str() : "", out.size());
 }
 
+// a Reader that counts what the library pulled from it (Decompresser::buffered() gives back the read-ahead)
+struct CountingReader : public libzpaq::Reader {
+  const std::string& s;
+  size_t pos = 0;
+  explicit CountingReader(const std::string& s_) : s(s_) {}
+  int get() override { return pos < s.size() ? (unsigned char)s[pos++] : -1; }
+  int read(char* buf, int n) override {
+    size_t k = s.size() - pos;
+    if ((size_t)n < k) k = (size_t)n;
+    memcpy(buf, s.data() + pos, k);
+    pos += k;
+    return (int)k;
+  }
+};
+
+static std::string slurp(const char* path) {
+  std::string s;
+  FILE* f = fopen(path, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  char buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+  fclose(f);
+  return s;
+}
+
+static std::string hex(const std::string& b) {
+  static const char* d = "0123456789abcdef";
+  std::string h;
+  for (unsigned char c : b) { h += d[c >> 4]; h += d[c & 15]; }
+  return h;
+}
+
 int main(int argc, char** argv) {
-  const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
+  const std::string mode = argc > 1 ? argv[1] : "host";
+  const bool gpu = mode == "gpu";
   try {
+    if (mode == "level") {         // built-in model N over a file, the way oracle/ref_shim.cpp drives the reference
+      const std::string data = slurp(argv[3]);
+      libzpaq::StringBuffer in, arc;
+      in.write(data.data(), (int)data.size());
+      libzpaq::Compressor co;
+      co.setOutput(&arc);
+      co.setInput(&in);
+      co.writeTag();
+      co.startBlock(atoi(argv[2]));
+      co.startSegment(argc > 5 ? argv[5] : 0, argc > 6 ? argv[6] : 0);
+      co.compress(-1);
+      libzpaq::SHA1 s;
+      s.write(data.data(), (int64_t)data.size());
+      co.endSegment(s.result());
+      co.endBlock();
+      FILE* f = fopen(argv[4], "wb");
+      fwrite(arc.c_str(), 1, arc.size(), f);
+      fclose(f);
+      printf("COMPAT_OK 1\n");
+      return 0;
+    }
+    if (mode == "threads") {       // concurrent callers, each with its own buffers (libzpaq.h:57-59)
+      const int T = atoi(argv[2]);
+      const char* method = argv[3];
+      std::vector<std::string> data(T), alone(T), together(T);
+      for (int i = 0; i < T; ++i) data[i] = text(30000 + 997 * i, 500 + i);
+      auto one = [&](int i, std::string& out) {
+        libzpaq::StringBuffer in, arc;
+        in.write(data[i].data(), (int)data[i].size());
+        libzpaq::compressBlock(&in, &arc, method, "f", 0, true);
+        out.assign(arc.c_str(), arc.size());
+      };
+      auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 2; ++i) one(i, alone[i]);
+      const double t_two = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      for (int i = 2; i < T; ++i) one(i, alone[i]);
+      t0 = std::chrono::steady_clock::now();
+      std::vector<std::thread> th;
+      std::vector<std::string> errs(T);
+      for (int i = 0; i < T; ++i)
+        th.emplace_back([&, i] { try { one(i, together[i]); } catch (std::exception& e) { errs[i] = e.what(); } });
+      for (auto& t : th) t.join();
+      const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      for (int i = 0; i < T; ++i) { CHECK(errs[i].empty()); CHECK(together[i] == alone[i]); }
+      // T concurrent callers must cost about ONE batch, not T launches one after the other
+      printf("threads=%d serial_per_block=%.3fs concurrent_total=%.3fs\n", T, t_two / 2, t_all);
+      CHECK(t_all < 0.35 * T * (t_two / 2) + 1.0);
+      libzpaq::StringBuffer all, out;
+      for (int i = 0; i < T; ++i) all.write(together[i].data(), (int)together[i].size());
+      libzpaq::decompress(&all, &out);
+      std::string want;
+      for (int i = 0; i < T; ++i) want += data[i];
+      CHECK(std::string(out.c_str(), out.size()) == want);
+      printf("COMPAT_OK %d\n", checks);
+      return 0;
+    }
     // SHA1
     libzpaq::SHA1 sha;
     sha.write("abc", 3);
@@ -94,12 +189,119 @@ int main(int argc, char** argv) {
       CHECK(sh[0] == 0);
       fn.reset(); CHECK(de.findFilename(&fn));
       de.readComment();
-      de.readSegmentEnd(sh);                 // skip the second segment without decoding it
+      // the second segment of the block carries no PP header of its own (the PostProcessor is per block)
+      libzpaq::StringBuffer out2;
+      libzpaq::SHA1 hd;
+      de.setOutput(&out2);
+      de.setSHA1(&hd);
+      de.decompress(-1);
+      CHECK(out2.size() == 2000 && memcmp(out2.c_str(), d0.data() + 1000, 2000) == 0);
+      de.readSegmentEnd(sh);
       CHECK(sh[0] == 1);
-      libzpaq::SHA1 h3; h3.write(d0.data() + 1000, 2000);
-      CHECK(memcmp(sh + 1, h3.result(), 20) == 0);
+      CHECK(memcmp(sh + 1, hd.result(), 20) == 0);
       CHECK(!de.findFilename());
       CHECK(!de.findBlock());
+    }
+    {
+      // the same archive again, second segment skipped without decoding (Decoder::skip)
+      libzpaq::StringBuffer arc, s1;
+      s1.write(d0.data(), 3000);
+      libzpaq::compress(&s1, &arc, "0");
+      libzpaq::Decompresser de;
+      de.setInput(&arc);
+      CHECK(de.findBlock());
+      CHECK(de.findFilename());
+      de.readComment();
+      char sh[21];
+      de.readSegmentEnd(sh);
+      CHECK(sh[0] == 1);
+      libzpaq::SHA1 h3; h3.write(d0.data(), 3000);
+      CHECK(memcmp(sh + 1, h3.result(), 20) == 0);
+    }
+
+    // built-in models: Compressor::startBlock(1|2|3) writes the reference's header bytes (libzpaq.cpp:2796-2822)
+    for (int level = 1; level <= 3 && argc >= 5; ++level) {
+      libzpaq::StringBuffer arc;
+      libzpaq::Compressor co;
+      co.setOutput(&arc);
+      co.startBlock(level);
+      const std::string got(arc.c_str(), arc.size());
+      CHECK(got.size() > 5 && got.substr(0, 3) == "zPQ" && got[3] == 1 && got[4] == 1);
+      CHECK(hex(got.substr(5)) == argv[1 + level]);
+    }
+    {
+      bool bad = false;
+      try { libzpaq::StringBuffer b; libzpaq::Compressor c; c.setOutput(&b); c.startBlock(4); } catch (std::runtime_error&) { bad = true; }
+      CHECK(bad);
+    }
+
+    // Decompresser::buffered(): the library reads ahead in 64 KiB pieces; callers recover the true archive offset
+    // as (bytes handed out by the Reader) - buffered() (zpaq.cpp:1474, 1631)
+    {
+      std::string arc;
+      std::vector<size_t> ends;
+      for (int i = 0; i < 3; ++i) {
+        libzpaq::StringBuffer in, a1;
+        const std::string d = text(5000 + 40000 * i, 30 + i);
+        in.write(d.data(), (int)d.size());
+        libzpaq::compress(&in, &a1, "0", "f", 0);
+        arc.append(a1.c_str(), a1.size());
+        ends.push_back(arc.size());
+      }
+      CountingReader rd(arc);
+      libzpaq::Decompresser de;
+      de.setInput(&rd);
+      size_t nblocks = 0;
+      while (de.findBlock()) {
+        while (de.findFilename()) {
+          de.readComment();
+          libzpaq::StringBuffer out;
+          de.setOutput(&out);
+          de.decompress(-1);
+          de.readSegmentEnd();
+        }
+        // one block done (the 255 end-of-block byte was consumed): offset must be exactly at a block end
+        bool at_end = false;
+        for (size_t e : ends) at_end = at_end || rd.pos - (size_t)de.buffered() == e;
+        CHECK(at_end);
+        ++nblocks;
+      }
+      CHECK(nblocks >= 3);
+    }
+
+    // PCOMP on a stored block: the program travels in the first segment, Decompresser::pcomp() hands it back,
+    // Compressor::setVerify(true) + endSegmentChecksum() report the SHA-1 of what the decompresser will produce
+    {
+      const char* cfg = "comp 0 0 0 0 0 hcomp pcomp nothing ; a> 255 if halt endif a++ out halt end\n";
+      libzpaq::StringBuffer arc, src, pc1, pc2, out;
+      src.write("HAL", 3);
+      libzpaq::Compressor co;
+      co.setOutput(&arc);
+      co.setInput(&src);
+      co.setVerify(true);
+      co.writeTag();
+      co.startBlock(cfg, 0);
+      CHECK(co.pcomp(&pc1));
+      co.startSegment("x", 0);
+      co.compress(-1);
+      int64_t usize = -1;
+      char* sum = co.endSegmentChecksum(&usize, true);
+      co.endBlock();
+      libzpaq::SHA1 want; want.write("IBM", 3);
+      CHECK(sum && usize == 3 && memcmp(sum, want.result(), 20) == 0);
+      libzpaq::Decompresser de;
+      de.setInput(&arc);
+      CHECK(de.findBlock());
+      CHECK(de.findFilename());
+      de.readComment();
+      de.setOutput(&out);
+      de.decompress(-1);
+      CHECK(std::string(out.c_str(), out.size()) == "IBM");
+      CHECK(de.pcomp(&pc2));
+      CHECK(pc2.size() == pc1.size() && memcmp(pc1.c_str(), pc2.c_str(), pc1.size()) == 0);
+      char sh[21];
+      de.readSegmentEnd(sh);
+      CHECK(sh[0] == 1 && memcmp(sh + 1, sum, 20) == 0);
     }
 
     // error() contract: bad method / bad config must call error(), which throws here

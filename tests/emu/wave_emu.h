@@ -87,6 +87,8 @@ static inline int __mul24(int a, int b) {
   return (int)((unsigned)x * (unsigned)y);
 }
 
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+
 // v_mov_b32_dpp semantics (gfx9): returns the new value of the destination whose previous content is `old`
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const int* v = emu::wave_exchange(src);

@@ -18,9 +18,10 @@ def _build(tmp_path):
     return exe
 
 
-def test_cpp_api_host_paths(tmp_path, zlib_):
+def test_cpp_api_host_paths(tmp_path, zlib_, golden):
     exe = _build(tmp_path)
-    r = subprocess.run([exe, "host"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    hdrs = [e["header"] for e in golden["level_cases"]]      # headers the reference wrote for startBlock(1|2|3)
+    r = subprocess.run([exe, "host", *hdrs], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
 
 
@@ -28,4 +29,31 @@ def test_cpp_api_host_paths(tmp_path, zlib_):
 def test_cpp_api_on_gpu(tmp_path, gpu):
     exe = _build(tmp_path)
     r = subprocess.run([exe, "gpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_builtin_models_through_our_startblock(tmp_path, gpu, golden):
+    """Compressor::startBlock(1|2|3) (min / mid / max.cfg) through OUR Compressor: the whole archive must be the
+    one the reference produced for the same input (golden level_cases were made by the reference)."""
+    import base64
+    from conftest import gen_input
+    exe = _build(tmp_path)
+    for level, e in enumerate(golden["level_cases"], start=1):
+        src, dst = str(tmp_path / f"in{level}"), str(tmp_path / f"out{level}")
+        open(src, "wb").write(gen_input(e).tobytes())
+        args = [exe, "level", str(level), src, dst]
+        if e.get("filename") or e.get("comment"):
+            args += [e.get("filename") or "", e.get("comment") or ""]
+        r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
+        assert open(dst, "rb").read() == base64.b64decode(e["archive_b64"]), level
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_are_coalesced(tmp_path, gpu):
+    """32 threads, one libzpaq::compressBlock(.., "5") each, as zpaq.cpp's compressThread pool does: archives
+    identical to the serial ones, and the whole thing takes about one batch, not 32 launches in a row."""
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "threads", "32", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout

@@ -103,3 +103,80 @@ def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle):
     assert g2_st == 0 and g2_out == d
     (p_out, p_st, p_used), = emu.run(header, [good], decode=True, waves=4, out_cap=701)
     assert p_st == 0 and p_used == 0 and p_out == d[:701]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h): the same generated source the GPU runs, executed
+# step by step on the host with consumers launched BEFORE producers inside a step (tests/emu/pipe_emu_main.cpp).
+
+def _pipe_check(oracle, header, inputs, **kw):
+    res = emu.pipe_run(header, inputs, **kw)
+    for i, (inp, (coded, status, consumed)) in enumerate(zip(inputs, res)):
+        assert status == 0 and consumed == len(inp), (i, status)
+        assert coded == oracle.encode(header, inp), i
+
+
+def test_pipe_encoder_standard_chains(zlib_, oracle):
+    """-m4 / -m5 chains, ragged blocks incl. empty and one-byte inputs, several chunks per block, more blocks than
+    one group, and every workgroup width the generator supports."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    h4, _, _ = zlib_.method_to_header(zlib_.expand_method("4", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    _pipe_check(oracle, h5, ragged + [b""], chunk=64)
+    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64)
+    _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16)
+
+
+def test_pipe_encoder_every_component_type_and_legacy_models(oracle, golden):
+    seen = set()
+    for e in [golden["config_cases"][0]] + golden["level_cases"] + golden["vm_cases"][:4]:
+        header = bytes.fromhex(e["header"])
+        if header in seen or not header[6] or header[6] > 64:
+            continue
+        seen.add(header)
+        d = gen_input(e).tobytes()
+        if len(d) < 64:
+            d = corpus.block("records", 600, 3).tobytes()
+        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64)
+    assert len(seen) >= 6
+
+
+PIPE_STRESS_CFG = """
+comp 3 8 0 0 9
+  0 icm 1
+  1 isse 2 0
+  2 cm 9 255
+  3 cm 10 8
+  4 match 8 10
+  5 mix2 8 0 1 24 255
+  6 mix 8 0 6 24 255
+  7 sse 8 6 32 255
+  8 mix2 9 7 6 16 255
+hcomp
+  c++ *c=a b=c
+  d= 0 *d=a
+  d++ a=*b a>>= 1 *d=a
+  d++ a=*b a<<= 1 *d=a
+  d++ b-- a=*b a+=*c *d=a
+  d++ hash *d=a
+  d++ a=*c a>>= 6 *d=a
+  d++ a=*c a>>= 2 *d=a
+  d++ a=*c a>>= 3 *d=a
+  d++ a=*c a<<= 1 *d=a
+  halt
+end
+"""
+
+
+def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
+    """The units fetch the next byte's table words before they store this byte's.  Tiny tables and contexts that
+    move by little from byte to byte take every aliasing path: same context (forwarding by bit position), contexts
+    closer than the address range of a byte (fetch after the stores), hash rows sharing a 64-byte line."""
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
+             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
+    _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64)

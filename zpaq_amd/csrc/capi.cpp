@@ -289,6 +289,14 @@ int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hc
   ZPQ_CATCH
 }
 
+int zpq_last_api_timing(double out[8]) {
+  if (!out) return ZPQ_E_ARG;
+  const ApiTiming t = last_api_timing();
+  out[0] = t.total_ms; out[1] = t.front_ms; out[2] = t.device_ms; out[3] = t.stitch_ms;
+  out[4] = t.kernel_init_ms; out[5] = t.kernel_code_ms; out[6] = (double)t.blocks; out[7] = 0;
+  return ZPQ_OK;
+}
+
 size_t zpq_table(int which, void* out, size_t cap) {
   try {
     const Tables& t = tables();

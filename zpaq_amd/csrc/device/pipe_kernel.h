@@ -304,23 +304,34 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
   constexpr CompK c = Chain::comp[I];
   constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
   constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I];
-  constexpr bool touch = rmask >= (1u << 18) - 1u;       // tables of 256 KiB and more: pull the next byte's lines early
   if (!L.nb) return;
+  // candidate rows of a byte's two nibbles (c8 = 1, c8 = 16 + high nibble): three 16-byte rows inside one 64-byte line each
+  auto lines = [&](unsigned hh, unsigned bytev, unsigned& ha, unsigned& hb) __attribute__((always_inline)) {
+    ha = ((hh + 16u) * 16u) & (rmask - 15u);
+    hb = ((hh + 16u * (16u + (bytev >> 4))) * 16u) & (rmask - 15u);
+  };
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-  unsigned ta = 0, tb2 = 0;
+  unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  unsigned ha, hb;
+  lines(h, byte, ha, hb);
+  uint4 a0 = L.A128(ht + ha), a1 = L.A128(ht + (ha ^ 16u)), a2 = L.A128(ht + (ha ^ 32u));
+  uint4 b0 = L.A128(ht + hb), b1 = L.A128(ht + (hb ^ 16u)), b2 = L.A128(ht + (hb ^ 32u));
   for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
-    // candidate rows of both nibbles (c8 = 1, c8 = 16 + high nibble), three per 64-byte line
-    const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
-    const unsigned ha = (cxa * 16u) & (rmask - 15u), hb = (cxb * 16u) & (rmask - 15u);
-    const uint4 a0 = L.A128(ht + ha), a1 = L.A128(ht + (ha ^ 16u)), a2 = L.A128(ht + (ha ^ 32u));
-    uint4 b0 = L.A128(ht + hb), b1 = L.A128(ht + (hb ^ 16u)), b2 = L.A128(ht + (hb ^ 32u));
-    if constexpr (touch) {
-      ZPQ_KEEP2(ta, tb2);
-      ta = L.A32(ht + (((hn + 16u) * 16u) & (rmask - 15u)));
-      tb2 = L.A32(ht + (((hn + 16u * (16u + (byten >> 4))) * 16u) & (rmask - 15u)));
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);          // streams run two bytes ahead ...
+    // ... the table one byte ahead: the next byte's six candidates are fetched before this byte's two rows are
+    // written back, unless they share a 64-byte line with them (then they are fetched after the stores)
+    unsigned han, hbn;
+    lines(h1, byte1, han, hbn);
+    const unsigned la = ha & ~63u, lb = hb & ~63u, lan = han & ~63u, lbn = hbn & ~63u;
+    const bool clash = lan == la || lan == lb || lbn == la || lbn == lb;
+    uint4 na0 = a0, na1 = a1, na2 = a2, nb0 = b0, nb1 = b1, nb2 = b2;
+    if (!clash) {
+      na0 = L.A128(ht + han); na1 = L.A128(ht + (han ^ 16u)); na2 = L.A128(ht + (han ^ 32u));
+      nb0 = L.A128(ht + hbn); nb1 = L.A128(ht + (hbn ^ 16u)); nb2 = L.A128(ht + (hbn ^ 32u));
     }
+    const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
     PipeRow ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
     uint2 o;
     o.x = pipe_row_bits(ra, byte >> 4, ns);
@@ -334,9 +345,14 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     o.y = pipe_row_bits(rb, byte & 15u, ns);
     L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
     L.bh(ri, k) = o;
-    h = hn; byte = byten;
+    if (clash) {
+      na0 = L.A128(ht + han); na1 = L.A128(ht + (han ^ 16u)); na2 = L.A128(ht + (han ^ 32u));
+      nb0 = L.A128(ht + hbn); nb1 = L.A128(ht + (hbn ^ 16u)); nb2 = L.A128(ht + (hbn ^ 32u));
+    }
+    a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
+    ha = han; hb = hbn;
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
-  if constexpr (touch) ZPQ_KEEP2(ta, tb2);
 }
 
 // CONS: a constant stream, so that consumers need no special case
@@ -351,36 +367,53 @@ template <class Chain, int I, class DT>
 __device__ __forceinline__ void pipe_cm(PipeLane<Chain>& L, const PipeStretch& stretch, const DT& dt) {
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I];
-  constexpr bool batch = c.mask0 >= 511u;      // the 8 words of a byte are distinct: fetch them together
-  constexpr bool touch = c.mask0 >= (1u << 16) - 1u;
+  constexpr bool batch = c.mask0 >= 511u;      // the 8 words of a byte are distinct: fetch them together, a byte ahead
   if (!L.nb) return;
+  auto addr = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * ((hh ^ pipe_hmap4(bytev, B)) & c.mask0);
+  };
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-  unsigned ta = 0, tb2 = 0;
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
-    unsigned v[8];
-    if constexpr (batch) {
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  unsigned v[8];
+  if constexpr (batch) {
 #pragma unroll
-      for (int B = 0; B < 8; ++B) v[B] = L.A32((unsigned)c.t0 + 4u * ((h ^ pipe_hmap4(byte, B)) & c.mask0));
-    }
-    if constexpr (touch) {
-      ZPQ_KEEP2(ta, tb2);
-      ta = L.A32((unsigned)c.t0 + 4u * ((hn ^ 1u) & c.mask0));
-      tb2 = L.A32((unsigned)c.t0 + 4u * ((hn ^ pipe_hmap4(byten, 4)) & c.mask0));
+    for (int B = 0; B < 8; ++B) v[B] = L.A32(addr(h, byte, B));
+  }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    // Words of the next byte: same context -> only equal bit positions can coincide (the hmap4 ranges of different
+    // positions are disjoint), forwarded below; contexts differing in the bits hmap4 covers -> fetched after the stores
+    const bool same = h1 == h;
+    const bool late = !same && (((h1 ^ h) & c.mask0) < 512u);
+    unsigned vn[8], nv[8];
+    if constexpr (batch) {
+      if (!late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) vn[B] = L.A32(addr(h1, byte1, B));
+      }
     }
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
-      const unsigned off = (unsigned)c.t0 + 4u * ((h ^ pipe_hmap4(byte, B)) & c.mask0);
+      const unsigned off = addr(h, byte, B);
       if constexpr (!batch) v[B] = L.A32(off);
       out.set(B, stretch(v[B] >> 17));
-      L.A32(off) = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+      nv[B] = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+      L.A32(off) = nv[B];
     }
     L.p(I, k) = out.get();
-    h = hn; byte = byten;
+    if constexpr (batch) {
+      if (late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) vn[B] = L.A32(addr(h1, byte1, B));
+      }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) v[B] = (same && addr(h1, byte1, B) == addr(h, byte, B)) ? nv[B] : vn[B];
+    }
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
-  if constexpr (touch) ZPQ_KEEP2(ta, tb2);
 }
 
 // MATCH (libzpaq.cpp:1883-1892, 1985-2008): length / offset / position live in registers, the predicted byte is
@@ -441,7 +474,7 @@ __device__ __forceinline__ void pipe_avg(PipeLane<Chain>& L) {
     const uint4 vj = L.p((int)c.a1, k), vk = L.p((int)c.a2, k);
     PipeP8 out;
 #pragma unroll
-    for (int B = 0; B < 8; ++B) out.set(B, (pipe_p_get(vj, B) * (int)c.a3 + pipe_p_get(vk, B) * (256 - (int)c.a3)) >> 8);
+    for (int B = 0; B < 8; ++B) out.set(B, (__mul24(pipe_p_get(vj, B), (int)c.a3) + __mul24(pipe_p_get(vk, B), 256 - (int)c.a3)) >> 8);
     L.p(I, k) = out.get();
   }
 }
@@ -452,35 +485,61 @@ __device__ __forceinline__ void pipe_mix2(PipeLane<Chain>& L, const PipeSquash& 
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I];
   constexpr bool single = c.mask0 == 0u;                          // one weight: it stays in a register
-  constexpr bool batch = !single && c.a5 == 255u && c.mask0 >= 255u;
+  constexpr bool batch = !single && c.a5 == 255u && c.mask0 >= 255u;   // the 8 weights of a byte are distinct
   if (!L.nb) return;
+  auto addr = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * ((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0);
+  };
   unsigned wreg = 0;
   if constexpr (single) wreg = L.A32((unsigned)c.t0);
   unsigned h = single ? 0u : (unsigned)L.ctx(ci, 0), byte = L.byte_at(0);
+  const unsigned k1 = L.next(0);
+  unsigned h1 = single ? 0u : (unsigned)L.ctx(ci, k1), byte1 = L.byte_at(k1);
   uint4 vj = L.p((int)c.a2, 0), vk = L.p((int)c.a3, 0);
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned hn = single ? 0u : (unsigned)L.ctx(ci, kn), byten = L.byte_at(kn);
-    const uint4 vjn = L.p((int)c.a2, kn), vkn = L.p((int)c.a3, kn);
-    unsigned v[8];
-    if constexpr (batch) {
+  uint4 vj1 = L.p((int)c.a2, k1), vk1 = L.p((int)c.a3, k1);
+  unsigned v[8];
+  if constexpr (batch) {
 #pragma unroll
-      for (int B = 0; B < 8; ++B) v[B] = L.A32((unsigned)c.t0 + 4u * ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0));
+    for (int B = 0; B < 8; ++B) v[B] = L.A32(addr(h, byte, B));
+  }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = single ? 0u : (unsigned)L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    const uint4 vj2 = L.p((int)c.a2, k2), vk2 = L.p((int)c.a3, k2);
+    // next byte's weights: same context -> only equal bit positions coincide (c8 ranges are disjoint), forwarded;
+    // contexts less than 256 apart -> any position may coincide: fetched after the stores
+    const bool same = h1 == h;
+    const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
+    unsigned vn[8], nv[8];
+    if constexpr (batch) {
+      if (!late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) vn[B] = L.A32(addr(h1, byte1, B));
+      }
     }
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
-      const unsigned off = (unsigned)c.t0 + 4u * ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0);
+      const unsigned off = addr(h, byte, B);
       const int w = (int)(single ? wreg : (batch ? v[B] : (unsigned)L.A32(off)));
       const int pj = pipe_p_get(vj, B), pk = pipe_p_get(vk, B);
-      const int pr = (w * pj + (65536 - w) * pk) >> 16;
+      const int pr = (__mul24(w, pj) + __mul24(65536 - w, pk)) >> 16;   // 17-bit x 12-bit
       out.set(B, pr);
-      const int err = ((pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr))) * (int)c.a4) >> 5;
-      const int nw = min(max(w + ((err * (pj - pk) + (1 << 12)) >> 13), 0), 65535);
-      if constexpr (single) wreg = (unsigned)nw; else L.A32(off) = (unsigned)nw;
+      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
+      nv[B] = (unsigned)min(max(w + ((__mul24(err, pj - pk) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
+      if constexpr (single) wreg = nv[B]; else L.A32(off) = nv[B];
     }
     L.p(I, k) = out.get();
-    h = hn; byte = byten; vj = vjn; vk = vkn;
+    if constexpr (batch) {
+      if (late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) vn[B] = L.A32(addr(h1, byte1, B));
+      }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) v[B] = (same && addr(h1, byte1, B) == addr(h, byte, B)) ? nv[B] : vn[B];
+    }
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+    vj = vj1; vk = vk1; vj1 = vj2; vk1 = vk2;
   }
   if constexpr (single) L.A32((unsigned)c.t0) = wreg;
 }
@@ -491,33 +550,49 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I];
   constexpr bool batch = c.mask0 >= 32u * 256u - 1u;               // the 8 rows of a byte are distinct
-  constexpr bool touch = batch && c.mask0 >= (1u << 16) - 1u;
+  constexpr unsigned rowmask = c.mask0 >> 5;                         // rows of 32 entries
   if (!L.nb) return;
+  // entry pair read for bit B: index of the lower one and the interpolation weight (libzpaq.cpp:1935-1939)
+  auto index = [&](unsigned hh, unsigned bytev, const uint4& pv, int B, int& wt) __attribute__((always_inline)) -> unsigned {
+    int pq = pipe_p_get(pv, B) + 992;
+    pq = min(max(pq, 0), 1983);
+    wt = pq & 63;
+    return (((hh + pipe_c8(bytev, B)) * 32u) & c.mask0) + (unsigned)(pq >> 6);
+  };
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-  uint4 vj = L.p((int)c.a2, 0);
-  unsigned tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
-    const uint4 vjn = L.p((int)c.a2, kn);
-    unsigned e0[8], e1[8], ix[8];
-    int wt[8];
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  uint4 vj = L.p((int)c.a2, 0), vj1 = L.p((int)c.a2, k1);
+  unsigned e0[8], e1[8], ix[8];
+  int wt[8];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
-      int pq = pipe_p_get(vj, B) + 992;
-      pq = min(max(pq, 0), 1983);
-      wt[B] = pq & 63;
-      ix[B] = ((((h + pipe_c8(byte, B)) * 32u) & c.mask0) + (unsigned)(pq >> 6));
-      if constexpr (batch) {
-        e0[B] = L.A32((unsigned)c.t0 + 4u * (ix[B] & c.mask0));
-        e1[B] = L.A32((unsigned)c.t0 + 4u * ((ix[B] + 1u) & c.mask0));
-      }
+  for (int B = 0; B < 8; ++B) {
+    ix[B] = index(h, byte, vj, B, wt[B]);
+    if constexpr (batch) {
+      e0[B] = L.A32((unsigned)c.t0 + 4u * (ix[B] & c.mask0));
+      e1[B] = L.A32((unsigned)c.t0 + 4u * ((ix[B] + 1u) & c.mask0));
     }
-    if constexpr (touch) {
-      ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]);
-      ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]);
+  }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    const uint4 vj2 = L.p((int)c.a2, k2);
+    // next byte's entries: same context -> only equal bit positions share a row, forwarded; rows less than 256 apart ->
+    // fetched after the stores
+    const bool same = h1 == h;
+    const bool late = !same && (((h1 - h) & rowmask) < 256u || ((h - h1) & rowmask) < 256u);
+    unsigned n0[8], n1[8], ixn[8], ti[8], nv[8];
+    int wtn[8];
 #pragma unroll
-      for (int B = 0; B < 8; ++B) tc[B] = L.A32((unsigned)c.t0 + 4u * ((((hn + pipe_c8(byten, B)) * 32u) & c.mask0) + 16u));
+    for (int B = 0; B < 8; ++B) ixn[B] = index(h1, byte1, vj1, B, wtn[B]);
+    if constexpr (batch) {
+      if (!late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) {
+          n0[B] = L.A32((unsigned)c.t0 + 4u * (ixn[B] & c.mask0));
+          n1[B] = L.A32((unsigned)c.t0 + 4u * ((ixn[B] + 1u) & c.mask0));
+        }
+      }
     }
     PipeP8 out;
 #pragma unroll
@@ -527,15 +602,32 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
         e1[B] = L.A32((unsigned)c.t0 + 4u * ((ix[B] + 1u) & c.mask0));
       }
       const int w = wt[B];
-      out.set(B, stretch(((e0[B] >> 10) * (unsigned)(64 - w) + (e1[B] >> 10) * (unsigned)w) >> 13));
+      out.set(B, stretch((__umul24(e0[B] >> 10, (unsigned)(64 - w)) + __umul24(e1[B] >> 10, (unsigned)w)) >> 13));
       const unsigned tv = (w >> 5) ? e1[B] : e0[B];
-      const unsigned ti = (ix[B] + (unsigned)(w >> 5)) & c.mask0;
-      L.A32((unsigned)c.t0 + 4u * ti) = pipe_train(tv, pipe_y(byte, B), (unsigned)dt[tv & 0x3ffu], c.limit);
+      ti[B] = (ix[B] + (unsigned)(w >> 5)) & c.mask0;
+      nv[B] = pipe_train(tv, pipe_y(byte, B), (unsigned)dt[tv & 0x3ffu], c.limit);
+      L.A32((unsigned)c.t0 + 4u * ti[B]) = nv[B];
     }
     L.p(I, k) = out.get();
-    h = hn; byte = byten; vj = vjn;
+    if constexpr (batch) {
+      if (late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) {
+          n0[B] = L.A32((unsigned)c.t0 + 4u * (ixn[B] & c.mask0));
+          n1[B] = L.A32((unsigned)c.t0 + 4u * ((ixn[B] + 1u) & c.mask0));
+        }
+      }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        e0[B] = (same && (ixn[B] & c.mask0) == ti[B]) ? nv[B] : n0[B];
+        e1[B] = (same && ((ixn[B] + 1u) & c.mask0) == ti[B]) ? nv[B] : n1[B];
+      }
+    }
+#pragma unroll
+    for (int B = 0; B < 8; ++B) { ix[B] = ixn[B]; wt[B] = wtn[B]; }
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+    vj = vj1; vj1 = vj2;
   }
-  if constexpr (touch) { ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]); ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]); }
 }
 
 // CODER: Encoder::compress / encode (libzpaq.cpp:2402-2447) fed by the last component's stream.
@@ -761,10 +853,10 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
         const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
         const int n0 = (int)tab[(2u * sn) * G + lane], n1 = (int)tab[(2u * sn + 1u) * G + lane];
         const int pj = pipe_p_get(vj, B);
-        const int pr = sp_clamp2k((w0 * pj + w1 * 64) >> 16);
+        const int pr = sp_clamp2k((__mul24(w0, pj) + w1 * 64) >> 16);          // 20-bit x 12-bit
         out.set(B, pr);
         const int err = pipe_y(byte, B) * 32767 - squash(pr);
-        const int u0 = sp_clamp512k(w0 + ((err * pj + (1 << 12)) >> 13));
+        const int u0 = sp_clamp512k(w0 + ((__mul24(err, pj) + (1 << 12)) >> 13));
         const int u1 = sp_clamp512k(w1 + ((err + 16) >> 5));
         tab[(2u * s) * G + lane] = (unsigned)u0;
         tab[(2u * s + 1u) * G + lane] = (unsigned)u1;
@@ -816,7 +908,6 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL, TAIL = m % 4;
     static_assert(BPW >= 1 && NQ <= QL, "MIX lane group");
     constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
-    constexpr bool touch = batch && c.mask0 >= 4095u;            // small tables stay in L2 anyway
     const unsigned wi = wg - (unsigned)first * ngroups;
     const unsigned g = wi / per_group, sub = wi % per_group;
     const unsigned bl = (unsigned)lane / QL, q = (unsigned)lane % QL;
@@ -836,29 +927,35 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
       tin[x] = J + (have[x] ? t : 0);
     }
     auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
-      return (unsigned)c.t0 + 4u * (((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0) * (unsigned)m) + qoff;
+      return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)m) + qoff;   // s <= 24
     };
     unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-    uint4 pv[4];
+    const unsigned k1 = L.next(0);
+    unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+    uint4 pv[4], pv1[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) pv[x] = L.p(tin[x], 0);
-    unsigned tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 4; ++x) { pv[x] = L.p(tin[x], 0); pv1[x] = L.p(tin[x], k1); }
+    uint4 w[8];
+    if constexpr (batch) {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + row_of(h, byte, B));
+    }
     for (unsigned k = 0; k < L.nb; ++k) {
-      const unsigned kn = L.next(k);
-      const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
-      uint4 pvn[4];
+      const unsigned k2 = min(k + 2u, L.nb - 1u);
+      const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+      uint4 pv2[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) pvn[x] = L.p(tin[x], kn);
-      uint4 w[8];
+      for (int x = 0; x < 4; ++x) pv2[x] = L.p(tin[x], k2);
+      // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint),
+      // forwarded below; contexts less than 256 apart -> any position may coincide: fetched after the stores
+      const bool same = h1 == h;
+      const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
+      uint4 wn[8], nw[8];
       if constexpr (batch) {
+        if (!late) {
 #pragma unroll
-        for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + row_of(h, byte, B));
-      }
-      if constexpr (touch) {
-        ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]);
-        ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]);
-#pragma unroll
-        for (int B = 0; B < 8; ++B) tc[B] = L.A32(row_of(hn, byten, B));
+          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + row_of(h1, byte1, B));
+        }
       }
       PipeP8 out;
 #pragma unroll
@@ -871,26 +968,38 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
         const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
         const int pr = sp_clamp2k(pipe_group_sum<QL>(act ? dot : 0) >> 8);
         out.set(B, pr);
-        const int err = ((pipe_y(byte, B) * 32767 - squash(pr)) * (int)c.a4) >> 4;
-        const unsigned n0 = (unsigned)sp_clamp512k(w0 + ((err * p0 + (1 << 12)) >> 13));
-        const unsigned n1 = (unsigned)sp_clamp512k(w1 + ((err * p1 + (1 << 12)) >> 13));
-        const unsigned n2 = (unsigned)sp_clamp512k(w2 + ((err * p2 + (1 << 12)) >> 13));
-        const unsigned n3 = (unsigned)sp_clamp512k(w3 + ((err * p3 + (1 << 12)) >> 13));
-        if (act && !tail) *(g_u128a4*)(L.arena + row) = make_uint4(n0, n1, n2, n3);
+        const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
+        nw[B].x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
+        nw[B].y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
+        nw[B].z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
+        nw[B].w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
+        if (act && !tail) *(g_u128a4*)(L.arena + row) = nw[B];
         if constexpr (TAIL != 0) {
           if (tail) {
-            L.A32(row) = n0;
-            if constexpr (TAIL >= 2) L.A32(row + 4u) = n1;
-            if constexpr (TAIL >= 3) L.A32(row + 8u) = n2;
+            L.A32(row) = nw[B].x;
+            if constexpr (TAIL >= 2) L.A32(row + 4u) = nw[B].y;
+            if constexpr (TAIL >= 3) L.A32(row + 8u) = nw[B].z;
           }
         }
       }
       if (q == 0) L.p(I, k) = out.get();
-      h = hn; byte = byten;
+      if constexpr (batch) {
+        if (late) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) pv[x] = pvn[x];
+          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + row_of(h1, byte1, B));
+        }
+#pragma unroll
+        for (int B = 0; B < 8; ++B) {
+          // (the tail lane's words past the row's end are never used: their inputs are 0 and they are not stored)
+          const bool fw = same && row_of(h1, byte1, B) == row_of(h, byte, B);
+          w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y;
+          w[B].z = fw ? nw[B].z : wn[B].z; w[B].w = fw ? nw[B].w : wn[B].w;
+        }
+      }
+      h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
     }
-    if constexpr (touch) { ZPQ_KEEP4(tc[0], tc[1], tc[2], tc[3]); ZPQ_KEEP4(tc[4], tc[5], tc[6], tc[7]); }
   });
 }
 

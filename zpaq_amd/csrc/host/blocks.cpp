@@ -6,6 +6,8 @@
 #include <sched.h>
 
 #include <atomic>
+#include <chrono>
+#include <mutex>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -23,13 +25,44 @@ namespace {
 struct PlanDeleter {
   void operator()(zpq_plan* p) const { if (p) { engine_plan_release(p); delete p; } }
 };
-typedef std::unique_ptr<zpq_plan, PlanDeleter> PlanPtr;
-typedef std::map<std::vector<U8>, PlanPtr> PlanCache;
+typedef std::shared_ptr<zpq_plan> PlanPtr;
+
+// Plans are shared by every call of the process (keyed by the header bytes): a plan owns device copies and loaded
+// code objects, and rebuilding them per call would re-read, re-hash and re-load the per-header kernels every time.
+// A call keeps the plans it uses alive through its PlanCache (shared_ptr), so trimming the global map is safe.
+struct GlobalPlans {
+  std::mutex mu;
+  std::map<std::vector<U8>, PlanPtr> map;
+};
+GlobalPlans& global_plans() { static GlobalPlans g; return g; }
+
+typedef std::map<std::vector<U8>, PlanPtr> PlanCache;     // the plans one call uses
 
 zpq_plan* plan_for(PlanCache& cache, const std::vector<U8>& header) {
   auto it = cache.find(header);
-  if (it == cache.end()) it = cache.emplace(header, PlanPtr(plan_from_header(header.data(), header.size()))).first;
-  return it->second.get();
+  if (it != cache.end()) return it->second.get();
+  GlobalPlans& g = global_plans();
+  PlanPtr p;
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto gi = g.map.find(header);
+    if (gi != g.map.end()) p = gi->second;
+  }
+  if (!p) {
+    p = PlanPtr(plan_from_header(header.data(), header.size()), PlanDeleter());
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.map.size() >= 256) g.map.clear();           // data-dependent chains: bound the cache
+    auto ins = g.map.emplace(header, p);
+    p = ins.first->second;                            // another thread may have been faster
+  }
+  cache.emplace(header, p);
+  return p.get();
+}
+
+std::mutex g_api_mu;
+ApiTiming g_api_last;
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // Device-side capacity for the coded form of n input bytes.  Incompressible
@@ -109,6 +142,8 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   };
   std::vector<Work> work(nb);
   archives.assign(nb, std::vector<U8>());
+  ApiTiming tm;
+  const double t0 = now_ms();
   // 1. host front half, parallel over blocks
   parallel_blocks(nb, [&](size_t b) {
     Work& w = work[b];
@@ -135,12 +170,26 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     if (!work[b].header.empty())
       jobs.push_back(EncJob{plan_for(plans, work[b].header), work[b].pp.data(), (U32)work[b].pp.size(), in[b].data,
                             in[b].n, &work[b].coded});
+  const double t1 = now_ms();
   encode_jobs(jobs);
+  const double t2 = now_ms();
+  const Timing dev = engine_last_timing();
   // 3. stitch the archives
   parallel_blocks(nb, [&](size_t b) {
     archives[b].insert(archives[b].end(), work[b].coded.begin(), work[b].coded.end());
     write_block_epilogue(archives[b], dosha1 ? work[b].sha1 : nullptr);
   });
+  const double t3 = now_ms();
+  tm.front_ms = t1 - t0; tm.device_ms = t2 - t1; tm.stitch_ms = t3 - t2; tm.total_ms = t3 - t0;
+  tm.kernel_init_ms = dev.init_ms; tm.kernel_code_ms = dev.code_ms;
+  tm.blocks = nb;
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  g_api_last = tm;
+}
+
+ApiTiming last_api_timing() {
+  std::lock_guard<std::mutex> lk(g_api_mu);
+  return g_api_last;
 }
 
 std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size_t npp, const U8* data, size_t n) {
@@ -206,12 +255,14 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
     size_t payload_end = 0;
     std::vector<U8> decoded;      // PP byte(s) + data
     U64 hint = 0;
+    size_t block = 0;             // index of the block the segment belongs to
   };
   std::vector<std::unique_ptr<Seg>> segs;
   PlanCache plans;
-  size_t pos = 0;
+  size_t pos = 0, nblocks = 0;
   FoundBlock blk;
   while (find_block(a, n, pos, blk)) {
+    const size_t this_block = nblocks++;
     const bool modeled = blk.header[6] != 0;
     zpq_plan* plan = modeled ? plan_for(plans, blk.header) : nullptr;
     int nseg = 0;
@@ -222,6 +273,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
         fail(ZPQ_E_UNSUPPORTED, "multi-segment modelled blocks are outside this build's scope");
       s->plan = plan;
       s->header = blk.header;
+      s->block = this_block;
       s->payload_end = skip_payload(a, n, pos, modeled);
       pos = s->payload_end;
       read_segment_end(a, n, pos, s->fs);
@@ -240,6 +292,8 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
       jobs.push_back(DecJob{s->plan, a + s->fs.payload_begin, (U32)(s->payload_end - s->fs.payload_begin),
                             s->hint ? s->hint + 1 : 0, &s->decoded});
   decode_jobs(jobs);
+  std::unique_ptr<PostProcessor> pp;
+  size_t pp_block = (size_t)-1;
   for (auto& s : segs) {
     if (!s->plan) {   // stored: Decoder::decompress n==0 branch (2146-2154)
       size_t p = s->fs.payload_begin;
@@ -251,8 +305,10 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
         p += l;
       }
     }
+    // one PostProcessor per block: only its first segment carries the PP header (libzpaq.cpp:2320-2330)
+    if (s->block != pp_block) { pp.reset(new PostProcessor(s->header[4], s->header[5])); pp_block = s->block; }
     std::vector<U8> data;
-    post_process(s->header, s->decoded, data);
+    pp->segment(s->decoded.data(), s->decoded.size(), data);
     std::vector<U8>().swap(s->decoded);
     if (s->fs.has_sha1) {
       Sha1 h; h.update(data.data(), data.size());

@@ -15,6 +15,18 @@ struct BlockInput {
   const char* comment;    // may be null; appended to the decimal size
 };
 
+// Wall-clock phases of the last compress_blocks call of this process (the end-to-end figure SURVEY section 8(d)
+// asks for: method expansion + SHA-1, H2D + kernels + D2H, framing), for bench.py.
+struct ApiTiming {
+  double front_ms = 0;        // SHA-1, method expansion, ZPAQL assembly, block prologue (host threads)
+  double device_ms = 0;       // staging copy + H2D + Predictor init + coding kernels + D2H
+  double stitch_ms = 0;       // coded bytes + segment trailer into the archives
+  double total_ms = 0;
+  double kernel_init_ms = 0, kernel_code_ms = 0;   // inside device_ms: the kernels alone (hipEvents)
+  size_t blocks = 0;
+};
+ApiTiming last_api_timing();
+
 // Batched libzpaq::compressBlock (libzpaq.cpp:7543-7731): one archive (tag ..
 // 255) per input, all modelled payloads coded on the device in one batch.
 void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool dosha1,
@@ -33,7 +45,24 @@ std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload,
 // receives each segment's post-processed data in order.
 void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, size_t)>& sink);
 
-// PostProcessor::write (2195-2241): turns a decoded segment (PP header + payload) into the
+// PostProcessor (libzpaq.cpp:2183-2241) of one block: the first segment's decoded bytes start with the PP header
+// (0 = PASS, or 1 len16 PCOMP program); every later segment of the block continues in the same mode -- PASS copies,
+// PROG feeds the same ZPAQL machine -- and each segment ends with the machine's EOS call.
+class PostProcessor {
+ public:
+  PostProcessor(int ph, int pm);
+  ~PostProcessor();
+  PostProcessor(const PostProcessor&) = delete;
+  PostProcessor& operator=(const PostProcessor&) = delete;
+  void segment(const U8* decoded, size_t n, std::vector<U8>& data);   // appends the segment's data to `data`
+  bool loaded() const;                          // the PP header has been read
+  const std::vector<U8>& program() const;       // PCOMP code (empty: PASS)
+ private:
+  struct Impl;
+  Impl* impl_;
+};
+
+// The same for a block of ONE segment: turns a decoded segment (PP header + payload) into the
 // segment's data -- either passing it through or running the PCOMP program it carries.
 void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data);
 

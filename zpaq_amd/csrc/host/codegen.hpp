@@ -24,7 +24,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
 struct PipeLayout {
   int n = 0;
   int C = 512;                 // chunk: input bytes per unit per step
-  int G = 64;                  // blocks per group = active lanes per wavefront (16 / 32 / 64)
+  int G = 32;                  // blocks per group = active lanes per wavefront (8 / 16 / 32 / 64; measured best: 32)
   int S = 0;                   // ring slots = highest level + 1
   int nctx = 0, nrow = 0, nstate = 0;
   int level[64], ctx[64], row[64], state[64];

@@ -5,6 +5,7 @@
 // any archive written by the reference's LZ77 / BWT / E8E9 methods decodes here without this
 // library knowing those programs.
 #include <cstring>
+#include <memory>
 
 #include "blocks.hpp"
 
@@ -127,21 +128,65 @@ class PcompVm {
 
 }  // namespace
 
-void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data) {
-  data.clear();
-  if (decoded.empty()) fail(ZPQ_E_CORRUPT, "Unexpected EOS");
-  if (decoded[0] == 0) {                       // PASS
-    data.assign(decoded.begin() + 1, decoded.end());
+// PostProcessor of ONE block (the reference initialises it once per block, libzpaq.cpp:2320-2330: only the first
+// segment carries the PP header; later segments continue in the same mode and, for PROG, with the same machine).
+struct PostProcessor::Impl {
+  int ph, pm;
+  int state = 0;                 // 0 initial, 1 PASS, 2..4 loading PROG, 5 PROG loaded (PostProcessor::write)
+  size_t want = 0;
+  std::vector<U8> prog;          // PCOMP code as carried by the first segment
+  std::vector<U8> sink;
+  std::unique_ptr<PcompVm> vm;
+};
+
+PostProcessor::PostProcessor(int ph, int pm) : impl_(new Impl) { impl_->ph = ph; impl_->pm = pm; }
+PostProcessor::~PostProcessor() { delete impl_; }
+
+void PostProcessor::segment(const U8* p, size_t n, std::vector<U8>& data) {
+  Impl& m = *impl_;
+  size_t i = 0;
+  while (i < n && m.state != 1 && m.state != 5) {
+    const U8 c = p[i++];
+    switch (m.state) {
+      case 0:
+        if (c > 1) fail(ZPQ_E_CORRUPT, "unknown post processing type");
+        m.state = c + 1;
+        break;
+      case 2: m.want = c; m.state = 3; break;
+      case 3:
+        m.want += 256u * c;
+        if (m.want < 1) fail(ZPQ_E_CORRUPT, "Empty PCOMP");
+        m.prog.clear();
+        m.state = 4;
+        break;
+      case 4:
+        m.prog.push_back(c);
+        if (m.prog.size() == m.want) {
+          m.vm.reset(new PcompVm(m.prog.data(), m.prog.size(), m.ph, m.pm, m.sink));
+          m.state = 5;
+        }
+        break;
+    }
+  }
+  if (m.state != 1 && m.state != 5) fail(ZPQ_E_CORRUPT, "Unexpected EOS");      // the segment ended inside the PP header
+  if (m.state == 1) {
+    data.insert(data.end(), p + i, p + n);
     return;
   }
-  if (decoded[0] != 1) fail(ZPQ_E_CORRUPT, "unknown post processing type");
-  if (decoded.size() < 3) fail(ZPQ_E_CORRUPT, "Unexpected EOS");
-  const size_t len = decoded[1] + 256u * decoded[2];
-  if (len < 1) fail(ZPQ_E_CORRUPT, "Empty PCOMP");
-  if (decoded.size() < 3 + len) fail(ZPQ_E_CORRUPT, "Unexpected EOS");
-  PcompVm vm(decoded.data() + 3, len, header[4], header[5], data);
-  for (size_t i = 3 + len; i < decoded.size(); ++i) vm.run(decoded[i]);
-  vm.run(0xFFFFFFFFu);                         // EOS: ZPAQL::run(-1) (libzpaq.cpp:2236-2237)
+  m.sink.clear();
+  for (; i < n; ++i) m.vm->run(p[i]);
+  m.vm->run(0xFFFFFFFFu);                      // EOS: ZPAQL::run(-1) (libzpaq.cpp:2236-2237)
+  data.insert(data.end(), m.sink.begin(), m.sink.end());
+  m.sink.clear();
+}
+
+bool PostProcessor::loaded() const { return impl_->state == 1 || impl_->state == 5; }
+const std::vector<U8>& PostProcessor::program() const { return impl_->prog; }
+
+void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data) {
+  data.clear();
+  PostProcessor pp(header[4], header[5]);
+  pp.segment(decoded.data(), decoded.size(), data);
 }
 
 }  // namespace zpq

@@ -171,8 +171,8 @@ void decompress(Reader* in, Writer* out) {
 // decompress() is called for it, and then served in the requested pieces.
 Decompresser::Decompresser()
     : in_(0), out_(0), sha1_(0), rpos_(0), plan_(0), dpos_(0), payload_end_(0), seg_decoded_(false),
-      segs_in_block_(0), state_(BLOCK) {}
-Decompresser::~Decompresser() {}
+      segs_in_block_(0), pp_(0), state_(BLOCK) {}
+Decompresser::~Decompresser() { delete (zpq::PostProcessor*)pp_; }
 
 int Decompresser::getc() {
   if (rpos_ == buf_.size()) {
@@ -221,6 +221,8 @@ bool Decompresser::findBlock(double* memptr) {
     } else *memptr = 0;
   }
   segs_in_block_ = 0;
+  delete (zpq::PostProcessor*)pp_;
+  pp_ = new zpq::PostProcessor(header_[4], header_[5]);
   state_ = FILENAME;
   return true;
 }
@@ -228,7 +230,19 @@ bool Decompresser::findBlock(double* memptr) {
 void Decompresser::hcomp(Writer* out2) {
   for (size_t i = 0; i < header_.size(); ++i) out2->put(header_[i]);
 }
-bool Decompresser::pcomp(Writer*) { return false; }
+// The PCOMP program of the block as the reference returns it (ZPAQL::write(out2, true), libzpaq.cpp:866-884):
+// len16 + code, false when the block is not post-processed.  Known once the first segment has been decoded.
+bool Decompresser::pcomp(Writer* out2) {
+  zpq::PostProcessor* pp = (zpq::PostProcessor*)pp_;
+  if (!pp || !pp->loaded() || pp->program().empty()) return false;
+  const std::vector<U8>& code = pp->program();
+  if (out2) {
+    out2->put((int)(code.size() & 255));
+    out2->put((int)(code.size() >> 8));
+    for (size_t i = 0; i < code.size(); ++i) out2->put(code[i]);
+  }
+  return true;
+}
 
 bool Decompresser::findFilename(Writer* filename) {
   const int c = getc();
@@ -281,10 +295,10 @@ void Decompresser::decode_segment() {
       for (U32 i = 0; i < len; ++i) { const int c = getc(); if (c < 0) error("unexpected end of file"); decoded_.push_back((U8)c); }
     }
   }
-  // PostProcessor: pass through, or run the PCOMP program carried by the segment
+  // PostProcessor of the block: pass through, or run the PCOMP program its first segment carried
   guarded([&] {
     std::vector<U8> data;
-    zpq::post_process(header_, decoded_, data);
+    ((zpq::PostProcessor*)pp_)->segment(decoded_.data(), decoded_.size(), data);
     decoded_.swap(data);
   });
   dpos_ = 0;
@@ -341,15 +355,34 @@ void Decompresser::readSegmentEnd(char* sha1string) {
 // -------------------------------------------------------------- Compressor
 // (reference libzpaq.cpp:2776-3004).  Bytes are gathered per segment and coded
 // on the device when the segment ends.
-Compressor::Compressor() : out_(0), in_(0), segs_(0), state_(INIT) { memset(sha1result_, 0, 20); }
-Compressor::~Compressor() {}
+Compressor::Compressor() : out_(0), in_(0), verify_(false), pp_(0), segs_(0), state_(INIT) { memset(sha1result_, 0, 20); }
+Compressor::~Compressor() { delete (zpq::PostProcessor*)pp_; }
+
+// Header bytes of the three built-in models (Compressor::startBlock(int), libzpaq.cpp:2796-2822: min.cfg, mid.cfg,
+// max.cfg).  They are format constants: an archive made with level 1..3 stores exactly these bytes.
+static const char* const kBuiltinModels[3] = {
+    "1a00010200000203100813000060041c3b0a3b70190a3b0a3b703800",
+    "450003030000080305080d000811010812020812030813040416180710000718ff0011684a045f013b700a193b700a193b700a193b700a19"
+    "3b700a193b0a3b701945cf08703800",
+    "c400050900001601a00305080d010810020812030813040813050814060416180311081309030d030d030d030e0710000f18ff0708001"
+    "00aff06000f10180009081120ff0608111210ff09101320ff0600131410000011684a045f023b700a193b700a193b700a193b700a193b700a"
+    "193b0a3b700a193b700a1945b720ef402f0ee75b2f0a193c1a30869714703f0946df00270319701a3419194a0a043b70190a043b70190a04"
+    "3b7019418fd448043b70088fd80844af3c3c1945cf09701919191919703800"};
 
 void Compressor::writeTag() {
   for (int i = 0; i < 13; ++i) out_->put(zpq::kBlockTag[i]);
 }
 
-void Compressor::startBlock(int) {
-  error("built-in min/mid/max models are not bundled; pass their header bytes or a config to startBlock()");
+void Compressor::startBlock(int level) {
+  if (level < 1) error("compression level must be at least 1");
+  if (level > 3) error("compression level too high");
+  const char* hex = kBuiltinModels[level - 1];
+  std::vector<char> bytes;
+  for (size_t i = 0; hex[i] && hex[i + 1]; i += 2) {
+    auto nib = [](char ch) { return ch <= '9' ? ch - '0' : ch - 'a' + 10; };
+    bytes.push_back((char)(nib(hex[i]) * 16 + nib(hex[i + 1])));
+  }
+  startBlock(bytes.data());
 }
 
 void Compressor::startBlock(const char* hcomp) {
@@ -362,6 +395,8 @@ void Compressor::startBlock(const char* hcomp) {
   out_->put(1);
   for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
   segs_ = 0;
+  delete (zpq::PostProcessor*)pp_;
+  pp_ = 0;
   state_ = BLOCK1;
 }
 
@@ -376,6 +411,8 @@ void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
   out_->put(1);
   for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
   segs_ = 0;
+  delete (zpq::PostProcessor*)pp_;
+  pp_ = 0;
   state_ = BLOCK1;
 }
 
@@ -432,6 +469,16 @@ bool Compressor::compress(int n) {
 
 void Compressor::flush_segment() {
   if (state_ == SEG1) postProcess();
+  if (verify_) {
+    // what the decompresser's PostProcessor will produce from this segment: its SHA-1 and size are what
+    // endSegmentChecksum() reports (libzpaq.cpp:2935-2939, 2976-2991)
+    guarded([&] {
+      if (!pp_) pp_ = new zpq::PostProcessor(header_[4], header_[5]);
+      std::vector<U8> data;
+      ((zpq::PostProcessor*)pp_)->segment(pending_.data(), pending_.size(), data);
+      seg_sha1_.write((const char*)data.data(), (int64_t)data.size());
+    });
+  }
   if (header_[6] == 0) {
     std::vector<U8> framed;
     zpq::write_stored_payload(framed, 0, 0, pending_.data(), pending_.size());
@@ -458,12 +505,16 @@ void Compressor::endSegment(const char* sha1string) {
   state_ = BLOCK2;
 }
 
-char* Compressor::endSegmentChecksum(int64_t*, bool) {
-  // verify mode (setVerify) needs the PCOMP interpreter on the host: not in scope
+char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
   flush_segment();
-  out_->put(254);
+  if (verify_) {
+    if (size) *size = (int64_t)seg_sha1_.usize();
+    memcpy(sha1result_, seg_sha1_.result(), 20);       // result() also resets the hash for the next segment
+  }
+  if (verify_ && dosha1) { out_->put(253); for (int i = 0; i < 20; ++i) out_->put(sha1result_[i]); }
+  else out_->put(254);
   state_ = BLOCK2;
-  return 0;
+  return verify_ ? sha1result_ : 0;
 }
 
 void Compressor::endBlock() {
