@@ -200,6 +200,10 @@ int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char*
  * model (len16 + code, empty if none); args9 receives $1..$9. */
 int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t hcap,
                          size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);
+/* The pre-processing half of compressBlock for an explicit "x.." method (libzpaq.cpp:7709-7716; LZ77 / BWT /
+ * E8E9, host/preproc.cpp): writes the stream the coder will see (the input itself when the method does not
+ * transform it).  E8E9 methods rewrite `data` in place, as the reference rewrites its input buffer. */
+int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t* out, size_t cap, size_t* len);
 /* Compiler alone (libzpaq.cpp:2698): ZPAQL source text -> header / PCOMP bytes. */
 int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hcap,
                  size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);

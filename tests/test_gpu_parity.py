@@ -391,3 +391,31 @@ def test_mixed_corpus_batch_against_the_reference(gpu, ref):
     for b, (d, a) in enumerate(zip(blocks, arch)):
         assert a == ref.compress_block(d, "5"), b
     assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)
+
+
+def _lcg_block(n, seed):
+    """BASELINE.md's generator: x = x * 1664525 + 1013904223, byte = x >> 24, first byte after one step."""
+    x, out = seed, bytearray(n)
+    for i in range(n):
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        out[i] = x >> 24
+    return np.frombuffer(bytes(out), np.uint8)
+
+
+def test_method_3_known_answer_and_preprocessing_levels(gpu, ref):
+    """BASELINE configs[1]'s method: "3" = byte-aligned LZ77 through a suffix array on the host, then an ICM-ISSE
+    chain (n = 2) on the GPU.  Known answer from BASELINE.md section 2; then levels 3 / 4 with every block-type hint
+    (LZ77, BWT, E8E9 variants) against the reference, whole archives, and back through decompress."""
+    a, = gpu.compress_blocks([_lcg_block(1 << 18, 12345)], "3")
+    assert len(a) == 263462 and hashlib.sha1(a).hexdigest() == "cc9ec4cf41c67b408c8a1de88e00cfed3fcb07cf"
+    r = np.random.default_rng(8)
+    exe = r.integers(0, 256, 60000, dtype=np.uint8)
+    exe[::37] = 0xE8
+    exe[4::37] = 0
+    blocks = [corpus.block("text", 70000, 31), corpus.block("records", 50000, 32), exe, corpus.block("lcg", 30000, 33),
+              corpus.block("zeros", 40000, 34), corpus.block("text", 0, 35)]
+    for m in ["3", "4", "3,128,1", "3,100,2", "3,30,0", "4,128,3", "4,30,2", "4,15,0", "4,240,1", "5,128,2"]:
+        ours = gpu.compress_blocks([b.copy() for b in blocks], m)
+        for b, a in zip(blocks, ours):
+            assert a == ref.compress_block(b.copy(), m), m
+        assert gpu.decompress(b"".join(ours)) == b"".join(b.tobytes() for b in blocks), m

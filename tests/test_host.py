@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, gen_input
+from oracle.oracle_py import parse_block
 from zpaq_amd import corpus
 
 
@@ -232,3 +233,106 @@ def test_hiprtc_compiles_a_generated_kernel_without_a_gpu(zlib_, golden):
     log = C.create_string_buffer(16384)
     n = L.zpq_plan_spec_jit(plan._h, log, len(log))
     assert n > 10000, log.value.decode(errors="replace")[:3000]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LZ77 / BWT / E8E9 on the compression side (host/preproc.cpp + the PCOMP generators of host/method.cpp):
+# levels 1-3, the hinted branches of 4, and explicit "x" methods.  SURVEY section 8(f) row 1.
+
+def _exe_like(n, seed):
+    """bytes with many E8|E9 xx xx xx 00|FF patterns, so that the E8E9 filter has work to do"""
+    r = np.random.default_rng(seed)
+    b = r.integers(0, 256, n, dtype=np.uint8)
+    for i in range(0, n - 8, 37):
+        b[i] = 0xE8 if (i // 37) % 2 else 0xE9
+        b[i + 4] = 0 if (i // 37) % 3 else 0xFF
+    return b
+
+
+def _preprocess(zlib_, xm, d):
+    import ctypes as C
+    L = zlib_.lib()
+    L.zpq_preprocess_block.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    buf = np.array(d, dtype=np.uint8, copy=True)
+    out = np.empty(len(d) * 2 + 4096, np.uint8)
+    ln = C.c_size_t(0)
+    assert L.zpq_preprocess_block(xm.encode(), buf.ctypes.data, len(buf), out.ctypes.data, out.size, C.byref(ln)) == 0
+    return out[:ln.value].tobytes()
+
+
+def test_preprocessing_methods_headers_and_pcomp_match_the_reference(zlib_, ref):
+    """makeConfig for every branch compressBlock takes at levels 1-4 (block type x hint) and every block-size
+    exponent: stored header and PCOMP bytes identical to the reference's (the PCOMP program is part of the archive)."""
+    n = 0
+    for kind, size in [("text", 30000), ("lcg", 20000), ("zeros", 10000), ("records", 25000)]:
+        d = corpus.block(kind, size, 11)
+        for level in "1234":
+            for hint in ["", ",0,0", ",10,0", ",30,1", ",60,2", ",100,3", ",128,1", ",200,0", ",255,2", ",20,3", ",250,1"]:
+                xm = zlib_.expand_method(level + hint, d)
+                cfg, args = ref.make_config(xm)
+                assert zlib_.method_to_header(xm)[:2] == ref.compile(cfg, args), (level + hint, xm)
+                n += 1
+    for a0 in range(0, 8):       # offsets with low bits (rb > 0), the two inverse-BWT variants
+        for body in [",1,4,0,3,%d" % (19 + a0 + (a0 <= 6)), ",5,4,0,3,%d" % (19 + a0 + (a0 <= 6)), ",2,12,0,7,%d,1c0,0,511i2" % (21 + a0),
+                     ",6,5,0,7,%d1c0,0,511" % (21 + a0), ",3ci1", ",7ci1", ",4ci1,1,1,1,2am"]:
+            xm = "x%d%s" % (a0, body)
+            cfg, args = ref.make_config(xm)
+            assert zlib_.method_to_header(xm)[:2] == ref.compile(cfg, args), xm
+            n += 1
+    assert n > 200
+
+
+def test_preprocessed_streams_match_the_reference(zlib_, ref, oracle):
+    """What the coder is fed after LZ77 / BWT / E8E9 must be the reference's bytes: checked through the reference's
+    archives -- stored payloads directly (methods without a model), modelled ones by coding our stream with the oracle."""
+    inputs = [corpus.block("text", 40000, 3), corpus.block("lcg", 20000, 4), corpus.block("zeros", 12000, 5),
+              corpus.block("records", 30000, 6), _exe_like(30000, 8), np.zeros(0, np.uint8), np.array([65], np.uint8),
+              corpus.block("text", 7, 9)]
+    methods = ["1", "2", "3", "4", "1,40,0", "1,100,0", "1,250,0", "2,40,0", "2,128,2", "3,30,0", "3,128,1", "3,160,3",
+               "4,15,0", "4,30,2", "4,128,3", "4,230,2", "x0,4", "x0,5,4,0,3,20", "x0,6,8,0,4,21", "x0,7", "x0,1,4,6,3,18,1"]
+    for di, d in enumerate(inputs):
+        for m in methods:
+            xm = zlib_.expand_method(m, d)
+            a = ref.compress_block(d, m)
+            f = parse_block(a)
+            hdr, ps = f["header"], f["payload_start"]
+            ours_hdr, pc, _ = zlib_.method_to_header(xm)
+            assert ours_hdr == hdr, (di, m)
+            body = ((b"\x01" + pc) if pc else b"\x00") + _preprocess(zlib_, xm, d)
+            if hdr[6] == 0:
+                want, pos = b"", 0
+                while pos < len(body):
+                    k = min(65536, len(body) - pos)
+                    want += k.to_bytes(4, "big") + body[pos:pos + k]
+                    pos += k
+                assert a[ps:ps + len(want) + 4] == want + b"\0\0\0\0", (di, m, xm)
+            else:
+                coded = oracle.encode(hdr, body)
+                assert a[ps:ps + len(coded) + 4] == coded + b"\0\0\0\0", (di, m, xm)
+
+
+def test_suffix_array_against_naive_sort(zlib_):
+    """host/preproc.cpp's SA-IS through the BWT it feeds: x0,3 over short strings with long repeats."""
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        n = int(rng.integers(1, 300))
+        d = rng.integers(0, int(rng.integers(1, 5)) + 1, n, dtype=np.uint8) + 97
+        s = d.tobytes()
+        sa = sorted(range(n), key=lambda i: s[i:])
+        want = bytes([s[n - 1]]) + bytes(255 if p == 0 else s[p - 1] for p in sa)
+        idx = sa.index(0) + 1
+        want += idx.to_bytes(4, "little")
+        assert _preprocess(zlib_, "x0,3", d) == want, trial
+
+
+def test_methods_1_and_2_whole_archives_without_a_gpu(zlib_, ref):
+    """Levels 1 and 2 have no context model: the whole compressBlock runs on the host.  Archives identical to the
+    reference's, incl. BASELINE.md's known answer (64 KiB zeros, method 1 -> 394 bytes), and they decode."""
+    a = zlib_.compress_blocks([np.zeros(65536, np.uint8)], "1")[0]
+    assert len(a) == 394 and hashlib.sha1(a).hexdigest() == "20fb8eb50acb4e41a6a6d455e388ffde0c7ebe4a"
+    blocks = [corpus.block("text", 50000, 21), corpus.block("records", 33333, 22), _exe_like(20000, 23), corpus.block("lcg", 9000, 24)]
+    for m in ("1", "2", "1,128,2"):
+        ours = zlib_.compress_blocks([b.copy() for b in blocks], m)
+        for b, a in zip(blocks, ours):
+            assert a == ref.compress_block(b, m), m
+        assert zlib_.decompress(b"".join(ours)) == b"".join(b.tobytes() for b in blocks)

@@ -289,6 +289,21 @@ int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hc
   ZPQ_CATCH
 }
 
+int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t* out, size_t cap, size_t* len) {
+  ZPQ_TRY
+  if (!xmethod || (!data && n) || !len) fail(ZPQ_E_ARG, "null argument");
+  int args[9];
+  (void)make_config(xmethod, args);
+  std::vector<U8> pre;
+  const bool made = preprocess_block(data, n, args, pre);
+  if (!made) pre.assign(data, data + n);
+  *len = pre.size();
+  if (pre.size() > cap) fail(ZPQ_E_OVERFLOW, "output buffer too small");
+  if (!pre.empty()) memcpy(out, pre.data(), pre.size());
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_last_api_timing(double out[8]) {
   if (!out) return ZPQ_E_ARG;
   const ApiTiming t = last_api_timing();

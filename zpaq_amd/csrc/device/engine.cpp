@@ -6,8 +6,11 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <mutex>
 
@@ -473,7 +476,85 @@ static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<
   return groups;
 }
 
-void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
+// ---- submission queue ------------------------------------------------------------------------------------------
+// libzpaq callers are threads that each code ONE block (zpaq.cpp:1918-1965 compressThread, 2848-2867
+// decompressThread).  One block is one lane of one wavefront per unit: launched alone it leaves the GPU empty, so
+// concurrent callers are coalesced: the first one to arrive becomes the leader, lingers while other callers are
+// known to be on their way (they announce themselves when they enter the host front half), takes everything that
+// queued up, runs it as ONE batch and hands the results back.  A lone caller is never delayed.
+namespace {
+struct Ticket {
+  const std::vector<HostBlock>* blocks;
+  std::vector<BlockResult>* results;
+  bool done = false;
+  std::exception_ptr err;
+};
+struct Batcher {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Ticket*> queue[2];      // [decode]
+  bool leader[2] = {false, false};
+  int approaching = 0;                // callers inside the host front half that will submit a block shortly
+};
+Batcher& batcher() { static Batcher b; return b; }
+void engine_code_host_now(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);
+}  // namespace
+
+void engine_caller_enter() { Batcher& b = batcher(); std::lock_guard<std::mutex> g(b.mu); ++b.approaching; }
+void engine_caller_leave() {
+  Batcher& b = batcher();
+  std::lock_guard<std::mutex> g(b.mu);
+  if (b.approaching > 0) --b.approaching;
+  b.cv.notify_all();
+}
+
+void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results, bool announced) {
+  Batcher& b = batcher();
+  const int d = decode ? 1 : 0;
+  Ticket me{&blocks, &results};
+  std::unique_lock<std::mutex> lk(b.mu);
+  b.queue[d].push_back(&me);
+  if (announced && b.approaching > 0) --b.approaching;
+  b.cv.notify_all();
+  for (;;) {
+    b.cv.wait(lk, [&] { return me.done || !b.leader[d]; });
+    if (me.done) break;
+    // become the leader
+    b.leader[d] = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (b.approaching > 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+      b.cv.wait_for(lk, std::chrono::milliseconds(1));
+    std::vector<Ticket*> batch;
+    batch.swap(b.queue[d]);
+    lk.unlock();
+    std::exception_ptr err;
+    if (batch.size() == 1) {
+      try { engine_code_host_now(decode, *batch[0]->blocks, *batch[0]->results); } catch (...) { err = std::current_exception(); }
+    } else {
+      std::vector<HostBlock> all;
+      for (Ticket* t : batch) all.insert(all.end(), t->blocks->begin(), t->blocks->end());
+      std::vector<BlockResult> res;
+      try {
+        engine_code_host_now(decode, all, res);
+        size_t pos = 0;
+        for (Ticket* t : batch) {
+          t->results->assign(res.begin() + (long)pos, res.begin() + (long)(pos + t->blocks->size()));
+          pos += t->blocks->size();
+        }
+      } catch (...) { err = std::current_exception(); }
+    }
+    lk.lock();
+    for (Ticket* t : batch) { t->err = err; t->done = true; }
+    b.leader[d] = false;
+    b.cv.notify_all();
+    if (me.done) break;       // (always: the leader's own ticket was in the batch)
+  }
+  lk.unlock();
+  if (me.err) std::rethrow_exception(me.err);
+}
+
+namespace {
+void engine_code_host_now(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
@@ -558,6 +639,7 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     pos = end;
   }
 }
+}  // namespace
 
 void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan, const void* d_in,
                         const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks, void* d_out,

@@ -34,8 +34,15 @@ void engine_plan_release(zpq_plan* p);
 // 4 pipelined encoder (compression only) / 3 specialised / 2 generic wave / 1 generic one-lane; note = origin of the specialised kernel or why not
 int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false);
 
-// Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.
-void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);
+// Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.  Concurrent callers are
+// coalesced into one device batch (see the submission queue in engine.cpp); a caller that will submit shortly
+// announces itself with engine_caller_enter() and withdraws the announcement with engine_caller_leave() right
+// before it submits (or gives up), so that the batch leader waits for it.
+// announced = the caller called engine_caller_enter() before: the announcement is withdrawn once its blocks are queued
+void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results,
+                      bool announced = false);
+void engine_caller_enter();
+void engine_caller_leave();
 
 // Device-resident batch; plans[0] for every block when one_plan, else plans[b] per block.  Results
 // land in the device array d_res in the caller's block order.

@@ -78,7 +78,7 @@ U32 coded_cap(U64 n, bool worst) {
 // Runs the encoder for a list of (plan, pp, data) jobs, retrying overflowed ones.
 struct EncJob { zpq_plan* plan; const U8* pp; U32 npp; const U8* data; U32 n; std::vector<U8>* coded; };
 
-void encode_jobs(std::vector<EncJob>& jobs) {
+void encode_jobs(std::vector<EncJob>& jobs, bool announced = false) {
   std::vector<size_t> todo(jobs.size());
   for (size_t i = 0; i < jobs.size(); ++i) todo[i] = i;
   bool worst = false;
@@ -90,7 +90,8 @@ void encode_jobs(std::vector<EncJob>& jobs) {
       hb.push_back(HostBlock{j.plan, j.pp, j.npp, j.data, j.n, j.coded->data(), (U32)j.coded->size()});
     }
     std::vector<BlockResult> res;
-    engine_code_host(false, hb, res);
+    engine_code_host(false, hb, res, announced);
+    announced = false;
     std::vector<size_t> again;
     for (size_t k = 0; k < todo.size(); ++k) {
       EncJob& j = jobs[todo[k]];
@@ -138,12 +139,21 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   const size_t nb = in.size();
   struct Work {
     std::vector<U8> pp, coded, header;
+    std::vector<U8> pre;        // LZ77 / BWT stream when the method pre-processes (else the input itself is coded)
+    bool use_pre = false;
     U8 sha1[20];
   };
   std::vector<Work> work(nb);
   archives.assign(nb, std::vector<U8>());
   ApiTiming tm;
   const double t0 = now_ms();
+  // other threads doing the same thing should end up in the same device batch: tell the queue we are coming
+  struct Announce {
+    bool on = true;
+    Announce() { engine_caller_enter(); }
+    void off() { if (on) { engine_caller_leave(); on = false; } }
+    ~Announce() { off(); }
+  } announce;
   // 1. host front half, parallel over blocks
   parallel_blocks(nb, [&](size_t b) {
     Work& w = work[b];
@@ -154,13 +164,18 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     int args[9];
     const std::string cfg = make_config(xm, args);
     const Assembled as = assemble(cfg.c_str(), args);
+    if ((U64)n + 4096 > (0x100000ull << args[0])) fail(ZPQ_E_ARG, "block larger than the method's block size");
+    // LZ77 / BWT / E8E9 (libzpaq.cpp:7709-7716); E8E9 rewrites the caller's buffer in place, as the reference does
+    w.use_pre = preprocess_block(in[b].data, n, args, w.pre);
     std::string cs = std::to_string(n);
     if (in[b].comment) cs += std::string(" ") + in[b].comment;
     write_block_prologue(archives[b], as.hcomp, in[b].filename, cs);
     // PP header: 0 = pass, or 1 len16 pcomp  (Compressor::postProcess 2888-2917)
     if (as.pcomp.empty()) w.pp.push_back(0);
     else { w.pp.push_back(1); w.pp.insert(w.pp.end(), as.pcomp.begin(), as.pcomp.end()); }
-    if (as.hcomp[6] == 0) write_stored_payload(archives[b], w.pp.data(), w.pp.size(), in[b].data, n);
+    const U8* src = w.use_pre ? w.pre.data() : in[b].data;
+    const size_t srcn = w.use_pre ? w.pre.size() : n;
+    if (as.hcomp[6] == 0) write_stored_payload(archives[b], w.pp.data(), w.pp.size(), src, srcn);
     else w.header = as.hcomp;
   });
   // 2. one device batch for every modelled block (blocks with identical headers share a plan)
@@ -168,10 +183,12 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   std::vector<EncJob> jobs;
   for (size_t b = 0; b < nb; ++b)
     if (!work[b].header.empty())
-      jobs.push_back(EncJob{plan_for(plans, work[b].header), work[b].pp.data(), (U32)work[b].pp.size(), in[b].data,
-                            in[b].n, &work[b].coded});
+      jobs.push_back(EncJob{plan_for(plans, work[b].header), work[b].pp.data(), (U32)work[b].pp.size(),
+                            work[b].use_pre ? work[b].pre.data() : in[b].data,
+                            work[b].use_pre ? (U32)work[b].pre.size() : in[b].n, &work[b].coded});
   const double t1 = now_ms();
-  encode_jobs(jobs);
+  if (jobs.empty()) announce.off();
+  else { announce.on = false; encode_jobs(jobs, true); }    // the queue withdraws the announcement when our blocks are in it
   const double t2 = now_ms();
   const Timing dev = engine_last_timing();
   // 3. stitch the archives

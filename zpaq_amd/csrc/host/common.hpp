@@ -80,4 +80,10 @@ std::string expand_method(const std::string& method, const U8* data, U32 n);
 // makeConfig (libzpaq.cpp:6887-7535) restated: "x.." -> ZPAQL source; fills args[9].
 std::string make_config(const std::string& xmethod, int args[9]);
 
+// ---- preproc.cpp: compression-side pre-processors (libzpaq.cpp:6450-6883) ----
+void e8e9_forward(U8* buf, U32 n);
+std::vector<U32> suffix_array(const U8* in, U32 n);
+// false: the (possibly E8E9-filtered, in place) input itself is coded; true: `out` holds the LZ77 / BWT stream
+bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out);
+
 }  // namespace zpq

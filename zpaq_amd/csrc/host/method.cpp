@@ -4,12 +4,13 @@
 //   expand_method : "0".."9" level strings (+ optional ",R,t" hints) -> the
 //                   explicit "x.." / "0.." method (libzpaq.cpp:7551-7691),
 //                   including the level-5 scan of the data for byte periods.
-//   make_config   : "x.." method -> ZPAQL source (libzpaq.cpp:6887-7535).  Only
-//                   the context-model half (COMP list + HCOMP program) is
-//                   restated; methods that need the LZ77/BWT/E8E9
-//                   pre-processors (their PCOMP programs + encoders are
-//                   SURVEY §8(f) row 1, not built yet) fail with
-//                   ZPQ_E_UNSUPPORTED rather than produce a different archive.
+//   make_config   : "x.." method -> ZPAQL source (libzpaq.cpp:6887-7535): the
+//                   context model (COMP list + HCOMP program) and, for methods
+//                   with LZ77 / BWT / E8E9 pre-processing, the PCOMP program
+//                   that inverts it.  PCOMP travels inside the archive, so its
+//                   assembled bytes are format data: the token sequences below
+//                   are the reference's (comments and layout are not); the
+//                   encoders themselves live in host/preproc.cpp.
 //
 // The generated text only has to ASSEMBLE to the same bytes as the
 // reference's; tests/test_host.py checks that against the compiled reference for every
@@ -185,6 +186,103 @@ class ModelWriter {
   std::string comp_, hcomp_;
 };
 
+// ---- PCOMP programs: the inverse transforms the decompresser runs (libzpaq.cpp:6921-7324) ----
+
+// inverse E8E9 over M[b..d) with output; enters with the loop's `do` already open
+const char* const kE8Loop =
+    "a=b a==d ifnot a+= 4 a<d if a=*b a&= 254 a== 232 if c=b b++ b++ b++ b++ a=*b a++ a&= 254 a== 0 if "
+    "b-- a=*b b-- a<<= 8 a+=*b b-- a<<= 8 a+=*b a-=b a++ *b=a a>>= 8 b++ *b=a a>>= 8 b++ *b=a b++ "
+    "endif b=c endif endif a=*b out b++ forever endif\n";
+
+// bit-packed LZ77 (codes of host/preproc.cpp level 1); r1 state, r2 length, r3 offset bits, r4 write pointer,
+// r5 low offset bits, c / d the bit buffer and its fill
+std::string pcomp_lz77_bits(int arg0, bool doe8) {
+  const int rb = arg0 > 4 ? arg0 - 4 : 0;
+  std::string s = "pcomp lazy2 3 ;\na> 255 if\n";
+  if (doe8) s += std::string("b=0 d=r 4 do ") + kE8Loop;
+  s += "a=0 b=0 c=0 d=0 r=a 1 r=a 2 r=a 3 r=a 4 halt endif\n"
+       "a<<=d a+=c c=a a= 8 a+=d d=a\n"
+       "a=r 1 a== 0 if a= 1 r=a 2 a=c a&= 3 a> 0 if\n"
+       "a-- a<<= 3 r=a 3 a=c a>>= 2 c=a b=r 3 a&= 7 a+=b r=a 3 a=c a>>= 3 c=a a=d a-= 5 d=a a= 1 r=a 1\n"
+       "else a=c a>>= 2 c=a d-- d-- a= 3 r=a 1 endif endif\n"
+       "do a=r 1 a== 1 if a=d a> 2 if a=c a&= 1 a== 1 if\n"
+       "a=c a>>= 1 c=a b=r 2 a=c a&= 1 a+=b a+=b r=a 2 a=c a>>= 1 c=a d-- d--\n"
+       "else a=c a>>= 1 c=a a=r 2 a<<= 2 b=a a=c a&= 3 a+=b r=a 2 a=c a>>= 2 c=a d-- d-- d--\n";
+  s += rb ? "a= 5 r=a 1\n" : "a= 2 r=a 1\n";
+  s += "endif forever endif endif\n";
+  if (rb)
+    s += "a=r 1 a== 5 if a=d a> " + num(rb - 1) + " if a=c a&= " + num((1 << rb) - 1) + " r=a 5 a=c a>>= " + num(rb) +
+         " c=a a=d a-= " + num(rb) + " d=a a= 2 r=a 1 endif endif\n";
+  s += "a=r 1 a== 2 if a=r 3 a>d ifnot a=c r=a 6 a=d r=a 7 b=r 3 a= 1 a<<=b d=a a-- a&=c a+=d\n";
+  if (rb) s += "a<<= " + num(rb) + " d=r 5 a+=d a-= " + num((1 << rb) - 1) + "\n";
+  s += "d=a b=r 4 a=b a-=d c=a d=r 2 do a=d a> 0 if d-- a=*c *b=a c++ b++\n";
+  if (!doe8) s += "out\n";
+  s += "forever endif a=b r=a 4 a=r 6 b=r 3 a>>=b c=a a=r 7 a-=b d=a a=0 r=a 1 endif endif\n"
+       "do a=r 1 a== 3 if a=d a> 1 if a=c a&= 1 a== 1 if\n"
+       "a=c a>>= 1 c=a b=r 2 a&= 1 a+=b a+=b r=a 2 a=c a>>= 1 c=a d-- d--\n"
+       "else a=c a>>= 1 c=a d-- a= 4 r=a 1 endif forever endif endif\n"
+       "a=r 1 a== 4 if a=d a> 7 if b=r 4 a=c *b=a\n";
+  if (!doe8) s += "out\n";
+  s += "b++ a=b r=a 4 a=c a>>= 8 c=a a=d a-= 8 d=a a=r 2 a-- r=a 2 a== 0 if a=0 r=a 1 endif endif endif\n"
+       "halt\nend\n";
+  return s;
+}
+
+// byte-aligned LZ77 (level 2): d state, r1 length, r2 offset so far, b write pointer
+std::string pcomp_lz77_bytes(bool doe8) {
+  std::string s = "pcomp lzpre c ;\na> 255 if\n";
+  if (doe8) s += std::string("d=b b=0 do ") + kE8Loop;
+  s += "b=0 c=0 d=0 a=0 r=a 1 r=a 2 halt endif\n"
+       "c=a a=d a== 0 if a=c a>>= 6 a++ d=a a== 1 if a+=c r=a 1 a=0 r=a 2\n"
+       "else d++ a=c a&= 63 a+= $3 r=a 1 a=0 r=a 2 endif\n"
+       "else a== 1 if a=c *b=a b++\n";
+  if (!doe8) s += "out\n";
+  s += "a=r 1 a-- a== 0 if d=0 endif r=a 1\n"
+       "else a> 2 if a=r 2 a<<= 8 a|=c r=a 2 d--\n"
+       "else a=r 2 a<<= 8 a|=c c=a a=b a-=c a-- c=a d=r 1 do a=*c *b=a c++ b++\n";
+  if (!doe8) s += "out\n";
+  s += "d-- a=d a> 0 while endif endif endif\nhalt\nend\n";
+  return s;
+}
+
+// inverse BWT: counts and the linked list in H, the text in M
+std::string pcomp_bwt(int arg0, bool doe8) {
+  std::string s =
+      "pcomp bwtrle c ;\na> 255 ifnot *b=a b++ elsel\n"
+      "b-- a=*b b-- a<<= 8 a+=*b b-- a<<= 8 a+=*b b-- a<<= 8 a+=*b c=a r=a 1 a=b r=a 2\n"
+      "do a=b a> 0 if b-- a=*b a++ a&= 255 d=a d! *d++ forever endif\n"
+      "d=0 d! *d= 1 a=0 do a+=*d *d=a d-- d<>a a! a> 255 a! d<>a until\n"
+      "b=0 do a=c a>b if d=*b d! *d++ d=*d d-- *d=b b++ forever endif\n"
+      "b=c b++ c=r 2 do a=c a>b if d=*b d! *d++ d=*d d-- *d=b b++ forever endif\n";
+  if (arg0 <= 4) {          // blocks up to 16 MiB: the byte rides in the low 8 bits of the list entry
+    s += "b=0 do a=c a>b if d=b a=*d a<<= 8 a+=*b *d=a b++ forever endif\n"
+         "d=r 1 b=0 do a=d a== 0 ifnot a=*d a>>= 8 d=a\n";
+    s += doe8 ? "*b=*d b++\n" : "a=*d out\n";
+    s += "forever endif\n";
+    if (doe8) s += std::string("d=b b=0 do ") + kE8Loop;
+    s += "endif\nhalt\nend\n";
+  } else if (doe8) {        // any block size, E8E9 undone on the fly through a 5-byte window in r4:r5
+    s += "a=r 2 a-- r=a 2 c=0 d=r 1 do a=d a== 0 ifnot d=*d b=d a=*b a<<= 24 b=a a=r 4 r=a 5 a>>= 8 a|=b r=a 4\n"
+         "a=c a> 3 if a=r 5 a&= 254 a== 232 if a=r 4 a>>= 24 b=a a++ a&= 254 a< 2 if\n"
+         "a=r 4 a-=c a+= 4 a<<= 8 a>>= 8 b<>a a<<= 24 a+=b r=a 4 endif endif endif\n"
+         "a=c a> 3 if a=r 5 out endif c++ forever endif\n"
+         "b=r 4 a=c a> 3 a=b if out endif a>>= 8 b=a a=c a> 2 a=b if out endif a>>= 8 b=a\n"
+         "a=c a> 1 a=b if out endif a>>= 8 b=a a=c a> 0 a=b if out endif\n"
+         "endif\nhalt\nend\n";
+  } else {
+    s += "d=r 1 do a=d a== 0 ifnot d=*d b=d a=*b out forever endif\nendif\nhalt\nend\n";
+  }
+  return s;
+}
+
+// inverse E8E9 alone, through a 5-byte window in b (4 bytes) and *b
+const char* const kPcompE8 =
+    "pcomp e8e9 d ;\na> 255 if a=c a> 4 if c= 4 else a! a+= 5 a<<= 3 d=a a=b a>>=d b=a endif\n"
+    "do a=c a> 0 if a=b out a>>= 8 b=a c-- forever endif\n"
+    "else *b=b a<<= 24 d=a a=b a>>= 8 a+=d b=a c++ a=c a> 4 if a=*b out a&= 254 a== 232 if\n"
+    "a=b a>>= 24 a++ a&= 254 a== 0 if a=b a>>= 24 a<<= 24 d=a a=b a-=c a+= 5 a<<= 8 a>>= 8 a|=d b=a\n"
+    "endif endif endif endif\nhalt\nend\n";
+
 }  // namespace
 
 std::string make_config(const std::string& xmethod, int args[9]) {
@@ -203,12 +301,18 @@ std::string make_config(const std::string& xmethod, int args[9]) {
 
   const int level = args[1] & 3;
   const bool doe8 = args[1] >= 4 && args[1] <= 7;
-  if (level != 0 || doe8)
-    fail(ZPQ_E_UNSUPPORTED,
-         "method needs the LZ77/BWT/E8E9 pre/post-processors, which are outside this build's hot-path scope");
+  if (args[1] > 7) fail(ZPQ_E_ARG, "Unsupported method");
   if (type == 'i') fail(ZPQ_E_UNSUPPORTED, "index-block methods are outside this build's scope");
+  std::string hdr, pcomp;
+  if (level == 1) { hdr = "comp 9 16 0 $1+20 "; pcomp = pcomp_lz77_bits(args[0], doe8); }
+  else if (level == 2) { hdr = "comp 9 16 0 $1+20 "; pcomp = pcomp_lz77_bytes(doe8); }
+  else if (level == 3) { hdr = "comp 9 16 $1+20 $1+20 "; pcomp = pcomp_bwt(args[0], doe8); }
+  else { hdr = "comp 9 16 0 0 "; pcomp = doe8 ? kPcompE8 : "end\n"; }
 
   ModelWriter w(args[0] + 20);
+  if (level == 2)     // the model follows the byte-aligned LZ77 parse: r1 = 1 + bytes until the next code, r2 = the code
+    w.raw_hcomp("a=r 1 a== 0 if a= " + num(111 + 57 * doe8) + " else a== 1 if a=*c r=a 2 a> 63 if a>>= 6 a++ a++ "
+                "else a++ a++ endif else a-- endif endif r=a 1\n");
   for (const Command& c : parse_commands(p)) {
     if (w.ncomp() >= 254) break;
     switch (c.letter) {
@@ -220,7 +324,7 @@ std::string make_config(const std::string& xmethod, int args[9]) {
       default: break;   // unknown letters are skipped, like the reference's loop
     }
   }
-  return "comp 9 16 0 0 " + num(w.ncomp()) + "\n" + w.comp() + w.hcomp() + "halt\nend\n";
+  return hdr + num(w.ncomp()) + "\n" + w.comp() + w.hcomp() + "halt\n" + pcomp;
 }
 
 std::string expand_method(const std::string& method_in, const U8* data, U32 n) {
