@@ -42,12 +42,19 @@ const char* zpq_last_error(void);
 const char* zpq_version(void);
 
 /* ---- device ---- */
-/* Bind the engine to one HIP device (one process per GPU; LOCAL_RANK picks it).
- * Idempotent.  Uploads the predictor's constant tables (squash/stretch/dt/
+/* device >= 0: bind the engine to that HIP device (one process per GPU; without a call LOCAL_RANK picks it).
+ * device == -1: drive EVERY visible GPU from this process (or the list in ZPAQ_AMD_DEVICES = "all" | "0,2,3"):
+ * one engine per device, host-buffer batches (zpq_encode_batch, zpq_decode_batch, zpq_compress_blocks,
+ * zpq_decompress, the libzpaq C++ classes) are sharded over them; the device-resident entry points keep using
+ * the first one.  Idempotent.  Uploads the predictor's constant tables (squash/stretch/dt/
  * dt2k/state table; Predictor::init libzpaq.cpp:1731-1761) after verifying the
  * reference's two table checksums (1759-1760) on the host. */
 int zpq_init(int device);
 int zpq_device_count(void);
+/* How a host-buffer batch of n blocks is split when the engine drives several GPUs (zpq_init(-1) or
+ * ZPAQ_AMD_DEVICES=all|0,1,..): shard k of `parts` codes blocks [lo, hi) -- contiguous ranges, so archive order is
+ * kept; one engine and one host thread per device, no collective (blocks are independent, libzpaq.h:57-59). */
+void zpq_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi);
 void zpq_shutdown(void);
 /* Cap on device bytes the engine may hold for model state (default: 85% of
  * free HBM at init).  Batches needing more are run in several residency waves. */

@@ -336,3 +336,23 @@ def test_methods_1_and_2_whole_archives_without_a_gpu(zlib_, ref):
         for b, a in zip(blocks, ours):
             assert a == ref.compress_block(b, m), m
         assert zlib_.decompress(b"".join(ours)) == b"".join(b.tobytes() for b in blocks)
+
+
+def test_host_batches_shard_contiguously_over_devices(zlib_):
+    """zpq_shard_range: how the engine splits a host batch when it drives several GPUs -- contiguous, ordered,
+    complete, balanced to within one block (same rule as zpaq_amd.dist.shard_range)."""
+    import ctypes as C
+    from zpaq_amd import dist as zd
+    L = zlib_.lib()
+    L.zpq_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.zpq_shard_range.restype = None
+    for n in (0, 1, 7, 8, 9, 1024, 8191, 8192):
+        for parts in (1, 2, 3, 4, 8):
+            prev = 0
+            for k in range(parts):
+                lo, hi = C.c_uint64(), C.c_uint64()
+                L.zpq_shard_range(n, parts, k, C.byref(lo), C.byref(hi))
+                assert lo.value == prev and hi.value >= lo.value and hi.value - lo.value in (n // parts, n // parts + 1)
+                assert (lo.value, hi.value) == tuple(zd.shard_range(n, k, parts))
+                prev = hi.value
+            assert prev == n

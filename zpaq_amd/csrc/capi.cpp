@@ -33,6 +33,7 @@ const char* zpq_version(void) { return "zpaq_amd 0.1 (ZPAQ level 2, libzpaq 7.15
 
 int zpq_init(int device) { ZPQ_TRY engine_init(device); return ZPQ_OK; ZPQ_CATCH }
 int zpq_device_count(void) { return engine_device_count(); }
+void zpq_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi) { engine_shard_range(n, parts ? parts : 1, k, lo, hi); }
 void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
 int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
 int zpq_set_kernel(int which) { if (which < 0 || which > 4) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }

@@ -13,6 +13,7 @@
 #include <exception>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "../host/codegen.hpp"
 #include "kernels.h"
@@ -75,9 +76,44 @@ struct Engine {
   hipEvent_t busy = nullptr;           // recorded after the last launch of a call that returned with work in flight
 };
 
-Engine& eng() {
-  static Engine e;
-  return e;
+// One engine per GPU.  `primary` serves the device-resident entry points and every batch when only one device is
+// configured; host-buffer batches are sharded over `ids` (contiguous block ranges, one thread and one engine per
+// device, no collective: blocks are independent, libzpaq.h:57-59).  Default: the one device LOCAL_RANK names (one
+// process per GPU under torch.distributed / zpaq_amd.dist); zpq_init(-1) or ZPAQ_AMD_DEVICES=all|0,1,.. selects more.
+struct DeviceSet {
+  std::mutex mu;
+  std::vector<int> ids;
+  int primary = -1;
+  uint64_t budget_override = 0;
+  int kernel_choice = 0;
+};
+DeviceSet& devset() { static DeviceSet d; return d; }
+Engine g_engines[zpq_plan::kMaxDevices];
+
+int default_device() {
+  if (const char* lr = getenv("LOCAL_RANK")) return atoi(lr);
+  return 0;
+}
+
+int primary_device() {
+  DeviceSet& d = devset();
+  std::lock_guard<std::mutex> g(d.mu);
+  if (d.primary < 0) {
+    d.primary = default_device();
+    if (d.primary < 0 || d.primary >= zpq_plan::kMaxDevices) d.primary = 0;
+  }
+  return d.primary;
+}
+
+Engine& eng(int dev = -1) {
+  if (dev < 0) dev = primary_device();
+  return g_engines[dev];
+}
+
+// binds the calling thread to a device: HIP's current device and the plan slot the loaders address
+void bind_device(int dev) {
+  HIP_CHECK(hipSetDevice(dev));
+  set_plan_device_index(dev);
 }
 
 int jit_budget() {
@@ -85,26 +121,22 @@ int jit_budget() {
   return 16;
 }
 
-void require_ready(Engine& e) {
-  if (!e.ready) {
-    // lazy default init: LOCAL_RANK selects the device (one process per GPU)
-    int dev = 0;
-    if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr);
-    engine_init_locked(dev);
-  }
+void engine_init_device(Engine& e, int device);
+void require_ready(Engine& e, int dev = -1) {
+  if (!e.ready) engine_init_device(e, dev < 0 ? primary_device() : dev);   // lazy default init
 }
 
 }  // namespace
 
-void engine_init_locked(int device) {
-  Engine& e = eng();
+namespace {
+void engine_init_device(Engine& e, int device) {
   if (e.ready && e.device == device) return;
   int count = 0;
   hipError_t err = hipGetDeviceCount(&count);
   if (err != hipSuccess || count <= 0)
     fail(ZPQ_E_DEVICE, "no HIP device available (the modelled path has no CPU fallback)");
-  if (device < 0 || device >= count) device = device % count;
-  HIP_CHECK(hipSetDevice(device));
+  if (device < 0 || device >= count) fail(ZPQ_E_DEVICE, "no such HIP device: " + std::to_string(device));
+  bind_device(device);
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
@@ -128,14 +160,47 @@ void engine_init_locked(int device) {
   HIP_CHECK(hipMemcpy(e.d_tables, &host_tb, sizeof(DeviceTables), hipMemcpyHostToDevice));
   size_t free_b = 0, total_b = 0;
   HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); e.budget = d.budget_override; e.kernel_choice = d.kernel_choice; }
   if (!e.budget) e.budget = (uint64_t)(free_b * 0.85);
   e.device = device;
   e.ready = true;
 }
+}  // namespace
 
+// Contiguous share of `n` blocks for shard `k` of `parts` (same rule as zpaq_amd.dist.shard_range).
+void engine_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi) {
+  *lo = n * k / parts;
+  *hi = n * (k + 1) / parts;
+}
+
+// device >= 0: drive that one GPU.  device == -1: every visible GPU, or the list in ZPAQ_AMD_DEVICES ("all" | "0,2,3").
 void engine_init(int device) {
-  std::lock_guard<std::mutex> g(eng().mu);
-  engine_init_locked(device);
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    fail(ZPQ_E_DEVICE, "no HIP device available (the modelled path has no CPU fallback)");
+  std::vector<int> ids;
+  const char* env = getenv("ZPAQ_AMD_DEVICES");
+  if (device >= 0 && !(env && env[0])) ids.push_back(device % count);
+  else if (!env || !env[0] || !strcmp(env, "all")) { for (int i = 0; i < count && i < zpq_plan::kMaxDevices; ++i) ids.push_back(i); }
+  else {
+    for (const char* p = env; *p;) {
+      if (*p >= '0' && *p <= '9') { const int v = atoi(p); if (v < count && v < zpq_plan::kMaxDevices) ids.push_back(v); while (*p >= '0' && *p <= '9') ++p; }
+      else ++p;
+    }
+    if (ids.empty()) fail(ZPQ_E_ARG, "ZPAQ_AMD_DEVICES names no usable device");
+  }
+  {
+    DeviceSet& d = devset();
+    std::lock_guard<std::mutex> g(d.mu);
+    d.ids = ids;
+    d.primary = (device >= 0 && std::find(ids.begin(), ids.end(), device % count) != ids.end()) ? device % count : ids[0];
+  }
+  for (int id : ids) {
+    Engine& e = g_engines[id];
+    std::lock_guard<std::mutex> g(e.mu);
+    engine_init_device(e, id);
+  }
+  bind_device(primary_device());
 }
 
 int engine_device_count() {
@@ -145,39 +210,59 @@ int engine_device_count() {
 }
 
 void engine_shutdown() {
-  Engine& e = eng();
-  std::lock_guard<std::mutex> g(e.mu);
-  if (!e.ready) return;
-  (void)hipSetDevice(e.device);
-  (void)hipStreamSynchronize(e.stream);
-  e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release();
-  for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
-  if (e.busy) { (void)hipEventDestroy(e.busy); e.busy = nullptr; }
-  if (e.d_tables) (void)hipFree(e.d_tables);
-  e.d_tables = nullptr;
-  if (e.stream) (void)hipStreamDestroy(e.stream);
-  e.stream = nullptr;
-  e.ready = false;
+  for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
+    Engine& e = g_engines[id];
+    std::lock_guard<std::mutex> g(e.mu);
+    if (!e.ready) continue;
+    (void)hipSetDevice(e.device);
+    (void)hipStreamSynchronize(e.stream);
+    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release();
+    for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
+    for (auto& ss : e.side) (void)hipStreamDestroy(ss);
+    e.side.clear();
+    if (e.busy) { (void)hipEventDestroy(e.busy); e.busy = nullptr; }
+    if (e.d_tables) (void)hipFree(e.d_tables);
+    e.d_tables = nullptr;
+    if (e.stream) (void)hipStreamDestroy(e.stream);
+    e.stream = nullptr;
+    e.ready = false;
+  }
 }
 
-void engine_set_budget(uint64_t bytes) { std::lock_guard<std::mutex> g(eng().mu); eng().budget = bytes; }
-void engine_set_kernel(int which) { std::lock_guard<std::mutex> g(eng().mu); eng().kernel_choice = which; }
-Timing engine_last_timing() { std::lock_guard<std::mutex> g(eng().mu); return eng().last; }
+void engine_set_budget(uint64_t bytes) {
+  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); d.budget_override = bytes; }
+  for (Engine& e : g_engines) { std::lock_guard<std::mutex> g(e.mu); if (e.ready) e.budget = bytes; }
+}
+void engine_set_kernel(int which) {
+  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); d.kernel_choice = which; }
+  for (Engine& e : g_engines) { std::lock_guard<std::mutex> g(e.mu); e.kernel_choice = which; }
+}
+Timing engine_last_timing() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last; }
 
 static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
-  if (p->d_blob && p->d_device == e.device) return (const uint8_t*)p->d_blob;
+  zpq_plan::OnDevice& od = p->dev[e.device];
+  if (od.d_blob) return (const uint8_t*)od.d_blob;
   void* d = nullptr;
   HIP_CHECK(hipMalloc(&d, p->blob.size()));
   HIP_CHECK(hipMemcpy(d, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
-  p->d_blob = d;
-  p->d_device = e.device;
+  od.d_blob = d;
   return (const uint8_t*)d;
 }
 
 void engine_plan_release(zpq_plan* p) {
-  if (p && p->d_blob) { (void)hipFree(p->d_blob); p->d_blob = nullptr; }
-  spec_kernel_release(p);
+  if (!p) return;
+  int before = -1;
+  (void)hipGetDevice(&before);
+  for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
+    zpq_plan::OnDevice& od = p->dev[id];
+    if (!od.d_blob && !od.pipe && !od.spec[0] && !od.spec[1]) continue;
+    if (hipSetDevice(id) != hipSuccess) continue;
+    set_plan_device_index(id);
+    if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
+    spec_kernel_release(p);
+  }
+  if (before >= 0) { (void)hipSetDevice(before); set_plan_device_index(before); }
 }
 
 // Which kernel codes a plan: 4 = pipelined encoder (compression only, device/pipe_kernel.h), 3 = per-header
@@ -207,20 +292,20 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
     PipeKernel* k = pipe_kernel_for(p, want == 4 || e.jit_left > 0, &did);
     if (did && e.jit_left > 0) --e.jit_left;
     if (k) { r.kind = 4; r.pipe = k; return r; }
-    if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->pipe_note);
+    if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->cur().pipe_note);
   }
   const int forced = spec_variant_forced();
   const int first = forced >= 0 ? forced : (dense ? 1 : 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1 && forced >= 0) break;                                     // a forced shape has no fallback
     const int variant = attempt == 0 ? first : 1 - first;
-    if (attempt == 1 && p->spec_state[variant] <= 0) break;                     // fall back only to a shape already loaded
+    if (attempt == 1 && p->cur().spec_state[variant] <= 0) break;                     // fall back only to a shape already loaded
     bool did = false;
     SpecKernel* k = spec_kernel_for(p, variant, want >= 3 || e.jit_left > 0, nullptr, &did);
     if (did && e.jit_left > 0) --e.jit_left;
     if (k) { r.kind = 3; r.spec = k; return r; }
   }
-  if (want >= 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->spec_note);
+  if (want >= 3) fail(ZPQ_E_UNSUPPORTED, "specialised kernel unavailable: " + p->cur().spec_note);
   r.kind = 2;
   return r;
 }
@@ -229,10 +314,10 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  HIP_CHECK(hipSetDevice(e.device));
+  bind_device(e.device);
   e.jit_left = jit_budget();
   const KernelPick k = kernel_kind(e, p, false, decode);
-  note = k.kind == 4 ? p->pipe_note : p->spec_note;
+  note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
 
@@ -554,11 +639,39 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
 }
 
 namespace {
+void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results);
+
+// One batch of host blocks: on the one configured device, or sharded over all of them (block b of B goes to shard
+// b * G / B -- contiguous ranges, output order preserved), one thread per device.
 void engine_code_host_now(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
-  Engine& e = eng();
+  std::vector<int> ids;
+  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); ids = d.ids; }
+  if (ids.empty()) ids.push_back(primary_device());
+  const size_t parts = std::min(ids.size(), blocks.size());
+  if (parts <= 1) { engine_code_host_on(ids[0], decode, blocks, results); return; }
+  results.assign(blocks.size(), BlockResult{0, 0, 0, 0});
+  std::vector<std::exception_ptr> errs(parts);
+  std::vector<std::thread> pool;
+  for (size_t k = 0; k < parts; ++k)
+    pool.emplace_back([&, k] {
+      try {
+        uint64_t lo, hi;
+        engine_shard_range(blocks.size(), (uint32_t)parts, (uint32_t)k, &lo, &hi);
+        std::vector<HostBlock> mine(blocks.begin() + (long)lo, blocks.begin() + (long)hi);
+        std::vector<BlockResult> res;
+        engine_code_host_on(ids[k], decode, mine, res);
+        std::copy(res.begin(), res.end(), results.begin() + (long)lo);
+      } catch (...) { errs[k] = std::current_exception(); }
+    });
+  for (auto& t : pool) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
+
+void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results) {
+  Engine& e = eng(dev);
   std::lock_guard<std::mutex> g(e.mu);
-  require_ready(e);
-  HIP_CHECK(hipSetDevice(e.device));
+  require_ready(e, dev);
+  bind_device(e.device);
   wait_in_flight(e);
   const size_t nb = blocks.size();
   e.jit_left = jit_budget();
@@ -647,7 +760,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  HIP_CHECK(hipSetDevice(e.device));
+  bind_device(e.device);
   wait_in_flight(e);
   hipStream_t st = stream ? (hipStream_t)stream : e.stream;
   e.jit_left = jit_budget();
@@ -696,7 +809,7 @@ int engine_selftest(int32_t out[8]) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  HIP_CHECK(hipSetDevice(e.device));
+  bind_device(e.device);
   int32_t* d = nullptr;
   HIP_CHECK(hipMalloc((void**)&d, 8 * sizeof(int32_t)));
   HIP_CHECK(hipMemsetAsync(d, 0, 8 * sizeof(int32_t), e.stream));

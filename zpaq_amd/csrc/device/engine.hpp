@@ -24,7 +24,8 @@ struct Timing {
 };
 
 void engine_init(int device);
-void engine_init_locked(int device);
+// contiguous share [lo, hi) of n blocks for shard k of `parts` (how host batches are split over devices)
+void engine_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi);
 int engine_device_count();
 void engine_shutdown();
 void engine_set_budget(uint64_t bytes);

@@ -8,6 +8,10 @@
 
 namespace zpq {
 
+static thread_local int tl_plan_device = 0;
+int plan_device_index() { return tl_plan_device; }
+void set_plan_device_index(int dev) { tl_plan_device = (dev >= 0 && dev < zpq_plan::kMaxDevices) ? dev : 0; }
+
 static const int kCompLen[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};   // libzpaq.cpp:714
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }

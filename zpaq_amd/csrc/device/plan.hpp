@@ -10,22 +10,35 @@ struct zpq_plan {
   std::vector<uint8_t> blob;       // PlanHeader + CompDesc[] + Segment[] + prog (host copy)
   double memory = 0;               // ZPAQL::memory()
   double algo_bytes = 0;
-  void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
-  int d_device = -1;
-  // per-header specialised kernels (device/spec_loader.hpp), one per workgroup shape:
-  // [0] 4 blocks per workgroup (all side tables in LDS, one wavefront per SIMD), [1] 8 (two per SIMD); the
-  // engine chooses per launch.  (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
-  void* spec[2] = {nullptr, nullptr};   // SpecKernel*
-  int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
-  void* pipe = nullptr;                 // PipeKernel*: the pipelined encoder (device/pipe_kernel.h)
-  int pipe_state = 0;                   // 0 not tried, 1 loaded, -1 unavailable
-  std::string pipe_note;
-  std::string spec_note;                // where the last kernel came from / why it is unavailable
+  // Everything a plan owns ON A DEVICE -- its uploaded copy and the loaded code objects -- exists once per GPU the
+  // engine drives (one engine per device, host-buffer batches are sharded over them).  The loaders and the engine
+  // address the slot of the device the calling thread works for (zpq::plan_device_index()).
+  struct OnDevice {
+    void* d_blob = nullptr;          // device copy (lazily uploaded by the engine)
+    // per-header specialised kernels (device/spec_loader.hpp), one per workgroup shape: [0] 4 blocks per workgroup
+    // (all side tables in LDS, one wavefront per SIMD), [1] 8 (two per SIMD); the engine chooses per launch.
+    // (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
+    void* spec[2] = {nullptr, nullptr};   // SpecKernel*
+    int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
+    void* pipe = nullptr;                 // PipeKernel*: the pipelined encoder (device/pipe_kernel.h)
+    int pipe_state = 0;
+    std::string pipe_note, spec_note;     // where the last kernel came from / why it is unavailable
+  };
+  static const int kMaxDevices = 16;
+  OnDevice dev[kMaxDevices];
+  OnDevice& cur();
+  const OnDevice& cur() const;
   const zpq::PlanHeader& hdr() const { return *(const zpq::PlanHeader*)blob.data(); }
   const zpq::CompDesc* comps() const { return (const zpq::CompDesc*)(blob.data() + hdr().off_comp); }
 };
 
 namespace zpq {
+// device slot the calling thread works for (set by the engine around every use of a plan's device state)
+int plan_device_index();
+void set_plan_device_index(int dev);
 // Parses a stored block header into a plan; throws Failure(ZPQ_E_HEADER/...).
 zpq_plan* plan_from_header(const U8* header, size_t hlen);
 }
+
+inline zpq_plan::OnDevice& zpq_plan::cur() { return dev[zpq::plan_device_index()]; }
+inline const zpq_plan::OnDevice& zpq_plan::cur() const { return dev[zpq::plan_device_index()]; }

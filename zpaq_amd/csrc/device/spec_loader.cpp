@@ -135,12 +135,12 @@ size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log
 
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* jit_deferred, bool* did_jit) {
   if (variant < 0 || variant > 1) variant = 0;
-  if (plan->spec_state[variant] > 0) return (SpecKernel*)plan->spec[variant];
-  if (plan->spec_state[variant] < 0) return nullptr;
-  plan->spec_state[variant] = -1;
-  if (getenv("ZPAQ_AMD_NO_SPEC")) { plan->spec_note = "disabled by ZPAQ_AMD_NO_SPEC"; return nullptr; }
+  if (plan->cur().spec_state[variant] > 0) return (SpecKernel*)plan->cur().spec[variant];
+  if (plan->cur().spec_state[variant] < 0) return nullptr;
+  plan->cur().spec_state[variant] = -1;
+  if (getenv("ZPAQ_AMD_NO_SPEC")) { plan->cur().spec_note = "disabled by ZPAQ_AMD_NO_SPEC"; return nullptr; }
   std::string source, key, why;
-  if (!spec_source_and_key(*plan, variant, source, key, why)) { plan->spec_note = why; return nullptr; }
+  if (!spec_source_and_key(*plan, variant, source, key, why)) { plan->cur().spec_note = why; return nullptr; }
   std::vector<char> code;
   std::string origin;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
@@ -150,15 +150,15 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
     origin = "cache:" + key;
   } else {
     if (!allow_jit) {                       // not prebuilt and the caller's JIT budget is spent
-      plan->spec_state[variant] = 0;
-      plan->spec_note = "hipRTC compile deferred (JIT budget of this batch spent)";
+      plan->cur().spec_state[variant] = 0;
+      plan->cur().spec_note = "hipRTC compile deferred (JIT budget of this batch spent)";
       if (jit_deferred) *jit_deferred = true;
       return nullptr;
     }
     if (did_jit) *did_jit = true;
     std::string log;
     if (!compile_hiprtc(source, code, log)) {
-      plan->spec_note = "hipRTC compile failed: " + log.substr(0, 2000);
+      plan->cur().spec_note = "hipRTC compile failed: " + log.substr(0, 2000);
       return nullptr;
     }
     origin = "hiprtc";
@@ -174,7 +174,7 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
       hipModuleGetFunction(&k->encode, k->module, "zpq_spec_encode") != hipSuccess ||
       hipModuleGetFunction(&k->decode, k->module, "zpq_spec_decode") != hipSuccess) {
-    plan->spec_note = "hipModuleLoadData failed for " + origin;
+    plan->cur().spec_note = "hipModuleLoadData failed for " + origin;
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
     return nullptr;
@@ -183,19 +183,19 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   if (hipFuncGetAttribute(&maxthr, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, k->encode) == hipSuccess && maxthr >= 64)
     k->waves = maxthr / 64;
   k->origin = origin;
-  plan->spec[variant] = k;
-  plan->spec_state[variant] = 1;
-  plan->spec_note = origin;
+  plan->cur().spec[variant] = k;
+  plan->cur().spec_state[variant] = 1;
+  plan->cur().spec_note = origin;
   return k;
 }
 
 PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
-  if (plan->pipe_state > 0) return (PipeKernel*)plan->pipe;
-  if (plan->pipe_state < 0) return nullptr;
-  plan->pipe_state = -1;
-  if (getenv("ZPAQ_AMD_NO_PIPE")) { plan->pipe_note = "disabled by ZPAQ_AMD_NO_PIPE"; return nullptr; }
+  if (plan->cur().pipe_state > 0) return (PipeKernel*)plan->cur().pipe;
+  if (plan->cur().pipe_state < 0) return nullptr;
+  plan->cur().pipe_state = -1;
+  if (getenv("ZPAQ_AMD_NO_PIPE")) { plan->cur().pipe_note = "disabled by ZPAQ_AMD_NO_PIPE"; return nullptr; }
   std::string source, key, why;
-  if (!pipe_source_and_key(*plan, source, key, why)) { plan->pipe_note = why; return nullptr; }
+  if (!pipe_source_and_key(*plan, source, key, why)) { plan->cur().pipe_note = why; return nullptr; }
   std::vector<char> code;
   std::string origin, blob;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
@@ -204,14 +204,14 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
     origin = "cache:" + key;
   } else {
     if (!allow_jit) {
-      plan->pipe_state = 0;
-      plan->pipe_note = "hipRTC compile deferred (JIT budget of this batch spent)";
+      plan->cur().pipe_state = 0;
+      plan->cur().pipe_note = "hipRTC compile deferred (JIT budget of this batch spent)";
       return nullptr;
     }
     if (did_jit) *did_jit = true;
     std::string log;
     if (!compile_hiprtc(source, code, log)) {
-      plan->pipe_note = "hipRTC compile failed: " + log.substr(0, 2000);
+      plan->cur().pipe_note = "hipRTC compile failed: " + log.substr(0, 2000);
       return nullptr;
     }
     origin = "hiprtc";
@@ -228,33 +228,33 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
   bool ok = hipModuleLoadData(&k->module, code.data()) == hipSuccess;
   for (int i = 0; ok && i < 6; ++i) ok = hipModuleGetFunction(&k->fn[i], k->module, names[i]) == hipSuccess;
   if (!ok) {
-    plan->pipe_note = "hipModuleLoadData failed for " + origin;
+    plan->cur().pipe_note = "hipModuleLoadData failed for " + origin;
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
     return nullptr;
   }
   k->origin = origin;
-  plan->pipe = k;
-  plan->pipe_state = 1;
-  plan->pipe_note = origin;
+  plan->cur().pipe = k;
+  plan->cur().pipe_state = 1;
+  plan->cur().pipe_note = origin;
   return k;
 }
 
 void spec_kernel_release(zpq_plan* plan) {
-  if (plan && plan->pipe) {
-    PipeKernel* k = (PipeKernel*)plan->pipe;
+  if (plan && plan->cur().pipe) {
+    PipeKernel* k = (PipeKernel*)plan->cur().pipe;
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
-    plan->pipe = nullptr;
-    plan->pipe_state = 0;
+    plan->cur().pipe = nullptr;
+    plan->cur().pipe_state = 0;
   }
   for (int v = 0; plan && v < 2; ++v) {
-    if (!plan->spec[v]) continue;
-    SpecKernel* k = (SpecKernel*)plan->spec[v];
+    if (!plan->cur().spec[v]) continue;
+    SpecKernel* k = (SpecKernel*)plan->cur().spec[v];
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
-    plan->spec[v] = nullptr;
-    plan->spec_state[v] = 0;
+    plan->cur().spec[v] = nullptr;
+    plan->cur().spec_state[v] = 0;
   }
 }
 
