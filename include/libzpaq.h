@@ -203,6 +203,9 @@ class Decompresser {
   bool seg_decoded_;
   int segs_in_block_;
   void* pp_;                 // PostProcessor of the current block (first segment carries the PP header)
+  std::vector<std::vector<U8> > block_cache_;   // modelled block of several segments: all of them, decoded together
+  bool skipped_in_block_;
+  int peek(size_t off);      // byte at rpos_ + off without consuming it (-1 at EOF)
   enum { BLOCK, FILENAME, COMMENT, DATA, SEGEND } state_;
 };
 
@@ -236,6 +239,10 @@ class Compressor {
   Reader* in_;
   std::vector<U8> header_, pcomp_;
   std::vector<U8> pending_;   // PP header + segment bytes awaiting the device
+  // a modelled block is coded when it ends (all its segments in ONE device job: the model runs on across them):
+  // per segment its header bytes, its data, its trailer
+  struct SegBuf { std::vector<U8> head, data, tail; };
+  std::vector<SegBuf> segq_;
   SHA1 seg_sha1_;
   char sha1result_[20];
   bool verify_;

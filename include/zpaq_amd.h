@@ -96,6 +96,10 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * [9] blocks per group (= threads per workgroup of every kernel but hcomp, which has 64), [10] ROW units. */
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
+/* The same for a block's PCOMP post-processing program (device/pcomp_kernel.h: LZ77 / BWT / E8E9 inverses run one
+ * lane per segment on the device when a batch has enough of them): code = the PCOMP bytes without their 2-byte
+ * length, ph / pm = header bytes 4 and 5. */
+int zpq_pcomp_source(const uint8_t* code, size_t codelen, int ph, int pm, char* src, size_t cap, size_t* len, char key41[41]);
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
@@ -168,6 +172,10 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
 /* Durations (ms, hipEvent) of the last timed call on this process: Predictor
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
+/* SHA-1 (libzpaq::SHA1, libzpaq.cpp:106-177) of n buffers ON THE DEVICE, one lane per buffer, 20 bytes each into
+ * out20n.  zpq_compress_blocks uses the same kernel for blocks that reach the device unchanged (methods without
+ * pre-processing): the digest for the segment trailer is computed beside the coder instead of on a host thread. */
+int zpq_sha1_batch_device(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out20n);
 /* Wall-clock phases (ms) of this process's last zpq_compress_blocks call -- the end-to-end path through the
  * drop-in API: out[0] total, [1] host front half (SHA-1, method expansion, header assembly), [2] device call
  * (staging + H2D + kernels + D2H), [3] archive stitching, [4] / [5] the Predictor-init and coding kernels inside

@@ -99,6 +99,20 @@ class Ref:
         return self._call_out(self.lib.ref_compress_level, data, n + n // 4 + 4096,
                               int(level), self._s(filename), self._s(comment), int(dosha1))
 
+    def compress_level_segments(self, parts, level) -> bytes:
+        """one block, built-in model `level`, one segment per part (named s0, s1, ..; SHA-1 trailers)"""
+        parts = [_bytes_arr(p) for p in parts]
+        allb = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        lens = (C.c_size_t * len(parts))(*[p.size for p in parts])
+        cap = allb.size * 2 + 65536
+        out = np.empty(cap, np.uint8)
+        self.lib.ref_compress_level_segments.restype = C.c_longlong
+        self.lib.ref_compress_level_segments.argtypes = [_u8p, C.POINTER(C.c_size_t), C.c_int, C.c_int, _u8p, C.c_size_t]
+        r = self.lib.ref_compress_level_segments(_ptr(allb), lens, len(parts), int(level), _ptr(out), cap)
+        if r < 0:
+            raise self._err()
+        return out[:r].tobytes()
+
     def compress_config(self, data, config, args=None, filename=None, comment=None, dosha1=True) -> bytes:
         n = len(data)
         a9 = (C.c_int * 9)(*(list(args or []) + [0] * 9)[:9])

@@ -108,6 +108,32 @@ long long ref_compress_level(const unsigned char* in, size_t n, int level,
   } catch (std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// One block of SEVERAL segments through a built-in model (libzpaq.cpp:2889-2891: the model and the coder are
+// initialised once per block and run on across its segments).  Segment i is named "s<i>", has a SHA-1 trailer.
+long long ref_compress_level_segments(const unsigned char* in, const size_t* lens, int nseg, int level,
+                                      unsigned char* out, size_t cap) {
+  try {
+    CapWriter w(out, cap);
+    libzpaq::Compressor co;
+    co.setOutput(&w);
+    co.writeTag();
+    co.startBlock(level);
+    size_t pos = 0;
+    for (int i = 0; i < nseg; ++i) {
+      MemReader r(in + pos, lens[i]);
+      co.setInput(&r);
+      std::string name = "s" + std::to_string(i);
+      co.startSegment(name.c_str(), 0);
+      co.compress(-1);
+      libzpaq::SHA1 s; s.write((const char*)in + pos, (int64_t)lens[i]);
+      co.endSegment(s.result());
+      pos += lens[i];
+    }
+    co.endBlock();
+    return (long long)w.n;
+  } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+
 // Arbitrary ZPAQL source config through Compressor::startBlock(config,args)
 // (libzpaq.cpp:2856) -- used to exercise all nine component types.
 long long ref_compress_config(const unsigned char* in, size_t n, const char* config,

@@ -3,6 +3,8 @@
 //                                       hdrN = expected header bytes (hex) of Compressor::startBlock(N)
 //   compat_test gpu                   : everything, including the modelled methods
 //   compat_test level N in out        : Compressor::startBlock(N) over file `in` (one segment, SHA-1) -> file `out`
+//   compat_test segments N out in.. : one block, built-in model N, one segment per input file (named s0, s1, ..) -> `out`;
+//                                       then decodes it back both ways and checks the data
 //   compat_test threads T method      : T threads, one libzpaq::compressBlock each, like zpaq.cpp's compressThread pool
 // Prints "COMPAT_OK <n checks>" on success.
 #include <chrono>
@@ -98,6 +100,65 @@ int main(int argc, char** argv) {
       fwrite(arc.c_str(), 1, arc.size(), f);
       fclose(f);
       printf("COMPAT_OK 1\n");
+      return 0;
+    }
+    if (mode == "segments") {
+      const int level = atoi(argv[2]);
+      std::vector<std::string> parts;
+      for (int i = 4; i < argc; ++i) parts.push_back(slurp(argv[i]));
+      libzpaq::StringBuffer arc;
+      libzpaq::Compressor co;
+      co.setOutput(&arc);
+      co.writeTag();
+      co.startBlock(level);
+      for (size_t i = 0; i < parts.size(); ++i) {
+        libzpaq::StringBuffer in;
+        in.write(parts[i].data(), (int)parts[i].size());
+        co.setInput(&in);
+        co.startSegment(("s" + std::to_string(i)).c_str(), 0);
+        co.compress(-1);
+        libzpaq::SHA1 s;
+        s.write(parts[i].data(), (int64_t)parts[i].size());
+        co.endSegment(s.result());
+      }
+      co.endBlock();
+      FILE* f = fopen(argv[3], "wb");
+      fwrite(arc.c_str(), 1, arc.size(), f);
+      fclose(f);
+      const std::string archive(arc.c_str(), arc.size());
+      // whole-archive decompress (all segments concatenated)
+      {
+        libzpaq::StringBuffer a2, out;
+        a2.write(archive.data(), (int)archive.size());
+        libzpaq::decompress(&a2, &out);
+        std::string want;
+        for (auto& p : parts) want += p;
+        CHECK(std::string(out.c_str(), out.size()) == want);
+      }
+      // streaming Decompresser: segment by segment, the second one in pieces, checksums verified
+      {
+        CountingReader rd(archive);
+        libzpaq::Decompresser de;
+        de.setInput(&rd);
+        CHECK(de.findBlock());
+        for (size_t i = 0; i < parts.size(); ++i) {
+          libzpaq::StringBuffer fn, out;
+          CHECK(de.findFilename(&fn));
+          CHECK(std::string(fn.c_str(), fn.size()) == "s" + std::to_string(i));
+          de.readComment();
+          libzpaq::SHA1 h;
+          de.setOutput(&out);
+          de.setSHA1(&h);
+          if (i == 1) { while (de.decompress(1000)) {} } else de.decompress(-1);
+          CHECK(std::string(out.c_str(), out.size()) == parts[i]);
+          char sh[21];
+          de.readSegmentEnd(sh);
+          CHECK(sh[0] == 1 && memcmp(sh + 1, h.result(), 20) == 0);
+        }
+        CHECK(!de.findFilename());
+        CHECK(rd.pos - (size_t)de.buffered() == archive.size());
+      }
+      printf("COMPAT_OK %d\n", checks);
       return 0;
     }
     if (mode == "threads") {       // concurrent callers, each with its own buffers (libzpaq.h:57-59)

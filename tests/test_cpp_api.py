@@ -55,3 +55,24 @@ def test_concurrent_callers_are_coalesced(tmp_path, gpu):
     exe = _build(tmp_path)
     r = subprocess.run([exe, "threads", "32", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_blocks_of_several_segments(tmp_path, gpu, ref):
+    """Compressor: three segments in one modelled block (mid.cfg and max.cfg) -- the model and the coder run on from
+    segment to segment (libzpaq.cpp:2889-2891, 2129).  Archive identical to the reference's; decoded both through
+    libzpaq::decompress and segment by segment through Decompresser (inside the C++ program)."""
+    from zpaq_amd import corpus
+    exe = _build(tmp_path)
+    parts = [corpus.block("text", 30000, 61).tobytes(), corpus.block("records", 17000, 62).tobytes(), b"", corpus.block("text", 9000, 63).tobytes()]
+    paths = []
+    for i, p in enumerate(parts):
+        paths.append(str(tmp_path / f"part{i}"))
+        open(paths[-1], "wb").write(p)
+    for level in (2, 3):
+        dst = str(tmp_path / f"multi{level}.zpaq")
+        r = subprocess.run([exe, "segments", str(level), dst, *paths], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
+        ours = open(dst, "rb").read()
+        assert ours == ref.compress_level_segments(parts, level), level
+        assert gpu.decompress(ours) == b"".join(parts)

@@ -419,3 +419,44 @@ def test_method_3_known_answer_and_preprocessing_levels(gpu, ref):
         for b, a in zip(blocks, ours):
             assert a == ref.compress_block(b.copy(), m), m
         assert gpu.decompress(b"".join(ours)) == b"".join(b.tobytes() for b in blocks), m
+
+
+def test_sha1_on_the_device(gpu):
+    """sha1_blocks_kernel against hashlib: lengths around every padding boundary, unaligned starts come from the
+    PP-byte offset inside compress_blocks (whole-archive tests cover that), a few MiB-sized buffers."""
+    import ctypes as C
+    L = gpu.lib()
+    rng = np.random.default_rng(4)
+    lens = list(range(0, 130)) + [55, 56, 63, 64, 65, 119, 120, 127, 128, 1000, 4095, 4096, 65537, (1 << 20) + 3, 3 << 20]
+    bufs = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    n = len(bufs)
+    IA = (C.POINTER(C.c_uint8) * n)(*[b.ctypes.data_as(C.POINTER(C.c_uint8)) for b in bufs])
+    LN = (C.c_uint32 * n)(*lens)
+    out = np.zeros(20 * n, np.uint8)
+    L.zpq_sha1_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    assert L.zpq_sha1_batch_device(IA, LN, n, out.ctypes.data) == 0, L.zpq_last_error()
+    for i, b in enumerate(bufs):
+        assert out[20 * i:20 * i + 20].tobytes() == hashlib.sha1(b.tobytes()).digest(), lens[i]
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_pcomp_post_processing_on_the_device(gpu, ref, monkeypatch, mode):
+    """Reference archives of the LZ77 / BWT / E8E9 methods: the block's PCOMP program, translated to HIP, runs one
+    lane per segment on the GPU (ZPAQ_AMD_PCOMP=device forces it even for this small batch); the host interpreter
+    must give the same bytes."""
+    monkeypatch.setenv("ZPAQ_AMD_PCOMP", mode)
+    r = np.random.default_rng(8)
+    exe = r.integers(0, 256, 50000, dtype=np.uint8)
+    exe[::37] = 0xE8
+    exe[4::37] = 0
+    parts, stream = [], b""
+    for kind, n, m in [("lcg", 40000, "3"), ("text", 60000, "3"), ("text", 50000, "3,128,1"), ("records", 30000, "4,30,0"),
+                       ("text", 30000, "4,128,3"), ("pattern", 20000, "3,200,2"), ("text", 70000, "1"), ("records", 44000, "2"),
+                       ("zeros", 10000, "1"), ("text", 0, "2"), ("text", 33000, "2,128,1")]:
+        d = corpus.block(kind, n, 99)
+        parts.append(d.tobytes())
+        stream += ref.compress_block(d, m)
+    for m in ("1,128,2", "3,100,2", "4,240,3", "x0,7", "x0,4"):
+        parts.append(exe.tobytes())
+        stream += ref.compress_block(exe.copy(), m)
+    assert gpu.decompress(stream) == b"".join(parts)

@@ -107,6 +107,18 @@ int zpq_plan_pipe_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   ZPQ_CATCH
 }
 
+int zpq_pcomp_source(const uint8_t* code, size_t codelen, int ph, int pm, char* src, size_t cap, size_t* len, char key41[41]) {
+  ZPQ_TRY
+  std::string source, key, why;
+  if (!pcomp_source_and_key(code, codelen, ph, pm, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (len) *len = source.size();
+  if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
+  if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
+  memcpy(src, source.c_str(), source.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_plan_pipe_layout(const zpq_plan* p, uint64_t out[16]) {
   ZPQ_TRY
   if (!p || !out) fail(ZPQ_E_ARG, "null argument");
@@ -301,6 +313,14 @@ int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t
   *len = pre.size();
   if (pre.size() > cap) fail(ZPQ_E_OVERFLOW, "output buffer too small");
   if (!pre.empty()) memcpy(out, pre.data(), pre.size());
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_sha1_batch_device(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out20n) {
+  ZPQ_TRY
+  if (n && (!in || !len || !out20n)) fail(ZPQ_E_ARG, "null argument");
+  engine_sha1_host(in, len, n, out20n);
   return ZPQ_OK;
   ZPQ_CATCH
 }

@@ -66,6 +66,8 @@ struct Engine {
   uint64_t budget = 0;
   int kernel_choice = 0;
   DevBuf arena, io_in, io_out, jobs, results;
+  DevBuf segs;                         // segment tables of multi-segment blocks
+  DevBuf sha_jobs, sha_out;            // SHA-1 of the staged inputs (sha1_blocks_kernel)
   DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
   hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
@@ -216,7 +218,7 @@ void engine_shutdown() {
     if (!e.ready) continue;
     (void)hipSetDevice(e.device);
     (void)hipStreamSynchronize(e.stream);
-    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release();
+    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release();
     for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
     for (auto& ss : e.side) (void)hipStreamDestroy(ss);
     e.side.clear();
@@ -403,8 +405,34 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
             kv.second.first / kv.second.second, kv.second.second);
 }
 
+// profiling aid (ZPAQ_AMD_PIPE_SPLIT): extra streams so that per-unit launches of one kernel still overlap
+static std::vector<hipStream_t> g_split_streams;
+static std::vector<std::pair<hipStream_t, hipStream_t>> g_split_used;      // (unit stream, the kernel stream it joins)
+static hipStream_t split_stream(Engine&, size_t idx, hipStream_t parent) {
+  while (g_split_streams.size() <= idx) {
+    hipStream_t s2;
+    HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    g_split_streams.push_back(s2);
+  }
+  hipStream_t su = g_split_streams[idx];
+  Event fork;
+  HIP_CHECK(hipEventRecord(fork, parent));
+  HIP_CHECK(hipStreamWaitEvent(su, fork, 0));
+  g_split_used.push_back({su, parent});
+  return su;
+}
+static void split_join(Engine&) {
+  for (auto& pr : g_split_used) {
+    Event done;
+    HIP_CHECK(hipEventRecord(done, pr.first));
+    HIP_CHECK(hipStreamWaitEvent(pr.second, done, 0));
+  }
+  g_split_used.clear();
+}
+
 static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
   if (runs.empty()) return;
+  const bool split = getenv("ZPAQ_AMD_PIPE_SPLIT") != nullptr;
   if (getenv("ZPAQ_AMD_PIPE_PROFILE")) { launch_pipe_profiled(e, runs, st); return; }
   for (auto& ps : e.pstream)
     if (!ps) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
@@ -419,9 +447,24 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
       if (step >= r.nsteps) continue;
       r.args.step = (int32_t)step;
       void* args[1] = {(void*)&r.args};
-      for (int k = 0; k < 6; ++k)
-        if (r.grid[k])
-          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : r.threads, 1, 1, 0, e.pstream[k], args, nullptr));
+      for (int k = 0; k < 6; ++k) {
+        if (!r.grid[k]) continue;
+        if (split && k != 0) {
+          // ZPAQ_AMD_PIPE_SPLIT=1 (profiling aid): one launch per unit type, so that a kernel trace shows which unit of
+          // a kernel is the slow one; still concurrent on the kernel's stream? no -- same stream serialises them, so the
+          // extra streams below keep them parallel
+          for (uint32_t w0 = 0, ui = 0; w0 < r.grid[k]; w0 += r.ngroups, ++ui) {
+            PipeArgs a2 = r.args;
+            a2.wg0 = w0;
+            void* args2[1] = {(void*)&a2};
+            hipStream_t su = split_stream(e, (size_t)k * 64 + ui, e.pstream[k]);
+            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, r.threads, 1, 1, 0, su, args2, nullptr));
+          }
+          continue;
+        }
+        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : r.threads, 1, 1, 0, e.pstream[k], args, nullptr));
+      }
+      if (split) split_join(e);
     }
     // join: stream 0 waits for 1..4, then 1..4 wait for stream 0
     for (int k = 1; k < 6; ++k) {
@@ -530,6 +573,13 @@ static void wait_in_flight(Engine& e) {
 static void mark_in_flight(Engine& e, hipStream_t st) {
   if (!e.busy) HIP_CHECK(hipEventCreateWithFlags(&e.busy, hipEventDisableTiming));
   HIP_CHECK(hipEventRecord(e.busy, st));
+}
+
+// kernel kind of sorted job k
+static int kind_of_sorted(const std::vector<LaunchGroup>& groups, size_t k) {
+  for (const LaunchGroup& g : groups)
+    if (k >= g.first && k < (size_t)g.first + g.count) return g.pick.kind;
+  return 0;
 }
 
 // Sort `order` so that every (kernel, plan) group is contiguous, and cut it into launch groups.
@@ -710,11 +760,34 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     std::vector<BlockJob> jobs(cnt);
     std::vector<uint8_t> stage(in_bytes + 64);
     std::vector<uint64_t> out_off(cnt);
+    // segment tables of the blocks that have several segments
+    std::vector<SegRange> segtab;
+    std::vector<size_t> seg_first(cnt, 0);
+    for (size_t k = 0; k < cnt; ++k) {
+      const HostBlock& hb = blocks[order[k]];
+      if (hb.nseg <= 1) continue;
+      const int kd = kind_of_sorted(groups, k);
+      if (kd != (decode ? 3 : 4))
+        fail(ZPQ_E_UNSUPPORTED, "blocks of several segments need the pipelined encoder / the per-header wavefront decoder");
+      seg_first[k] = segtab.size();
+      U32 at = 0;
+      for (U32 sgi = 0; sgi < hb.nseg; ++sgi) {
+        const U32 l = hb.seg_len[sgi] + (sgi == 0 ? hb.prefix_len : 0);
+        segtab.push_back(SegRange{at, at + l, 0, 0});
+        at += l;
+      }
+      if (at != hb.in_len + hb.prefix_len) fail(ZPQ_E_ARG, "segment lengths do not add up to the block");
+    }
+    if (!segtab.empty()) {
+      e.segs.ensure(segtab.size() * sizeof(SegRange));
+      HIP_CHECK(hipMemcpyAsync(e.segs.p, segtab.data(), segtab.size() * sizeof(SegRange), hipMemcpyHostToDevice, e.stream));
+    }
     uint64_t a_off = 0, i_off = 0, o_off = 0;
     for (size_t k = 0; k < cnt; ++k) {
       const HostBlock& hb = blocks[order[k]];
       BlockJob& j = jobs[k];
       memset(&j, 0, sizeof(j));
+      if (hb.nseg > 1) { j.nseg = hb.nseg; j.segs = (SegRange*)e.segs.p + seg_first[k]; }
       j.plan = plan_on_device(e, hb.plan);
       j.arena = (uint8_t*)e.arena.p + a_off;
       j.in = (const uint8_t*)e.io_in.p + i_off;
@@ -731,6 +804,27 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     }
     HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
     HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
+    // SHA-1 of the blocks whose caller asked for it: one lane per block, on a side stream beside the coder
+    std::vector<Sha1Job> shj;
+    std::vector<size_t> sh_of;
+    for (size_t k = 0; k < cnt; ++k) {
+      const HostBlock& hb = blocks[order[k]];
+      if (!hb.sha1_out || decode) continue;
+      shj.push_back(Sha1Job{jobs[k].in + hb.prefix_len, hb.in_len, (uint32_t)shj.size()});
+      sh_of.push_back(order[k]);
+    }
+    Event sha_done;
+    if (!shj.empty()) {
+      e.sha_jobs.ensure(shj.size() * sizeof(Sha1Job));
+      e.sha_out.ensure(shj.size() * 20);
+      if (e.side.empty()) { hipStream_t s2; HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); e.side.push_back(s2); }
+      Event staged;
+      HIP_CHECK(hipMemcpyAsync(e.sha_jobs.p, shj.data(), shj.size() * sizeof(Sha1Job), hipMemcpyHostToDevice, e.stream));
+      HIP_CHECK(hipEventRecord(staged, e.stream));
+      HIP_CHECK(hipStreamWaitEvent(e.side[0], staged, 0));
+      HIP_CHECK(launch_sha1((const Sha1Job*)e.sha_jobs.p, (uint32_t)shj.size(), (uint8_t*)e.sha_out.p, e.side[0]));
+      HIP_CHECK(hipEventRecord(sha_done, e.side[0]));
+    }
     Timing before = e.last;
     e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
@@ -739,8 +833,26 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     e.last.code_ms += before.code_ms;
     e.last.blocks += before.blocks;
     std::vector<BlockResult> res(cnt);
+    std::vector<uint8_t> digests(shj.size() * 20);
+    if (!shj.empty()) {
+      HIP_CHECK(hipStreamWaitEvent(e.stream, sha_done, 0));
+      HIP_CHECK(hipMemcpyAsync(digests.data(), e.sha_out.p, digests.size(), hipMemcpyDeviceToHost, e.stream));
+    }
     HIP_CHECK(hipMemcpyAsync(res.data(), e.results.p, cnt * sizeof(BlockResult), hipMemcpyDeviceToHost, e.stream));
     HIP_CHECK(hipStreamSynchronize(e.stream));
+    for (size_t i = 0; i < sh_of.size(); ++i) memcpy(blocks[sh_of[i]].sha1_out, digests.data() + 20 * i, 20);
+    if (!segtab.empty()) {
+      HIP_CHECK(hipMemcpyAsync(segtab.data(), e.segs.p, segtab.size() * sizeof(SegRange), hipMemcpyDeviceToHost, e.stream));
+      HIP_CHECK(hipStreamSynchronize(e.stream));
+      for (size_t k = 0; k < cnt; ++k) {
+        const HostBlock& hb = blocks[order[k]];
+        if (hb.nseg <= 1 || !hb.seg_out_end) continue;
+        for (U32 sgi = 0; sgi < hb.nseg; ++sgi) hb.seg_out_end[sgi] = segtab[seg_first[k] + sgi].out_end;
+        if (decode && !res[k].status)
+          for (U32 sgi = 0; sgi < hb.nseg; ++sgi)
+            if (segtab[seg_first[k] + sgi].status) res[k].consumed = 0;      // capacity reached before the last end-of-stream
+      }
+    }
     for (size_t k = 0; k < cnt; ++k) {
       const HostBlock& hb = blocks[order[k]];
       results[order[k]] = res[k];
@@ -803,6 +915,107 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
   launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed);
   if (!timed) mark_in_flight(e, st);
+}
+
+bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<PcompSeg>& segs, std::string& note) {
+  if (segs.empty()) return true;
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  bind_device(e.device);
+  wait_in_flight(e);
+  PcompKernel* k = pcomp_kernel_for(code, codelen, ph, pm, note);
+  if (!k) return false;
+  const size_t n = segs.size();
+  const uint64_t mbytes = ((1ull << pm) + 255) & ~255ull, hbytes = ((4ull << ph) + 255) & ~255ull;
+  std::vector<uint64_t> cap(n);
+  for (size_t i = 0; i < n; ++i) cap[i] = (segs[i].hint ? segs[i].hint : 8ull * segs[i].in_len) + 65536;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    uint64_t in_bytes = 0, out_bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (cap[i] > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
+      in_bytes += ((uint64_t)segs[i].in_len + 63) & ~63ull;
+      out_bytes += (cap[i] + 63) & ~63ull;
+    }
+    const uint64_t work = (uint64_t)n * (mbytes + hbytes + 1024);
+    if (in_bytes + out_bytes + work > e.budget) { note = "post-processor state exceeds the device budget"; return false; }
+    e.io_in.ensure(in_bytes + 64);
+    e.io_out.ensure(out_bytes + 64);
+    e.arena.ensure(work);
+    e.jobs.ensure(n * sizeof(PcompJob));
+    e.results.ensure(n * 8);
+    std::vector<uint8_t> stage(in_bytes + 64);
+    std::vector<PcompJob> jobs(n);
+    std::vector<uint64_t> ooff(n);
+    uint64_t io = 0, oo = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (segs[i].in_len) memcpy(stage.data() + io, segs[i].in, segs[i].in_len);
+      PcompJob& j = jobs[i];
+      j.in = (const uint8_t*)e.io_in.p + io;
+      j.out = (uint8_t*)e.io_out.p + oo;
+      uint8_t* w = (uint8_t*)e.arena.p + (uint64_t)i * (mbytes + hbytes + 1024);
+      j.M = w;
+      j.H = (uint32_t*)(w + mbytes);
+      j.R = (uint32_t*)(w + mbytes + hbytes);
+      j.in_len = segs[i].in_len;
+      j.out_cap = (uint32_t)cap[i];
+      j.result = (uint32_t*)e.results.p + 2 * i;
+      ooff[i] = oo;
+      io += ((uint64_t)segs[i].in_len + 63) & ~63ull;
+      oo += (cap[i] + 63) & ~63ull;
+    }
+    HIP_CHECK(hipMemsetAsync(e.arena.p, 0, work, e.stream));
+    HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), n * sizeof(PcompJob), hipMemcpyHostToDevice, e.stream));
+    const PcompJob* d_jobs = (const PcompJob*)e.jobs.p;
+    unsigned nn = (unsigned)n;
+    void* args[2] = {(void*)&d_jobs, (void*)&nn};
+    HIP_CHECK(hipModuleLaunchKernel(k->fn, (unsigned)((n + 63) / 64), 1, 1, 64, 1, 1, 0, e.stream, args, nullptr));
+    std::vector<uint32_t> res(2 * n);
+    HIP_CHECK(hipMemcpyAsync(res.data(), e.results.p, n * 8, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    bool again = false;
+    for (size_t i = 0; i < n; ++i) {
+      if (res[2 * i + 1]) fail(ZPQ_E_VM, "ZPAQL execution error");
+      if (res[2 * i] > cap[i]) { cap[i] = res[2 * i]; again = true; }
+    }
+    if (again && attempt == 0) continue;
+    for (size_t i = 0; i < n; ++i) {
+      segs[i].out->resize(res[2 * i]);
+      if (res[2 * i])
+        HIP_CHECK(hipMemcpyAsync(segs[i].out->data(), (const uint8_t*)e.io_out.p + ooff[i], res[2 * i], hipMemcpyDeviceToHost, e.stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    return true;
+  }
+  return false;
+}
+
+// SHA-1 of n host buffers on the device (one lane per buffer); 20 bytes each into out.
+void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out) {
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  bind_device(e.device);
+  wait_in_flight(e);
+  uint64_t bytes = 0;
+  for (uint32_t i = 0; i < n; ++i) bytes += ((uint64_t)len[i] + 63) & ~63ull;
+  e.io_in.ensure(bytes + 64);
+  e.sha_jobs.ensure((size_t)n * sizeof(Sha1Job));
+  e.sha_out.ensure((size_t)n * 20);
+  std::vector<uint8_t> stage(bytes + 64);
+  std::vector<Sha1Job> jobs(n);
+  uint64_t off = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (len[i]) memcpy(stage.data() + off, in[i], len[i]);
+    jobs[i] = Sha1Job{(const uint8_t*)e.io_in.p + off, len[i], i};
+    off += ((uint64_t)len[i] + 63) & ~63ull;
+  }
+  HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), bytes, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(e.sha_jobs.p, jobs.data(), (size_t)n * sizeof(Sha1Job), hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(launch_sha1((const Sha1Job*)e.sha_jobs.p, n, (uint8_t*)e.sha_out.p, e.stream));
+  HIP_CHECK(hipMemcpyAsync(out, e.sha_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, e.stream));
+  HIP_CHECK(hipStreamSynchronize(e.stream));
 }
 
 int engine_selftest(int32_t out[8]) {

@@ -15,6 +15,13 @@ struct HostBlock {
   U32 in_len;
   U8* out;        // host destination (may be null to discard)
   U32 out_cap;    // encode: capacity; decode: max bytes to decode
+  // A block of several segments (model and coder state run on from one to the next): nseg > 1, seg_len[s] = the
+  // segment's share of `in` (encode: input bytes, the prefix belongs to the first; decode: coded bytes incl. its
+  // terminator), seg_out_end[s] <- where the segment's output ends in `out`.  Pipelined encoder / wavefront decoder only.
+  U32 nseg = 0;
+  const U32* seg_len = nullptr;
+  U32* seg_out_end = nullptr;
+  U8* sha1_out = nullptr;   // encode: if set, SHA-1 of `in` (without the prefix) is computed on the device into these 20 bytes
 };
 
 struct Timing {
@@ -51,6 +58,12 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
                         const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks, void* d_out,
                         const uint64_t* out_off, const uint32_t* out_cap, BlockResult* d_res, void* stream, bool timed);
 
+// Post-processing on the device: every segment's stream (decoded bytes after the PP header) through its block's PCOMP
+// program, one lane per segment.  Returns false (note says why) when the program cannot run there: the caller then
+// uses the host interpreter.  out[i] receives segment i's data; hint[i] = expected size or 0.
+struct PcompSeg { const U8* in; U32 in_len; U64 hint; std::vector<U8>* out; };
+bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<PcompSeg>& segs, std::string& note);
+void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out);
 int engine_selftest(int32_t out[8]);
 
 }  // namespace zpq

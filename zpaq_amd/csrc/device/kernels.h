@@ -11,5 +11,6 @@ hipError_t launch_code_serial(bool decode, const BlockJob* d_jobs, BlockResult* 
                               const DeviceTables* d_tb, hipStream_t st);
 hipError_t launch_code_wave(bool decode, const BlockJob* d_jobs, BlockResult* d_res, uint32_t nblocks,
                             const DeviceTables* d_tb, hipStream_t st);
+hipError_t launch_sha1(const Sha1Job* d_jobs, uint32_t n, uint8_t* d_digests, hipStream_t st);
 hipError_t launch_selftest(int32_t* d_out, hipStream_t st);
 }  // namespace zpq

@@ -145,6 +145,72 @@ __global__ void code_serial_kernel(const BlockJob* jobs, BlockResult* res, uint3
   out_res.steps = steps;
 }
 
+// ------------------------------------------------------------------- SHA-1
+// FIPS 180-1, one lane per block (the hash is a serial chain over the block's 64-byte groups; the batch supplies the
+// parallelism).  Replaces libzpaq::SHA1 (libzpaq.cpp:106-177) for the digest compressBlock stores in the segment
+// trailer when the block is already on the device unchanged (methods without pre-processing).
+__device__ __forceinline__ uint32_t sha_rol(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+__device__ __forceinline__ void sha1_rounds(uint32_t h[5], uint32_t w[16]) {
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+#pragma unroll
+  for (int i = 0; i < 80; ++i) {
+    uint32_t x;
+    if (i < 16) x = w[i];
+    else x = w[i & 15] = sha_rol(w[(i + 13) & 15] ^ w[(i + 8) & 15] ^ w[(i + 2) & 15] ^ w[i & 15], 1);
+    uint32_t f, k;
+    if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999u; }
+    else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1u; }
+    else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDCu; }
+    else { f = b ^ c ^ d; k = 0xCA62C1D6u; }
+    const uint32_t t = sha_rol(a, 5) + f + e + k + x;
+    e = d; d = c; c = sha_rol(b, 30); b = a; a = t;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e;
+}
+
+__global__ __launch_bounds__(64) void sha1_blocks_kernel(const Sha1Job* jobs, uint32_t n, uint8_t* digests) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const Sha1Job job = jobs[b];
+  typedef __attribute__((address_space(1))) const uint8_t g8;
+  typedef uint32_t __attribute__((aligned(1))) u32u;
+  g8* p = (g8*)job.p;
+  uint32_t h[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+  uint32_t w[16];
+  const uint32_t full = job.len >> 6;
+  for (uint32_t k = 0; k < full; ++k) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = __builtin_bswap32(*(__attribute__((address_space(1))) const u32u*)(p + 64u * k + 4u * i));
+    sha1_rounds(h, w);
+  }
+  // the tail: remaining bytes, 0x80, zeros, the bit length as 64 bits big-endian -- one or two more groups
+  const uint32_t rem = job.len & 63u;
+  g8* q = p + 64u * full;
+  const int groups = rem < 56 ? 1 : 2;
+  for (int gi = 0; gi < groups; ++gi) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t at = (uint32_t)gi * 64u + 4u * i + j;
+        const uint32_t byte = at < rem ? (uint32_t)q[at] : (at == rem ? 0x80u : 0u);
+        v = v << 8 | byte;
+      }
+      w[i] = v;
+    }
+    if (gi == groups - 1) { w[14] = job.len >> 29; w[15] = job.len << 3; }
+    sha1_rounds(h, w);
+  }
+  uint8_t* out = digests + 20u * job.slot;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i];
+  }
+}
+
 // ---------------------------------------------------------------- selftest
 // Checks the cross-lane idioms the wave kernel relies on (DPP reduction,
 // readlane, bpermute shuffles).  out[0]=wave_sum(lane) (2016), out[1]=wave_sum
@@ -172,6 +238,12 @@ hipError_t launch_init_arena(const BlockJob* d_jobs, uint32_t nblocks, const Dev
                              uint32_t chunks, hipStream_t st) {
   if (!nblocks) return hipSuccess;
   hipLaunchKernelGGL(init_arena_kernel, dim3(chunks, nblocks), dim3(256), 0, st, d_jobs, d_tb);
+  return last();
+}
+
+hipError_t launch_sha1(const Sha1Job* d_jobs, uint32_t n, uint8_t* d_digests, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(sha1_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_jobs, n, d_digests);
   return last();
 }
 

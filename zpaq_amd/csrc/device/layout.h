@@ -73,6 +73,8 @@ struct PlanHeader {       // followed in the same buffer by CompDesc[n], Segment
   uint64_t mix_mask;      // wave kernel: MIX lanes
 };
 
+struct SegRange { uint32_t in_begin, in_end, out_end, status; };
+
 // Per-block job descriptor (device array, one per block in the batch).
 struct BlockJob {
   const uint8_t* plan;    // -> PlanHeader
@@ -82,7 +84,10 @@ struct BlockJob {
   uint32_t in_len;
   uint32_t out_cap;       // encode: capacity; decode: max bytes to decode
   uint32_t res_slot;      // index of this block's BlockResult in the results array
-  uint32_t pad;
+  uint32_t nseg;          // 0 / 1: one segment.  > 1: a block of several segments (model and coder state run on,
+                          // Compressor::postProcess / Decoder::decompress, libzpaq.cpp:2889-2891, 2129): `segs` has nseg entries
+  SegRange* segs;         // encode: in_begin..in_end = the segment's input bytes (consecutive), out_end <- coded bytes so far
+                          // decode: in_begin..in_end = the segment's coded bytes incl. terminator, out_end <- decoded bytes so far
 };
 
 struct BlockResult {      // 16 bytes
@@ -104,6 +109,25 @@ struct DeviceTables {
   uint32_t sse_row[32];
   uint32_t stretch_cb[2016];   // compact stretch (host/common.hpp Tables)
   int16_t stretch_top[256];
+};
+
+// One segment to post-process on the device (device/pcomp_kernel.h): the decoded stream after the PP header goes
+// through the block's PCOMP program; H, M, R are the program's zeroed work arrays.
+struct PcompJob {
+  const uint8_t* in;
+  uint8_t* out;
+  uint8_t* M;
+  uint32_t* H;
+  uint32_t* R;          // 256 words
+  uint32_t in_len, out_cap;
+  uint32_t* result;     // [0] bytes produced (may exceed out_cap: then nothing past the capacity was stored), [1] status
+};
+
+// One block to hash on the device (sha1_blocks_kernel): digest 20 * slot in the output array.
+struct Sha1Job {
+  const uint8_t* p;
+  uint32_t len;
+  uint32_t slot;
 };
 
 // Argument block of the pipelined encoder's kernels (device/pipe_kernel.h), passed by value.

@@ -83,6 +83,8 @@ struct PipeLane {
   const g_u8* in;
   g_u8* out;
   unsigned len, out_cap, rslot;
+  unsigned nseg;
+  SegRange* segs;
   g_u8* gb;                 // group base in the pipe buffer
   int chunk;                // chunk this unit works on in this step
   unsigned slot;            // chunk % S
@@ -97,6 +99,8 @@ struct PipeLane {
     len = live ? job.in_len : 0u;
     out_cap = job.out_cap;
     rslot = job.res_slot;
+    nseg = job.nseg;
+    segs = job.segs;
     gl = blk % G;
     gb = (g_u8*)a.pipe + (unsigned long long)(blk / G) * Chain::PIPE_GROUP_BYTES;
     chunk = a.step - level;
@@ -416,30 +420,46 @@ __device__ __forceinline__ void pipe_cm(PipeLane<Chain>& L, const PipeStretch& s
   }
 }
 
-// MATCH (libzpaq.cpp:1883-1892, 1985-2008): length / offset / position live in registers, the predicted byte is
-// fetched once per byte.  State words: len, offset, pos, predicted byte, 2048/len, last predicted bit.
+// MATCH (libzpaq.cpp:1883-1892, 1985-2008): length / offset / position live in registers.  What update0 reads from
+// memory at the end of a byte -- the index entry of the byte's context, the history behind the candidate it names
+// (compared backwards with the bytes just coded) and the byte the match predicts next -- has addresses that are
+// known when the byte STARTS, so all of it is fetched then and is in registers by the time the 8 bits are done:
+//   * the index entry is fetched a byte ahead (forwarded when the next byte hashes to the entry just written);
+//   * the 8 history bytes before the candidate come as one unaligned 64-bit load and are compared with the last 8
+//     input bytes (which ARE the history on our side) in one xor / count-trailing-zeros; longer matches, candidates
+//     that overlap the byte being written, and the buffer's wrap-around take the byte loop of the reference;
+//   * both possible "predicted next byte" positions (continuing match, new match) are fetched as well.
+// State words: len, offset, pos, predicted byte, 2048/len, last predicted bit, last 8 input bytes (2 words).
 template <class Chain, int I, class DT2K>
 __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch& stretch, const DT2K& dt2k) {
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I], sw = Chain::P_STATE[I];
   constexpr unsigned off0 = (unsigned)c.t0, off1 = (unsigned)c.t1, mask = c.mask1;
+  typedef unsigned long long __attribute__((aligned(1))) u64u;
+  typedef __attribute__((address_space(1))) const u64u g_u64u;
   if (!L.nb) return;
   unsigned ra = 0, rb = 0, rlimit = 0, mpred = 0, mdd = 0, rc = 0;
+  unsigned long long hist = 0;
   if (L.chunk > 0) {
     ra = L.state(sw + 0); rb = L.state(sw + 1); rlimit = L.state(sw + 2);
     mpred = L.state(sw + 3); mdd = L.state(sw + 4); rc = L.state(sw + 5);
+    hist = (unsigned long long)(unsigned)L.state(sw + 6) | (unsigned long long)(unsigned)L.state(sw + 7) << 32;
   }
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-  unsigned tch = 0;
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  unsigned cmv = L.A32(off0 + 4u * (h & c.mask0));
   for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned hn = L.ctx(ci, kn), byten = L.byte_at(kn);
-    // the index entry of this byte's context is only read at the end of the byte and nobody else writes it:
-    // fetch it now, and pull the next byte's entry towards L2
-    const unsigned eo = off0 + 4u * (h & c.mask0);
-    const unsigned cmv = L.A32(eo);
-    ZPQ_KEEP2(tch, tch);
-    tch = L.A32(off0 + 4u * (hn & c.mask0));
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    const unsigned eo = off0 + 4u * (h & c.mask0), eon = off0 + 4u * (h1 & c.mask0);
+    const unsigned cmvn_mem = L.A32(eon);                        // next byte's index entry (patched below if it is this one)
+    // history behind the candidate (positions cmv-8 .. cmv-1), the byte at the candidate, the byte a continuing match predicts
+    const unsigned cpos = (cmv - 8u) & mask;
+    const bool wraps = cpos + 8u > mask + 1u || mask < 15u;
+    const unsigned long long cand = *(g_u64u*)(L.arena + off1 + (wraps ? 0u : cpos));
+    const unsigned at_cand = L.A8(off1 + (cmv & mask));
+    const unsigned at_cont = L.A8(off1 + ((rlimit + 1u - rb) & mask));
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
@@ -450,20 +470,41 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
       ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
     }
     L.p(I, k) = out.get();
-    L.A8(off1 + (rlimit & mask)) = (unsigned char)byte;
+    const unsigned wpos = rlimit & mask;                         // where this byte goes
+    L.A8(off1 + wpos) = (unsigned char)byte;
+    hist = hist << 8 | byte;
     rlimit = (rlimit + 1) & mask;
+    bool fresh = false;
     if (ra == 0) {
       rb = rlimit - cmv;
-      if (rb & mask)
-        while (ra < 255 && L.A8(off1 + ((rlimit - ra - 1) & mask)) == L.A8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+      if (rb & mask) {
+        // fast path legal when the 8 candidate bytes were not touched by this byte's store and do not wrap
+        const bool overlap = ((cmv - 1u - wpos) & mask) < 8u;
+        unsigned m = 0;
+        if (!wraps && !overlap) {
+          const unsigned long long diff = __builtin_bswap64(cand) ^ hist;
+          m = diff ? (unsigned)(__builtin_ctzll(diff) >> 3) : 8u;
+          if (k + L.k0 + 1u < 8u) m = min(m, 8u);                // (hist of a young block holds zeros = what the buffer holds)
+        }
+        ra = m;
+        if (wraps || overlap || m == 8u)
+          while (ra < 255 && L.A8(off1 + ((rlimit - ra - 1) & mask)) == L.A8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+      }
+      fresh = true;
     } else ra += ra < 255;
     L.A32(eo) = rlimit;
-    if (ra != 0) { mpred = L.A8(off1 + ((rlimit - rb) & mask)); mdd = dt2k[ra]; }
-    h = hn; byte = byten;
+    if (ra != 0) {
+      const unsigned ppos = (rlimit - rb) & mask;                // = cmv for a fresh match, the continuing position otherwise
+      const unsigned early = fresh ? at_cand : at_cont;
+      mpred = ppos == wpos ? byte : early;
+      mdd = dt2k[ra];
+    }
+    cmv = eon == eo ? rlimit : cmvn_mem;
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
-  ZPQ_KEEP2(tch, tch);
   L.state(sw + 0) = ra; L.state(sw + 1) = rb; L.state(sw + 2) = rlimit;
   L.state(sw + 3) = mpred; L.state(sw + 4) = mdd; L.state(sw + 5) = rc;
+  L.state(sw + 6) = (unsigned)hist; L.state(sw + 7) = (unsigned)(hist >> 32);
 }
 
 // AVG (libzpaq.cpp:1894-1896)
@@ -638,7 +679,13 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
   const bool active = L.live && L.chunk >= 0 && (unsigned)L.chunk < nchunks;
   if (!active) return;
   unsigned low = 1, high = 0xFFFFFFFFu, n = 0;
-  if (L.chunk > 0) { low = L.state(sw + 0); high = L.state(sw + 1); n = L.state(sw + 2); }
+  // a block of several segments: the end-of-segment code (and nothing else) separates them, the model never notices
+  unsigned seg = 0, seg_end = 0xFFFFFFFFu;
+  const bool multi = L.nseg > 1;
+  if (L.chunk > 0) { low = L.state(sw + 0); high = L.state(sw + 1); n = L.state(sw + 2); seg = L.state(sw + 3); }
+  typedef __attribute__((address_space(1))) SegRange g_seg;
+  g_seg* const segs = (g_seg*)L.segs;
+  if (multi) seg_end = segs[seg].in_end;
   auto encode = [&](int y, unsigned pr) __attribute__((always_inline)) {
     const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
     if (y) high = mid; else low = mid + 1;
@@ -657,6 +704,14 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
       const unsigned kn = L.next(k);
       const unsigned byten = L.byte_at(kn);
       const uint4 vn = L.p(Chain::N - 1, kn);
+      if (multi) {
+        while (seg + 1 < L.nseg && L.k0 + k == seg_end) {      // (empty segments: several boundaries at one byte)
+          encode(1, 0);
+          segs[seg].out_end = n;
+          ++seg;
+          seg_end = segs[seg].in_end;
+        }
+      }
       encode(0, 0);
 #pragma unroll
       for (int B = 0; B < 8; ++B) {
@@ -668,13 +723,17 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
   }
   if ((unsigned)L.chunk == nchunks - 1u) {
     int status = (int)(unsigned)L.state(Chain::HCOMP_STATE + 4);
+    if (multi && !status) {
+      while (seg + 1 < L.nseg) { encode(1, 0); segs[seg].out_end = n; ++seg; }     // trailing empty segments
+    }
     if (!status) encode(1, 0);
+    if (multi) segs[seg].out_end = n;
     if (!status && n > L.out_cap) status = 3;
     BlockResult r;
     r.out_len = n; r.consumed = L.len; r.status = status; r.steps = 8u * L.len;
     a.res[L.rslot] = r;
   } else {
-    L.state(sw + 0) = low; L.state(sw + 1) = high; L.state(sw + 2) = n;
+    L.state(sw + 0) = low; L.state(sw + 1) = high; L.state(sw + 2) = n; L.state(sw + 3) = seg;
   }
 }
 

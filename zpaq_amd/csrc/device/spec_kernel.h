@@ -858,10 +858,13 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
   } else {
     unsigned rp = 0, n = 0, curr = 0;
     bool eos = false;
-    for (int i = 0; i < 4; ++i) {
-      if (rp >= job.in_len) { status = 6; break; }
-      curr = curr << 8 | sp_uni(in_ptr[rp++]);
-    }
+    // A block of several segments (job.nseg > 1): each segment has its own coded range and ends with its own
+    // end-of-stream flag; the decoder re-reads 4 bytes at the start of each (Decoder::decompress, libzpaq.cpp:2129),
+    // the model and the range state run on.
+    typedef __attribute__((address_space(1))) SegRange g_seg;
+    g_seg* const segs = (g_seg*)sp_uni64((unsigned long long)job.segs);
+    const unsigned nseg = max(sp_uni(job.nseg), 1u);
+    unsigned in_end = job.in_len;
     // Decoder::decode (libzpaq.cpp:2159-2181); sets `status` on a corrupt or truncated stream
     auto decode = [&](unsigned pr) __attribute__((always_inline)) -> int {
       if (curr < low || curr > high) { status = 2; return 0; }
@@ -872,28 +875,39 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         high = high << 8 | 255u;
         low = low << 8;
         low += (low == 0);
-        if (rp >= job.in_len) { status = 6; break; }
+        if (rp >= in_end) { status = 6; break; }
         curr = curr << 8 | sp_uni(in_ptr[rp++]);
       }
       return y;
     };
-    while (!status && !eos && n < job.out_cap) {
-      int ch = 1;
-      const int flag = decode(0);                       // end-of-stream flag, coded with p = 0
-      if (status) break;
-      if (flag) { eos = true; if (curr != 0) status = 2; break; }
-      for_bits([&](auto bitc, int) __attribute__((always_inline)) {
-        if (status) return;
-        const unsigned pr = predict(bitc) * 2 + 1;
-        const int y = decode(pr);
-        if (status) return;
-        ch += ch + y;
-        status = after_bit(bitc, y);
-        ++steps;
-      });
-      if (status || eos) break;
-      if (lane == 0) out_ptr[n] = (unsigned char)(ch - 256);
-      ++n;
+    for (unsigned seg = 0; seg < nseg && !status; ++seg) {
+      if (nseg > 1) { rp = sp_uni(segs[seg].in_begin); in_end = sp_uni(segs[seg].in_end); }
+      eos = false;
+      curr = 0;
+      for (int i = 0; i < 4; ++i) {
+        if (rp >= in_end) { status = 6; break; }
+        curr = curr << 8 | sp_uni(in_ptr[rp++]);
+      }
+      while (!status && !eos && n < job.out_cap) {
+        int ch = 1;
+        const int flag = decode(0);                       // end-of-stream flag, coded with p = 0
+        if (status) break;
+        if (flag) { eos = true; if (curr != 0) status = 2; break; }
+        for_bits([&](auto bitc, int) __attribute__((always_inline)) {
+          if (status) return;
+          const unsigned pr = predict(bitc) * 2 + 1;
+          const int y = decode(pr);
+          if (status) return;
+          ch += ch + y;
+          status = after_bit(bitc, y);
+          ++steps;
+        });
+        if (status || eos) break;
+        if (lane == 0) out_ptr[n] = (unsigned char)(ch - 256);
+        ++n;
+      }
+      if (nseg > 1 && lane == 0) { segs[seg].out_end = n; segs[seg].status = eos ? 0u : 1u; }
+      if (!eos) break;                                    // capacity reached (or an error) inside this segment
     }
     if (lane == 0) { res[rslot].out_len = n; res[rslot].consumed = eos ? rp : 0; }
   }

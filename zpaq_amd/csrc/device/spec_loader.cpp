@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <vector>
 
@@ -237,6 +238,69 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
   plan->cur().pipe = k;
   plan->cur().pipe_state = 1;
   plan->cur().pipe_note = origin;
+  return k;
+}
+
+bool pcomp_source_and_key(const U8* code, size_t len, int ph, int pm, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_pcomp_source(code, len, ph, pm, source, why_not)) return false;
+  std::string h1, h2, h3;
+  const std::string inc = spec_include_dir();
+  if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) || !read_file(inc + "/pcomp_kernel.h", h3)) {
+    why_not = "kernel template headers not found under " + inc;
+    return false;
+  }
+  Sha1 s;
+  s.update(source.data(), source.size());
+  s.update(h1.data(), h1.size());
+  s.update(h2.data(), h2.size());
+  s.update(h3.data(), h3.size());
+  key = hex20(s.result());
+  return true;
+}
+
+PcompKernel* pcomp_kernel_for(const U8* code, size_t len, int ph, int pm, std::string& note) {
+  static std::mutex mu;
+  static std::map<std::pair<int, std::string>, PcompKernel*> loaded;     // (device, cache key)
+  std::string source, key, why;
+  if (!pcomp_source_and_key(code, len, ph, pm, source, key, why)) { note = why; return nullptr; }
+  const int dev = plan_device_index();
+  std::lock_guard<std::mutex> g(mu);
+  const auto it = loaded.find({dev, key});
+  if (it != loaded.end()) { note = it->second ? it->second->origin : "unavailable"; return it->second; }
+  std::vector<char> bin;
+  std::string origin, blob;
+  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
+  if (read_file(path, blob) && !blob.empty()) {
+    bin.assign(blob.begin(), blob.end());
+    origin = "cache:" + key;
+  } else {
+    std::string log;
+    if (!compile_hiprtc(source, bin, log)) {
+      note = "hipRTC compile failed: " + log.substr(0, 2000);
+      loaded[{dev, key}] = nullptr;
+      return nullptr;
+    }
+    origin = "hiprtc";
+    ::mkdir(spec_cache_dir().c_str(), 0755);
+    std::ofstream f(path + ".tmp", std::ios::binary);
+    if (f) {
+      f.write(bin.data(), (std::streamsize)bin.size());
+      f.close();
+      ::rename((path + ".tmp").c_str(), path.c_str());
+    }
+  }
+  PcompKernel* k = new PcompKernel;
+  if (hipModuleLoadData(&k->module, bin.data()) != hipSuccess ||
+      hipModuleGetFunction(&k->fn, k->module, "zpq_pcomp_run") != hipSuccess) {
+    note = "hipModuleLoadData failed for " + origin;
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    loaded[{dev, key}] = nullptr;
+    return nullptr;
+  }
+  k->origin = origin;
+  note = origin;
+  loaded[{dev, key}] = k;
   return k;
 }
 

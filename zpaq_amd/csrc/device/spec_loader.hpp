@@ -38,6 +38,16 @@ struct PipeKernel {
 PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit = true, bool* did_jit = nullptr);
 bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
 
+// A block's PCOMP post-processor translated for the device (device/pcomp_kernel.h), per (program, ph, pm) and device;
+// loaded kernels live until the process ends.  nullptr + note when the program cannot be translated or compiled.
+struct PcompKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  std::string origin;
+};
+PcompKernel* pcomp_kernel_for(const U8* code, size_t len, int ph, int pm, std::string& note);
+bool pcomp_source_and_key(const U8* code, size_t len, int ph, int pm, std::string& source, std::string& key, std::string& why_not);
+
 // Source text + cache key (with the template-header digest) for prebuilding.
 bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.

@@ -76,7 +76,11 @@ U32 coded_cap(U64 n, bool worst) {
 }
 
 // Runs the encoder for a list of (plan, pp, data) jobs, retrying overflowed ones.
-struct EncJob { zpq_plan* plan; const U8* pp; U32 npp; const U8* data; U32 n; std::vector<U8>* coded; };
+struct EncJob {
+  zpq_plan* plan; const U8* pp; U32 npp; const U8* data; U32 n; std::vector<U8>* coded; U8* sha1_out = nullptr;
+  // several segments in one block: lengths of the segments' shares of `data`, and where each one's code ends
+  U32 nseg = 0; const U32* seg_len = nullptr; U32* seg_out_end = nullptr;
+};
 
 void encode_jobs(std::vector<EncJob>& jobs, bool announced = false) {
   std::vector<size_t> todo(jobs.size());
@@ -87,7 +91,10 @@ void encode_jobs(std::vector<EncJob>& jobs, bool announced = false) {
     for (size_t i : todo) {
       EncJob& j = jobs[i];
       j.coded->resize(coded_cap((U64)j.n + j.npp, worst));
-      hb.push_back(HostBlock{j.plan, j.pp, j.npp, j.data, j.n, j.coded->data(), (U32)j.coded->size()});
+      HostBlock h{j.plan, j.pp, j.npp, j.data, j.n, j.coded->data(), (U32)j.coded->size()};
+      h.sha1_out = j.sha1_out;
+      h.nseg = j.nseg; h.seg_len = j.seg_len; h.seg_out_end = j.seg_out_end;
+      hb.push_back(h);
     }
     std::vector<BlockResult> res;
     engine_code_host(false, hb, res, announced);
@@ -141,6 +148,7 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     std::vector<U8> pp, coded, header;
     std::vector<U8> pre;        // LZ77 / BWT stream when the method pre-processes (else the input itself is coded)
     bool use_pre = false;
+    bool sha1_on_device = false;
     U8 sha1[20];
   };
   std::vector<Work> work(nb);
@@ -159,11 +167,14 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     Work& w = work[b];
     const U32 n = in[b].n;
     if ((U64)n > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
-    if (dosha1) { Sha1 s; s.update(in[b].data, n); memcpy(w.sha1, s.result(), 20); }
     const std::string xm = expand_method(method, in[b].data, n);
     int args[9];
     const std::string cfg = make_config(xm, args);
     const Assembled as = assemble(cfg.c_str(), args);
+    // The segment trailer carries the SHA-1 of the ORIGINAL block.  A modelled block that is coded as it is goes to the
+    // device unchanged, so it is hashed there (sha1_blocks_kernel, beside the coder); everything else here.
+    w.sha1_on_device = dosha1 && args[1] == 0 && as.hcomp[6] != 0 && !getenv("ZPAQ_AMD_HOST_SHA1");
+    if (dosha1 && !w.sha1_on_device) { Sha1 s; s.update(in[b].data, n); memcpy(w.sha1, s.result(), 20); }
     if ((U64)n + 4096 > (0x100000ull << args[0])) fail(ZPQ_E_ARG, "block larger than the method's block size");
     // LZ77 / BWT / E8E9 (libzpaq.cpp:7709-7716); E8E9 rewrites the caller's buffer in place, as the reference does
     w.use_pre = preprocess_block(in[b].data, n, args, w.pre);
@@ -185,7 +196,8 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     if (!work[b].header.empty())
       jobs.push_back(EncJob{plan_for(plans, work[b].header), work[b].pp.data(), (U32)work[b].pp.size(),
                             work[b].use_pre ? work[b].pre.data() : in[b].data,
-                            work[b].use_pre ? (U32)work[b].pre.size() : in[b].n, &work[b].coded});
+                            work[b].use_pre ? (U32)work[b].pre.size() : in[b].n, &work[b].coded,
+                            work[b].sha1_on_device ? work[b].sha1 : nullptr, 0, nullptr, nullptr});
   const double t1 = now_ms();
   if (jobs.empty()) announce.off();
   else { announce.on = false; encode_jobs(jobs, true); }    // the queue withdraws the announcement when our blocks are in it
@@ -212,15 +224,43 @@ ApiTiming last_api_timing() {
 std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size_t npp, const U8* data, size_t n) {
   PlanCache plans;
   std::vector<U8> coded;
-  std::vector<EncJob> jobs(1, EncJob{plan_for(plans, header), pp, (U32)npp, data, (U32)n, &coded});
+  std::vector<EncJob> jobs(1, EncJob{plan_for(plans, header), pp, (U32)npp, data, (U32)n, &coded, nullptr, 0, nullptr, nullptr});
   if ((U64)n + npp > 0x7FFFF000ull) fail(ZPQ_E_ARG, "segment too large");
   encode_jobs(jobs);
   return coded;
 }
 
+// A modelled block of several segments: one device job, the end-of-segment code between them.
+std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& segments) {
+  PlanCache plans;
+  std::vector<U8> all, coded;
+  std::vector<U32> lens, ends(segments.size(), 0);
+  for (const auto& sg : segments) {
+    if ((U64)all.size() + sg.size() > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
+    all.insert(all.end(), sg.begin(), sg.end());
+    lens.push_back((U32)sg.size());
+  }
+  std::vector<EncJob> jobs(1, EncJob{plan_for(plans, header), nullptr, 0, all.data(), (U32)all.size(), &coded, nullptr,
+                                     (U32)segments.size(), lens.data(), ends.data()});
+  if (segments.size() <= 1) jobs[0].nseg = 0;
+  encode_jobs(jobs);
+  std::vector<std::vector<U8>> out;
+  if (segments.size() <= 1) { out.push_back(coded); return out; }
+  U32 at = 0;
+  for (size_t i = 0; i < segments.size(); ++i) {
+    if (ends[i] < at || ends[i] > coded.size()) fail(ZPQ_E_DEVICE, "device coder returned inconsistent segment ends");
+    out.emplace_back(coded.begin() + at, coded.begin() + ends[i]);
+    at = ends[i];
+  }
+  return out;
+}
+
 namespace {
 
-struct DecJob { zpq_plan* plan; const U8* payload; U32 len; U64 hint; std::vector<U8>* decoded; };
+struct DecJob {
+  zpq_plan* plan; const U8* payload; U32 len; U64 hint; std::vector<U8>* decoded;
+  U32 nseg = 0; const U32* seg_len = nullptr; U32* seg_out_end = nullptr;     // several segments: coded lengths / decoded ends
+};
 
 void decode_jobs(std::vector<DecJob>& jobs) {
   std::vector<size_t> todo(jobs.size());
@@ -235,7 +275,9 @@ void decode_jobs(std::vector<DecJob>& jobs) {
     for (size_t i : todo) {
       if (cap[i] > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
       jobs[i].decoded->resize(cap[i]);
-      hb.push_back(HostBlock{jobs[i].plan, nullptr, 0, jobs[i].payload, jobs[i].len, jobs[i].decoded->data(), (U32)cap[i]});
+      HostBlock h{jobs[i].plan, nullptr, 0, jobs[i].payload, jobs[i].len, jobs[i].decoded->data(), (U32)cap[i]};
+      h.nseg = jobs[i].nseg; h.seg_len = jobs[i].seg_len; h.seg_out_end = jobs[i].seg_out_end;
+      hb.push_back(h);
     }
     std::vector<BlockResult> res;
     engine_code_host(true, hb, res);
@@ -259,9 +301,35 @@ std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload,
   PlanCache plans;
   std::vector<U8> decoded;
   if (len > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
-  std::vector<DecJob> jobs(1, DecJob{plan_for(plans, header), payload, (U32)len, hint, &decoded});
+  std::vector<DecJob> jobs(1, DecJob{plan_for(plans, header), payload, (U32)len, hint, &decoded, 0, nullptr, nullptr});
   decode_jobs(jobs);
   return decoded;
+}
+
+// The segments of ONE modelled block decoded together (model and coder state run on from segment to segment):
+// payloads[s] = coded bytes of segment s incl. its terminator; returns the decoded bytes per segment.
+std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& payloads, U64 hint) {
+  PlanCache plans;
+  std::vector<U8> all, decoded;
+  std::vector<U32> lens, ends(payloads.size(), 0);
+  for (const auto& p : payloads) {
+    if ((U64)all.size() + p.size() > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "block too large");
+    all.insert(all.end(), p.begin(), p.end());
+    lens.push_back((U32)p.size());
+  }
+  std::vector<DecJob> jobs(1, DecJob{plan_for(plans, header), all.data(), (U32)all.size(), hint, &decoded,
+                                     (U32)payloads.size(), lens.data(), ends.data()});
+  if (payloads.size() <= 1) jobs[0].nseg = 0;
+  decode_jobs(jobs);
+  std::vector<std::vector<U8>> out;
+  if (payloads.size() <= 1) { out.push_back(decoded); return out; }
+  U32 at = 0;
+  for (size_t i = 0; i < payloads.size(); ++i) {
+    if (ends[i] < at || ends[i] > decoded.size()) fail(ZPQ_E_DEVICE, "device decoder returned inconsistent segment ends");
+    out.emplace_back(decoded.begin() + at, decoded.begin() + ends[i]);
+    at = ends[i];
+  }
+  return out;
 }
 
 void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, size_t)>& sink) {
@@ -283,11 +351,11 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
     const bool modeled = blk.header[6] != 0;
     zpq_plan* plan = modeled ? plan_for(plans, blk.header) : nullptr;
     int nseg = 0;
+    (void)nseg;
     for (;;) {
       std::unique_ptr<Seg> s(new Seg);
       if (!find_segment(a, n, pos, s->fs)) break;
-      if (modeled && ++nseg > 1)
-        fail(ZPQ_E_UNSUPPORTED, "multi-segment modelled blocks are outside this build's scope");
+      ++nseg;
       s->plan = plan;
       s->header = blk.header;
       s->block = this_block;
@@ -303,29 +371,115 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
       segs.push_back(std::move(s));
     }
   }
+  // one device job per modelled block; a block of several segments is ONE job (its model and coder state run on
+  // from segment to segment), fed with the segments' payloads back to back
+  struct Multi { std::vector<U8> all, decoded; std::vector<U32> lens, ends; std::vector<size_t> members; };
+  std::vector<std::unique_ptr<Multi>> multis;
   std::vector<DecJob> jobs;
-  for (auto& s : segs)
-    if (s->plan)
-      jobs.push_back(DecJob{s->plan, a + s->fs.payload_begin, (U32)(s->payload_end - s->fs.payload_begin),
-                            s->hint ? s->hint + 1 : 0, &s->decoded});
+  {
+    std::vector<size_t> count(nblocks, 0);
+    for (auto& s : segs) if (s->plan) ++count[s->block];
+    std::map<size_t, Multi*> open;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      Seg& s = *segs[i];
+      if (!s.plan) continue;
+      const U8* payload = a + s.fs.payload_begin;
+      const size_t plen = s.payload_end - s.fs.payload_begin;
+      if (count[s.block] == 1) {
+        jobs.push_back(DecJob{s.plan, payload, (U32)plen, s.hint ? s.hint + 1 : 0, &s.decoded, 0, nullptr, nullptr});
+        continue;
+      }
+      Multi*& m = open[s.block];
+      if (!m) { multis.emplace_back(new Multi); m = multis.back().get(); }
+      if ((U64)m->all.size() + plen > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "block too large");
+      m->all.insert(m->all.end(), payload, payload + plen);
+      m->lens.push_back((U32)plen);
+      m->members.push_back(i);
+    }
+    for (auto& m : multis) {
+      m->ends.assign(m->lens.size(), 0);
+      U64 hint = 0;
+      for (size_t i : m->members) hint = (hint || segs[i]->hint) ? hint + segs[i]->hint + 1 : 0;
+      jobs.push_back(DecJob{segs[m->members[0]]->plan, m->all.data(), (U32)m->all.size(), hint, &m->decoded,
+                            (U32)m->lens.size(), m->lens.data(), m->ends.data()});
+    }
+  }
   decode_jobs(jobs);
-  std::unique_ptr<PostProcessor> pp;
-  size_t pp_block = (size_t)-1;
+  for (auto& m : multis) {
+    U32 at = 0;
+    for (size_t k = 0; k < m->members.size(); ++k) {
+      if (m->ends[k] < at || m->ends[k] > m->decoded.size()) fail(ZPQ_E_DEVICE, "device decoder returned inconsistent segment ends");
+      segs[m->members[k]]->decoded.assign(m->decoded.begin() + at, m->decoded.begin() + m->ends[k]);
+      at = m->ends[k];
+    }
+  }
+  // stored segments: Decoder::decompress n == 0 branch (2146-2154)
   for (auto& s : segs) {
-    if (!s->plan) {   // stored: Decoder::decompress n==0 branch (2146-2154)
-      size_t p = s->fs.payload_begin;
-      for (;;) {
-        const U32 l = (U32)a[p] << 24 | (U32)a[p + 1] << 16 | (U32)a[p + 2] << 8 | a[p + 3];
-        p += 4;
-        if (!l) break;
-        s->decoded.insert(s->decoded.end(), a + p, a + p + l);
-        p += l;
+    if (s->plan) continue;
+    size_t p = s->fs.payload_begin;
+    for (;;) {
+      const U32 l = (U32)a[p] << 24 | (U32)a[p + 1] << 16 | (U32)a[p + 2] << 8 | a[p + 3];
+      p += 4;
+      if (!l) break;
+      s->decoded.insert(s->decoded.end(), a + p, a + p + l);
+      p += l;
+    }
+  }
+  // Post-processing.  Segments whose block carries a PCOMP program (LZ77 / BWT / E8E9 methods) go through it ON THE
+  // DEVICE when there is enough of them to fill lanes: one lane per segment, the program translated like HCOMP
+  // (device/pcomp_kernel.h).  Blocks of several segments share one machine across segments and small jobs are not
+  // worth a launch: those run through the host interpreter (host/postproc.cpp), like stored blocks on a box without
+  // a GPU.  ZPAQ_AMD_PCOMP=device|host forces one.
+  std::vector<size_t> per_block(nblocks, 0);
+  for (auto& s : segs) ++per_block[s->block];
+  std::vector<std::vector<U8>> done(segs.size());
+  std::vector<char> on_device(segs.size(), 0);
+  {
+    const char* mode = getenv("ZPAQ_AMD_PCOMP");
+    const bool force_dev = mode && !strcmp(mode, "device"), force_host = mode && !strcmp(mode, "host");
+    std::map<std::vector<U8>, std::vector<size_t>> by_prog;     // key: ph pm code
+    U64 prog_bytes = 0;
+    for (size_t i = 0; i < segs.size() && !force_host; ++i) {
+      const Seg& s = *segs[i];
+      const std::vector<U8>& d = s.decoded;
+      if (per_block[s.block] != 1 || d.size() < 4 || d[0] != 1) continue;
+      const size_t len = d[1] + 256u * d[2];
+      if (len < 1 || d.size() < 3 + len) continue;
+      std::vector<U8> key;
+      key.push_back(s.header[4]); key.push_back(s.header[5]);
+      key.insert(key.end(), d.begin() + 3, d.begin() + 3 + (long)len);
+      by_prog[key].push_back(i);
+      prog_bytes += d.size();
+    }
+    size_t nprog = 0;
+    for (auto& kv : by_prog) nprog += kv.second.size();
+    if (nprog && (force_dev || nprog >= 4 || prog_bytes >= (256u << 10)) && engine_device_count() > 0) {
+      for (auto& kv : by_prog) {
+        const std::vector<U8>& key = kv.first;
+        std::vector<PcompSeg> ps;
+        for (size_t i : kv.second) {
+          const Seg& s = *segs[i];
+          const size_t skip = 3 + (key.size() - 2);
+          ps.push_back(PcompSeg{s.decoded.data() + skip, (U32)(s.decoded.size() - skip), s.hint, &done[i]});
+        }
+        std::string note;
+        if (engine_pcomp(key.data() + 2, key.size() - 2, key[0], key[1], ps, note))
+          for (size_t i : kv.second) on_device[i] = 1;
+        else if (force_dev) fail(ZPQ_E_UNSUPPORTED, "PCOMP on the device unavailable: " + note);
       }
     }
-    // one PostProcessor per block: only its first segment carries the PP header (libzpaq.cpp:2320-2330)
-    if (s->block != pp_block) { pp.reset(new PostProcessor(s->header[4], s->header[5])); pp_block = s->block; }
+  }
+  std::unique_ptr<PostProcessor> pp;
+  size_t pp_block = (size_t)-1;
+  for (size_t si = 0; si < segs.size(); ++si) {
+    auto& s = segs[si];
     std::vector<U8> data;
-    pp->segment(s->decoded.data(), s->decoded.size(), data);
+    if (on_device[si]) data.swap(done[si]);
+    else {
+      // one PostProcessor per block: only its first segment carries the PP header (libzpaq.cpp:2320-2330)
+      if (s->block != pp_block) { pp.reset(new PostProcessor(s->header[4], s->header[5])); pp_block = s->block; }
+      pp->segment(s->decoded.data(), s->decoded.size(), data);
+    }
     std::vector<U8>().swap(s->decoded);
     if (s->fs.has_sha1) {
       Sha1 h; h.update(data.data(), data.size());

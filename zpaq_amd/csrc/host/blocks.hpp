@@ -36,6 +36,12 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
 // returns the coded bytes (Encoder::compress loop, 2419-2447).
 std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size_t npp, const U8* data, size_t n);
 
+// The same for a block of several segments (libzpaq.cpp:2889-2891: the encoder and the model are initialised once per
+// block): segments[0] starts with the PP header; returns each segment's coded bytes (its end-of-segment code included).
+std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& segments);
+// ... and back: payloads[s] = coded bytes of segment s incl. terminator -> decoded bytes per segment (PP header in the first)
+std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& payloads, U64 hint);
+
 // Decodes one modelled payload (coded bytes + zero terminator) to EOS on the
 // device; returns the decoded bytes, PP header included.  `hint` = expected
 // decoded size or 0.

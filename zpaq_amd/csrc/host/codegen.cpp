@@ -52,7 +52,7 @@ std::string dst_stmt(int g, const std::string& e) {
 
 // Translates the HCOMP program; returns false if it cannot be compiled
 // statically (then the generic interpreter kernel is used instead).
-bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
+bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with_out = false) {
   std::map<int, Insn> insns;
   std::vector<int> work(1, 0);
   std::set<int> bad;    // pcs where execution is an error
@@ -78,13 +78,33 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
     if (op == 255) { work.push_back(prog[pc + 1] + 256 * prog[pc + 2]); continue; }
     work.push_back(pc + l);
   }
+  // R[n] is only ever addressed by an immediate: the slots a program uses become locals, loaded on entry and written
+  // back at HALT, so no R access sits in the machine's dependent chain as a memory round trip
+  std::set<int> r_used, r_written;
+  for (auto& kv : insns) {
+    const Insn& in = kv.second;
+    if (in.op < 64 && (in.op & 7) == 7 && in.len >= 2) {
+      const int g = in.op >> 3;
+      if (g < 4) r_used.insert(prog[in.pc + 1]);
+      else if (g == 6) { r_used.insert(prog[in.pc + 1]); r_written.insert(prog[in.pc + 1]); }
+    }
+  }
+  if (with_out)     // PCOMP: the same machine plus OUT (libzpaq.cpp:1177), and loops as long as the block
+    out << "  template <class MP, class HP, class RP, class OP>\n"
+           "  static __device__ __forceinline__ int pcomp(unsigned input, unsigned& rb, unsigned& rc, unsigned& rd,\n"
+           "                                              unsigned& rf, MP M, HP H, RP R, OP& out) {\n"
+           "    unsigned a = input, b = rb, c = rc, d = rd, f = rf;\n"
+           "    unsigned budget = " << (1u << 30) << "u;\n";
+  else
   out << "  template <class MP, class HP, class RP>\n"
          "  static __device__ __forceinline__ int hcomp(unsigned input, unsigned& rb, unsigned& rc, unsigned& rd,\n"
          "                                              unsigned& rf, MP M, HP H, RP R) {\n"
          "    unsigned a = input, b = rb, c = rc, d = rd, f = rf;\n"
-         "    unsigned budget = " << kMaxVmSteps << "u;\n"
-         "    (void)R; (void)budget;\n"
-         "    goto L0;\n";
+         "    unsigned budget = " << kMaxVmSteps << "u;\n";
+  out <<
+         "    (void)R; (void)budget;\n";
+  for (int r : r_used) out << "    unsigned r_" << r << " = R[" << r << "];\n";
+  out << "    goto L0;\n";
   auto label = [&](int pc) -> std::string {
     if (insns.count(pc)) return "L" + std::to_string(pc);
     return "Lerr";
@@ -105,16 +125,16 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
     if (op < 64) {
       if (g == 7) {
         if (op == 56) { st = "goto Lhalt;"; falls = false; }
-        else if (op == 57) st = ";";
+        else if (op == 57) st = with_out ? "out(a);" : ";";
         else if (op == 59) st = "a = (a + (unsigned)M[b & MMASK] + 512u) * 773u;";
         else if (op == 60) st = "H[d & HMASK] = (H[d & HMASK] + a + 512u) * 773u;";
         else if (op == 63) { st = jump(pc + 2 + (int)(int8_t)imm, ""); falls = false; }
         else { st = "goto Lerr;"; falls = false; }
       } else if (k == 7) {
-        if (g < 4) st = dst_stmt(g, "R[" + std::to_string(imm) + "]");
+        if (g < 4) st = dst_stmt(g, "r_" + std::to_string(imm));
         else if (g == 4) st = jump(pc + 2 + (int)(int8_t)imm, "f");
         else if (g == 5) st = jump(pc + 2 + (int)(int8_t)imm, "!f");
-        else st = "R[" + std::to_string(imm) + "] = a;";
+        else st = "r_" + std::to_string(imm) + " = a;";
       } else if (op == 0 || k > 4) { st = "goto Lerr;"; falls = false; }
       else if (k == 0) {
         if (g == 4 || g == 5) {
@@ -155,7 +175,9 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out) {
     }
     out << "\n";
   }
-  out << "    Lhalt: rb = b; rc = c; rd = d; rf = f; return 0;\n"
+  out << "    Lhalt:";
+  for (int r : r_written) out << " R[" << r << "] = r_" << r << ";";
+  out << " rb = b; rc = c; rd = d; rf = f; return 0;\n"
          "    Lerr: return 5;\n"
          "  }\n";
   return true;
@@ -364,6 +386,26 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   for (const char* nm : names)
     o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << nm << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp: 64)
          "  zpq::pipe_" << nm << "_body<zpq_gen::Chain>(a);\n}\n";
+  source = o.str();
+  return true;
+}
+
+// PCOMP on the device: the post-processing program a block carries (PostProcessor, libzpaq.cpp:2183-2241), translated
+// like HCOMP and run one lane per segment (device/pcomp_kernel.h).  `code` = the PCOMP bytes without the length.
+bool generate_pcomp_source(const U8* code, size_t len, int ph, int pm, std::string& source, std::string& why_not) {
+  if (len < 1 || len > 65535) { why_not = "empty or oversized PCOMP"; return false; }
+  if (ph > 28 || pm > 30) { why_not = "PCOMP arrays too large"; return false; }
+  std::ostringstream o;
+  o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " (PCOMP post-processor) -- do not edit\n"
+       "#include \"pcomp_kernel.h\"\n"
+       "namespace zpq_gen {\n"
+       "struct Post {\n"
+       "  static constexpr unsigned HMASK = " << ((1u << ph) - 1u) << "u, MMASK = " << ((1u << pm) - 1u) << "u;\n";
+  if (!translate_hcomp(code, (int)len, o, true)) { why_not = "PCOMP program too irregular to translate"; return false; }
+  o << "};\n"
+       "}  // namespace zpq_gen\n"
+       "extern \"C\" __global__ __launch_bounds__(64) void zpq_pcomp_run(const zpq::PcompJob* jobs, unsigned n) {\n"
+       "  zpq::pcomp_body<zpq_gen::Post>(jobs, n);\n}\n";
   source = o.str();
   return true;
 }

@@ -8,7 +8,7 @@
 
 namespace zpq {
 
-static const int kCodegenVersion = 3;
+static const int kCodegenVersion = 4;
 
 // Emits the specialised translation unit for `plan`.  Returns false (with a
 // reason) when the chain cannot be specialised (n > 64, MIX wider than a wave,
@@ -39,6 +39,9 @@ struct PipeLayout {
 // false + reason when the chain cannot run on the pipelined encoder (then the per-wavefront kernels code it)
 bool pipe_layout(const zpq_plan& plan, PipeLayout& out, std::string& why_not);
 bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string& why_not);
+
+// PCOMP translated for the device (device/pcomp_kernel.h); code = PCOMP bytes without the 2 length bytes
+bool generate_pcomp_source(const U8* code, size_t len, int ph, int pm, std::string& source, std::string& why_not);
 
 // Cache key of a generated source: SHA-1 over the text (which embeds the codegen
 // version) -- the loader extends it with a digest of the kernel template headers.

@@ -171,7 +171,7 @@ void decompress(Reader* in, Writer* out) {
 // decompress() is called for it, and then served in the requested pieces.
 Decompresser::Decompresser()
     : in_(0), out_(0), sha1_(0), rpos_(0), plan_(0), dpos_(0), payload_end_(0), seg_decoded_(false),
-      segs_in_block_(0), pp_(0), state_(BLOCK) {}
+      segs_in_block_(0), pp_(0), skipped_in_block_(false), state_(BLOCK) {}
 Decompresser::~Decompresser() { delete (zpq::PostProcessor*)pp_; }
 
 int Decompresser::getc() {
@@ -186,6 +186,19 @@ int Decompresser::getc() {
     if (buf_.empty()) return -1;
   }
   return buf_[rpos_++];
+}
+
+// byte at rpos_ + off, reading ahead as far as needed without consuming anything (buffered() stays exact)
+int Decompresser::peek(size_t off) {
+  while (rpos_ + off >= buf_.size()) {
+    if (!in_) return -1;
+    const size_t old = buf_.size();
+    buf_.resize(old + (1 << 16));
+    const int got = in_->read((char*)buf_.data() + old, 1 << 16);
+    buf_.resize(old + (got > 0 ? (size_t)got : 0));
+    if (got <= 0) return -1;
+  }
+  return buf_[rpos_ + off];
 }
 
 bool Decompresser::findBlock(double* memptr) {
@@ -221,6 +234,8 @@ bool Decompresser::findBlock(double* memptr) {
     } else *memptr = 0;
   }
   segs_in_block_ = 0;
+  block_cache_.clear();
+  skipped_in_block_ = false;
   delete (zpq::PostProcessor*)pp_;
   pp_ = new zpq::PostProcessor(header_[4], header_[5]);
   state_ = FILENAME;
@@ -278,15 +293,44 @@ void Decompresser::decode_segment() {
   std::vector<U8> payload;
   const bool modeled = header_[6] != 0;
   if (modeled) {
-    if (++segs_in_block_ > 1) error("multi-segment modelled blocks are outside this build's scope");
-    U32 curr = 0;
-    int c = 0;
-    while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); payload.push_back((U8)c); curr = (U32)c; }
-    while (curr) { c = getc(); if (c < 0) error("unexpected end of file"); payload.push_back((U8)c); curr = curr << 8 | (U32)c; }
-    // a flush byte of 00 puts a fifth zero in front of the marker (Decoder::skip 2165)
-    while ((c = getc()) == 0) payload.push_back(0);
-    if (c >= 0) --rpos_;
-    guarded([&] { decoded_ = zpq::decode_payload(header_, payload.data(), payload.size(), 0); });
+    if (skipped_in_block_) error("decompression after skipped segment");
+    const int my_index = segs_in_block_++;
+    if (my_index == 0) {
+      // The model and the coder run on from segment to segment, so the block's segments are decoded together: look
+      // ahead (without consuming) over this payload, its trailer and any further segments up to the end of the block
+      std::vector<std::vector<U8> > payloads;
+      size_t off = 0;
+      auto need = [&](size_t o) -> int { const int c = peek(o); if (c < 0) error("unexpected end of file"); return c; };
+      for (;;) {
+        std::vector<U8> pl;
+        U32 curr = 0;
+        int c = 0;
+        while (curr == 0) { c = need(off++); pl.push_back((U8)c); curr = (U32)c; }
+        while (curr) { c = need(off++); pl.push_back((U8)c); curr = curr << 8 | (U32)c; }
+        while ((c = peek(off)) == 0) { pl.push_back(0); ++off; }     // a flush byte of 00 puts a fifth zero in front
+        payloads.push_back(pl);
+        c = need(off++);                                             // trailer
+        if (c == 253) off += 20;
+        else if (c != 254) error("missing end of segment marker");
+        c = need(off++);
+        if (c != 1) break;                                           // 255: end of block
+        while (need(off++) != 0) {}                                  // filename
+        while (need(off++) != 0) {}                                  // comment
+        if (need(off++) != 0) error("missing reserved byte");
+      }
+      guarded([&] { block_cache_ = zpq::decode_payload_segments(header_, payloads, 0); });
+    }
+    if ((size_t)my_index >= block_cache_.size()) error("segment not found in its block");
+    // consume this segment's payload
+    {
+      U32 curr = 0;
+      int c = 0;
+      while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); curr = (U32)c; }
+      while (curr) { c = getc(); if (c < 0) error("unexpected end of file"); curr = curr << 8 | (U32)c; }
+      while ((c = getc()) == 0) {}
+      if (c >= 0) --rpos_;
+    }
+    decoded_.swap(block_cache_[(size_t)my_index]);
   } else {
     for (;;) {
       U32 len = 0;
@@ -331,6 +375,7 @@ void Decompresser::readSegmentEnd(char* sha1string) {
         while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); curr = (U32)c; }
         while (curr && (c = getc()) >= 0) curr = curr << 8 | (U32)c;
         ++segs_in_block_;
+        if (block_cache_.empty()) skipped_in_block_ = true;     // the model missed this segment (Decoder::skip, SKIP state)
       } else {
         for (;;) {
           U32 len = 0;
@@ -395,6 +440,7 @@ void Compressor::startBlock(const char* hcomp) {
   out_->put(1);
   for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
   segs_ = 0;
+  segq_.clear();
   delete (zpq::PostProcessor*)pp_;
   pp_ = 0;
   state_ = BLOCK1;
@@ -411,6 +457,7 @@ void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
   out_->put(1);
   for (size_t i = 0; i < header_.size(); ++i) out_->put(header_[i]);
   segs_ = 0;
+  segq_.clear();
   delete (zpq::PostProcessor*)pp_;
   pp_ = 0;
   state_ = BLOCK1;
@@ -424,12 +471,15 @@ bool Compressor::pcomp(Writer* out2) {
 }
 
 void Compressor::startSegment(const char* filename, const char* comment) {
-  out_->put(1);
-  while (filename && *filename) out_->put(*filename++);
-  out_->put(0);
-  while (comment && *comment) out_->put(*comment++);
-  out_->put(0);
-  out_->put(0);
+  std::vector<U8> head;
+  head.push_back(1);
+  while (filename && *filename) head.push_back((U8)*filename++);
+  head.push_back(0);
+  while (comment && *comment) head.push_back((U8)*comment++);
+  head.push_back(0);
+  head.push_back(0);
+  if (header_[6] == 0) out_->write((const char*)head.data(), (int)head.size());
+  else { segq_.push_back(SegBuf()); segq_.back().head.swap(head); }
   if (state_ == BLOCK1) state_ = SEG1;
   if (state_ == BLOCK2) state_ = SEG2;
   pending_.clear();
@@ -483,25 +533,24 @@ void Compressor::flush_segment() {
     std::vector<U8> framed;
     zpq::write_stored_payload(framed, 0, 0, pending_.data(), pending_.size());
     if (!framed.empty()) out_->write((const char*)framed.data(), (int)framed.size());
+    for (int i = 0; i < 4; ++i) out_->put(0);
   } else {
-    if (++segs_ > 1) error("multi-segment modelled blocks are outside this build's scope");
-    std::vector<U8> coded;
-    guarded([&] { coded = zpq::encode_payload(header_, 0, 0, pending_.data(), pending_.size()); });
-    size_t pos = 0;
-    while (pos < coded.size()) {
-      const size_t k = std::min<size_t>(coded.size() - pos, 1u << 30);
-      out_->write((const char*)coded.data() + pos, (int)k);
-      pos += k;
-    }
+    segq_.back().data.swap(pending_);        // coded at endBlock(), together with the block's other segments
   }
   pending_.clear();
-  for (int i = 0; i < 4; ++i) out_->put(0);
+}
+
+static void put_trailer(std::vector<U8>& t, const char* sha1) {
+  if (sha1) { t.push_back(253); t.insert(t.end(), (const U8*)sha1, (const U8*)sha1 + 20); }
+  else t.push_back(254);
 }
 
 void Compressor::endSegment(const char* sha1string) {
   flush_segment();
-  if (sha1string) { out_->put(253); for (int i = 0; i < 20; ++i) out_->put(sha1string[i]); }
-  else out_->put(254);
+  std::vector<U8> t;
+  put_trailer(t, sha1string);
+  if (header_[6] == 0) out_->write((const char*)t.data(), (int)t.size());
+  else segq_.back().tail.swap(t);
   state_ = BLOCK2;
 }
 
@@ -511,13 +560,34 @@ char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
     if (size) *size = (int64_t)seg_sha1_.usize();
     memcpy(sha1result_, seg_sha1_.result(), 20);       // result() also resets the hash for the next segment
   }
-  if (verify_ && dosha1) { out_->put(253); for (int i = 0; i < 20; ++i) out_->put(sha1result_[i]); }
-  else out_->put(254);
+  std::vector<U8> t;
+  put_trailer(t, verify_ && dosha1 ? sha1result_ : 0);
+  if (header_[6] == 0) out_->write((const char*)t.data(), (int)t.size());
+  else segq_.back().tail.swap(t);
   state_ = BLOCK2;
   return verify_ ? sha1result_ : 0;
 }
 
 void Compressor::endBlock() {
+  if (header_[6] != 0 && !segq_.empty()) {
+    // the block's segments through the model in one device job (Predictor and Encoder are initialised once per block,
+    // libzpaq.cpp:2889-2891), then the bytes in archive order
+    std::vector<std::vector<U8> > inputs, coded;
+    for (size_t i = 0; i < segq_.size(); ++i) inputs.push_back(segq_[i].data);
+    guarded([&] { coded = zpq::encode_payload_segments(header_, inputs); });
+    for (size_t i = 0; i < segq_.size(); ++i) {
+      out_->write((const char*)segq_[i].head.data(), (int)segq_[i].head.size());
+      size_t pos = 0;
+      while (pos < coded[i].size()) {
+        const size_t k = std::min<size_t>(coded[i].size() - pos, 1u << 30);
+        out_->write((const char*)coded[i].data() + pos, (int)k);
+        pos += k;
+      }
+      for (int z = 0; z < 4; ++z) out_->put(0);
+      out_->write((const char*)segq_[i].tail.data(), (int)segq_[i].tail.size());
+    }
+    segq_.clear();
+  }
   out_->put(255);
   state_ = INIT;
 }

@@ -85,6 +85,39 @@ def pipe_source_and_key(header):
     return buf.value.decode(), key.value.decode()
 
 
+def standard_pcomp_programs():
+    """PCOMP programs of the pre-processing methods compressBlock generates (levels 1-4, every block type branch and
+    block-size exponent): {(code, ph, pm): description}."""
+    import zpaq_amd as z
+    progs = {}
+    for arg0 in range(0, 7):
+        for body in (",1,4,0,3,%d" % (19 + arg0 + (arg0 <= 6)), ",5,4,0,3,%d" % (19 + arg0 + (arg0 <= 6)),
+                     ",2,12,0,7,%d,1c0,0,511i2" % (21 + arg0), ",6,12,0,7,%d,1c0,0,511i2" % (21 + arg0),
+                     ",2,5,0,7,%d1c0,0,511" % (21 + arg0), ",6,5,0,7,%d1c0,0,511" % (21 + arg0),
+                     ",3ci1", ",7ci1", ",4ci1,1,1,1,2am", ",4"):
+            xm = "x%d%s" % (arg0, body)
+            try:
+                h, pc, _ = z.method_to_header(xm)
+            except z.ZpaqError:
+                continue
+            if pc:
+                progs[(bytes(pc[2:]), h[4], h[5])] = xm
+    return progs
+
+
+def pcomp_source_and_key(code, ph, pm):
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_pcomp_source.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    rc = L.zpq_pcomp_source(code, len(code), ph, pm, buf, len(buf), C.byref(ln), key)
+    if rc != 0:
+        return None, L.zpq_last_error().decode()
+    return buf.value.decode(), key.value.decode()
+
+
 def compile_one(args):
     src, key, cache, inc = args
     out = os.path.join(cache, key + ".hsaco")
@@ -132,6 +165,11 @@ def main(verbose=True):
                 continue
             if key in seen:
                 continue
+            seen.add(key)
+            jobs.append((src, key, cache, inc))
+    for (code, ph, pm), why in standard_pcomp_programs().items():
+        src, key = pcomp_source_and_key(code, ph, pm)
+        if src is not None and key not in seen:
             seen.add(key)
             jobs.append((src, key, cache, inc))
     if forced is None:
