@@ -1,6 +1,6 @@
 #!/bin/bash
 run() {  # env blocks bytes
-  env $1 timeout 300 python bench.py --blocks $2 --block-bytes $3 --cpu-seconds 0 --warmup 1 --verify-blocks 2 2>&1 | tail -1 | python -c "
+  env $1 timeout 300 python bench.py --blocks $2 --block-bytes $3 --cpu-seconds 0 --warmup 1 --verify-blocks 2 --api-blocks 0 2>&1 | tail -1 | python -c "
 import sys, json
 l = sys.stdin.read().strip()
 try:
@@ -11,10 +11,11 @@ except Exception as e:
     print('%-58s %5d x %-8d FAILED %s' % ('$1', $2, $3, l[-300:]))
 "
 }
-python profiles/pipe_probe.py
 run "X=1" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=64" 1024 65536
-run "ZPAQ_AMD_PIPE_GROUP=16" 1024 65536
-run "X=1" 2048 65536
 run "X=1" 1024 1048576
-ZPAQ_AMD_PIPE_PROFILE=1 python bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --verify-blocks 0 2>&1 | grep "pipe profile" | awk '{k=$4; t[k]+=$7; n[k]+=1; if ($7>m[k]) m[k]=$7} END {for (k in t) printf "alone: %-6s units=%d avg=%.3f max=%.3f ms/step\n", k, n[k], t[k]/n[k], m[k]}'
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tl -o tl -- python $GRAFT_REPO_ROOT/bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --api-blocks 0 --verify-blocks 0 > /dev/null 2>&1
+ZPAQ_AMD_PIPE_SPLIT=1 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tls -o tls -- python $GRAFT_REPO_ROOT/bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --api-blocks 0 --verify-blocks 0 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python profiles/pipe_timeline.py gpurun_out/prof_tl/tl_results.db
+python profiles/pipe_timeline.py gpurun_out/prof_tls/tls_results.db --split

@@ -180,3 +180,7 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
     datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
              corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
     _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64)
+    # MATCH: long matches, a history buffer (1 KiB here) that wraps, candidates overlapping the byte being written
+    rep = bytes(np.random.default_rng(5).integers(0, 256, 97, dtype=np.uint8)) * 40
+    more = [rep, corpus.block("text", 1500, 3).tobytes() * 3, bytes(3000), b"abcabcabd" * 400, corpus.block("records", 4000, 8).tobytes()]
+    _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256)

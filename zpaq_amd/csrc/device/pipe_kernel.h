@@ -479,12 +479,12 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
       rb = rlimit - cmv;
       if (rb & mask) {
         // fast path legal when the 8 candidate bytes were not touched by this byte's store and do not wrap
+        // (before 8 bytes have been coded `hist` holds zeros where the reference reads the never-written end of the buffer)
         const bool overlap = ((cmv - 1u - wpos) & mask) < 8u;
         unsigned m = 0;
         if (!wraps && !overlap) {
           const unsigned long long diff = __builtin_bswap64(cand) ^ hist;
           m = diff ? (unsigned)(__builtin_ctzll(diff) >> 3) : 8u;
-          if (k + L.k0 + 1u < 8u) m = min(m, 8u);                // (hist of a young block holds zeros = what the buffer holds)
         }
         ra = m;
         if (wraps || overlap || m == 8u)
