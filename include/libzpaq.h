@@ -9,8 +9,8 @@
 // What is here:   Reader, Writer, error(), toU16, Array<T>, SHA1, StringBuffer,
 //                 compress(), compressBlock(), decompress(), Compressor,
 //                 Decompresser, plus the batched extension compressBlocks().
-// What is not:    the archiver-only services of the reference library (SHA256,
-//                 AES_CTR, scrypt/stretchKey, random) and the LZ77/BWT/E8E9
+// What is not:    encryption (AES_CTR / stretchKey are declared so that zpaq.cpp
+//                 links, and call error()) and the LZ77/BWT/E8E9
 //                 pre/post-processors; methods that need the latter report
 //                 through error() instead of writing a different archive.
 //
@@ -105,6 +105,35 @@ class SHA1 {
   U8 buf_[64];
   char out_[20];
 };
+
+// ---- archiver-only services of the reference library (libzpaq.h:956-1015) ----
+// zpaq.cpp needs these names to link.  SHA-256 and random() are real; encryption (AES in CTR mode keyed through
+// scrypt) is outside this library's scope: constructing an AES_CTR or calling stretchKey() calls error().
+class SHA256 {
+ public:
+  SHA256() { init(); }
+  void put(int c);
+  double size() const { return (double)len_; }
+  uint64_t usize() const { return len_; }
+  const char* result();    // 32-byte digest; resets the object
+ private:
+  void init();
+  void block();
+  U32 s_[8];
+  U64 len_;
+  U8 buf_[64];
+  char out_[32];
+};
+
+class AES_CTR {
+ public:
+  AES_CTR(const char* key, int keylen, const char* iv = 0);
+  void encrypt(U32 s0, U32 s1, U32 s2, U32 s3, unsigned char* ct);
+  void encrypt(char* buf, int n, U64 offset);
+};
+
+void stretchKey(char* out, const char* key, const char* salt);
+void random(char* buf, int n);    // n random bytes, the first never '7' or 'z' (a ZPAQ archive cannot start with them)
 
 // In-memory Reader+Writer (reference libzpaq.h:1377-1494).
 class StringBuffer : public Reader, public Writer {

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(args):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--warmup", "0"] + args
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-seconds", "0", "--warmup", "0", "--api-blocks", "0"] + args
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
     if not lines:
         return {"error": r.stderr[-500:], "args": args}
@@ -38,6 +38,10 @@ def main():
                 if kib / 1024 > max_mib:
                     continue
                 pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
+    if which == "north":      # BASELINE.json north star: random and highly compressible blocks, 64 KiB .. 16 MiB
+        for kind in ("zeros", "lcg"):
+            for kib, blocks in ((64, 1024), (256, 1024), (1024, 1024), (4096, 256), (16384, 64)):
+                pts.append(["--kind", kind, "--blocks", str(blocks), "--block-bytes", str(kib * 1024)])
     if which == "sizes4":
         for kind in ("zeros", "lcg"):
             pts.append(["--kind", kind, "--blocks", "256", "--block-bytes", str(4096 * 1024)])
@@ -46,7 +50,24 @@ def main():
         pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--mode", "decode"])   # config 5
         pts.append(["--kind", "text", "--blocks", "1024", "--block-bytes", str(256 * 1024), "--method", "4"])
         pts.append(["--kind", "pattern", "--blocks", "256", "--block-bytes", str(64 * 1024)])     # one chain per block: JIT budget
+    if which == "north":
+        # known answer of BASELINE.md section 2 at the top of the range: 16 MiB zeros, method 5 -> 688 bytes
+        import hashlib
+        import time
+        import numpy as np
+        sys.path.insert(0, ROOT)
+        import zpaq_amd as z
+        z.init(0)
+        t0 = time.time()
+        a, = z.compress_blocks([np.zeros(16 << 20, np.uint8)], "5")
+        ka = {"known_answer": "16 MiB zeros, method 5", "len": len(a), "sha1": hashlib.sha1(a).hexdigest(),
+              "ok": len(a) == 688 and hashlib.sha1(a).hexdigest() == "aecc5f154175bc56a6af2d0015f1e01acef55655",
+              "roundtrip": z.decompress(a) == bytes(16 << 20), "seconds": round(time.time() - t0, 1)}
+        print(ka, flush=True)
+        z.shutdown()
     with open(out, "w") as fh:
+        if which == "north":
+            fh.write(json.dumps(ka) + "\n")
         for p in pts:
             res = run(p)
             fh.write(json.dumps(res) + "\n")

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -362,6 +363,8 @@ struct PipeRun {
   uint32_t nsteps;
   uint32_t ngroups;
   uint32_t threads;          // lanes per workgroup of every kernel but hcomp (= blocks per group)
+  bool consumes[6][6];
+  int slack;
 };
 
 // ZPAQ_AMD_PIPE_PROFILE=1: run every unit type of every step alone on one stream between two events and print the
@@ -438,21 +441,40 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
     if (!ps) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   uint32_t nsteps = 0;
   for (auto& r : runs) nsteps = std::max(nsteps, r.nsteps);
-  Event fork, join;
-  Event done[6];
+  // Each kernel has its own in-order stream.  A launch of kernel k for step s waits only for what it really depends on:
+  //   * the producers of the streams it reads, at step s-1 (every value it reads was written at an earlier step);
+  //   * the consumers of the streams it writes, at step s-1-slack (the ring slot it is about to overwrite held a chunk
+  //     whose last reader ran at the latest then): with `slack` extra ring slots a fast producer runs that many steps
+  //     ahead of a slow consumer, so the run proceeds at the pace of the slowest KERNEL, not the sum of each step's slowest.
+  bool cons[6][6] = {};
+  int slack = 1 << 30;
+  for (auto& r : runs) {
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) cons[a][b] = cons[a][b] || r.consumes[a][b];
+    slack = std::min(slack, r.slack);
+  }
+  bool used[6] = {};
+  for (auto& r : runs) for (int k = 0; k < 6; ++k) used[k] = used[k] || r.grid[k] != 0;
+  const int R = slack + 2;                               // events kept per kernel
+  std::vector<std::unique_ptr<Event>> ev[6];
+  for (int k = 0; k < 6; ++k) for (int i = 0; i < R; ++i) ev[k].emplace_back(new Event());
+  Event fork;
   HIP_CHECK(hipEventRecord(fork, st));
   for (int k = 0; k < 6; ++k) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], fork, 0));
   for (uint32_t step = 0; step < nsteps; ++step) {
-    for (auto& r : runs) {
-      if (step >= r.nsteps) continue;
-      r.args.step = (int32_t)step;
-      void* args[1] = {(void*)&r.args};
-      for (int k = 0; k < 6; ++k) {
-        if (!r.grid[k]) continue;
+    for (int k = 0; k < 6; ++k) {
+      if (!used[k]) continue;
+      for (int p = 0; p < 6; ++p) {
+        if (p == k || !used[p]) continue;
+        if (cons[k][p] && step >= 1) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], *ev[p][(step - 1) % R], 0));
+        if (cons[p][k] && step >= 1u + (uint32_t)slack) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], *ev[p][(step - 1 - slack) % R], 0));
+      }
+      for (auto& r : runs) {
+        if (step >= r.nsteps || !r.grid[k]) continue;
+        r.args.step = (int32_t)step;
+        void* args[1] = {(void*)&r.args};
         if (split && k != 0) {
-          // ZPAQ_AMD_PIPE_SPLIT=1 (profiling aid): one launch per unit type, so that a kernel trace shows which unit of
-          // a kernel is the slow one; still concurrent on the kernel's stream? no -- same stream serialises them, so the
-          // extra streams below keep them parallel
+          // ZPAQ_AMD_PIPE_SPLIT=1 (profiling aid): one launch per unit type, on streams of their own, so that a kernel
+          // trace shows which unit of a kernel is the slow one
           for (uint32_t w0 = 0, ui = 0; w0 < r.grid[k]; w0 += r.ngroups, ++ui) {
             PipeArgs a2 = r.args;
             a2.wg0 = w0;
@@ -465,17 +487,11 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
         HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : r.threads, 1, 1, 0, e.pstream[k], args, nullptr));
       }
       if (split) split_join(e);
+      HIP_CHECK(hipEventRecord(*ev[k][step % R], e.pstream[k]));
     }
-    // join: stream 0 waits for 1..4, then 1..4 wait for stream 0
-    for (int k = 1; k < 6; ++k) {
-      HIP_CHECK(hipEventRecord(done[k], e.pstream[k]));
-      HIP_CHECK(hipStreamWaitEvent(e.pstream[0], done[k], 0));
-    }
-    HIP_CHECK(hipEventRecord(join, e.pstream[0]));
-    if (step + 1 < nsteps)
-      for (int k = 1; k < 6; ++k) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], join, 0));
   }
-  HIP_CHECK(hipStreamWaitEvent(st, join, 0));
+  for (int k = 0; k < 6; ++k)
+    if (used[k] && nsteps) HIP_CHECK(hipStreamWaitEvent(st, *ev[k][(nsteps - 1) % R], 0));
 }
 
 // Launch init + coding kernels for jobs already resident on the device, grouped
@@ -511,6 +527,8 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     const uint32_t ng = (g.count + (uint32_t)L.G - 1) / (uint32_t)L.G;
     r.ngroups = ng;
     r.threads = (uint32_t)L.G;
+    memcpy(r.consumes, L.consumes, sizeof(r.consumes));
+    r.slack = L.slack;
     r.grid[0] = (g.count + (uint32_t)L.hcomp_lanes - 1) / (uint32_t)L.hcomp_lanes;
     r.grid[1] = (uint32_t)L.rows.size() * ng;
     r.grid[2] = (uint32_t)L.light.size() * ng;

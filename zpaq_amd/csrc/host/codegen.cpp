@@ -301,7 +301,29 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   for (int i = 0; i < n; ++i) if (L.row[i] >= 0) L.rows.push_back(i);
   L.light.push_back({K_CODER, n - 1});
   L.coder_level = L.level[n - 1] + 1;
-  L.S = L.coder_level + 1;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 16) L.slack = v; }
+  L.S = L.coder_level + 1 + L.slack;
+  {
+    // which kernel produces the p stream of component i, and who reads what
+    auto kernel_of = [&](int i) { const unsigned t = comp[i].type; return t == C_ICM ? 3 : (t == C_ISSE ? 4 : (t == C_MIX ? 5 : 2)); };
+    auto reads = [&](int consumer_kernel, int j) { const int pk = kernel_of(j); if (pk != consumer_kernel) L.consumes[consumer_kernel][pk] = true; };
+    for (int i = 0; i < n; ++i) {
+      const CompDesc& c = comp[i];
+      const int k = kernel_of(i);
+      if (L.ctx[i] >= 0 && c.type != C_ICM && c.type != C_ISSE) L.consumes[k][0] = true;     // contexts from HCOMP
+      if (L.row[i] >= 0) { L.consumes[1][0] = true; L.consumes[k][1] = true; }                 // ROW unit reads ctx, the map reads bh
+      switch (c.type) {
+        case C_ISSE: reads(k, (int)c.a2); break;
+        case C_AVG: reads(k, (int)c.a1); reads(k, (int)c.a2); break;
+        case C_MIX2: reads(k, (int)c.a2); reads(k, (int)c.a3); break;
+        case C_SSE: reads(k, (int)c.a2); break;
+        case C_MIX: for (unsigned t = 0; t < c.a3; ++t) reads(k, (int)(c.a2 + t)); break;
+        default: break;
+      }
+    }
+    reads(2, n - 1);                       // the coder (light kernel) reads the last component
+    L.consumes[2][0] = true;               // ... and HCOMP's status word
+  }
   L.hcomp_state = L.nstate; L.nstate += 8;
   L.coder_state = L.nstate; L.nstate += 4;
   const uint64_t hbytes = 4ull * (ph.hmask + 1);

@@ -34,6 +34,11 @@ struct PipeLayout {
   std::vector<std::pair<int, int>> light;   // (PipeKind, component): CONS, CM, MATCH, AVG, MIX2, SSE units and the coder
   std::vector<int> rows, icm, isse, mix, mix_ql;
   uint64_t off_ctx = 0, off_bh = 0, off_p = 0, off_state = 0, group_bytes = 0;
+  // kernel-level dataflow (0 hcomp, 1 rows, 2 light, 3 icm, 4 isse, 5 mix): consumes[c][p] = some unit of kernel c reads a
+  // stream some unit of kernel p writes; slack = ring slots beyond the minimum, i.e. how many steps a producer kernel
+  // may run ahead of its slowest consumer
+  bool consumes[6][6] = {};
+  int slack = 3;
   int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += q; return s; }
 };
 // false + reason when the chain cannot run on the pipelined encoder (then the per-wavefront kernels code it)

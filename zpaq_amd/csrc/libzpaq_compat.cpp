@@ -3,6 +3,7 @@
 // (predict/update/encode/decode) is never executed on the host here.
 #include "../../include/libzpaq.h"
 
+#include <cstdio>
 #include <stdexcept>
 
 #include "device/plan.hpp"
@@ -163,6 +164,65 @@ void decompress(Reader* in, Writer* out) {
       }
     });
   });
+}
+
+// ---------------------------------------------------- archiver-only services
+// SHA-256 from FIPS 180-2.
+static const U32 kSha256K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+void SHA256::init() {
+  static const U32 h0[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  memcpy(s_, h0, sizeof(s_));
+  len_ = 0;
+}
+void SHA256::block() {
+  U32 w[64];
+  for (int i = 0; i < 16; ++i) w[i] = (U32)buf_[4 * i] << 24 | (U32)buf_[4 * i + 1] << 16 | (U32)buf_[4 * i + 2] << 8 | buf_[4 * i + 3];
+  auto ror = [](U32 x, int n) { return x >> n | x << (32 - n); };
+  for (int i = 16; i < 64; ++i)
+    w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
+           (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+  U32 a = s_[0], b = s_[1], c = s_[2], d = s_[3], e = s_[4], f = s_[5], g = s_[6], h = s_[7];
+  for (int i = 0; i < 64; ++i) {
+    const U32 t1 = h + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + kSha256K[i] + w[i];
+    const U32 t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  s_[0] += a; s_[1] += b; s_[2] += c; s_[3] += d; s_[4] += e; s_[5] += f; s_[6] += g; s_[7] += h;
+}
+void SHA256::put(int c) {
+  buf_[len_ & 63] = (U8)c;
+  if ((++len_ & 63) == 0) block();
+}
+const char* SHA256::result() {
+  const U64 bits = len_ * 8;
+  put(0x80);
+  while ((len_ & 63) != 56) put(0);
+  for (int i = 7; i >= 0; --i) put((int)(bits >> (8 * i)) & 255);
+  for (int i = 0; i < 8; ++i) {
+    out_[4 * i] = (char)(s_[i] >> 24); out_[4 * i + 1] = (char)(s_[i] >> 16);
+    out_[4 * i + 2] = (char)(s_[i] >> 8); out_[4 * i + 3] = (char)s_[i];
+  }
+  init();
+  return out_;
+}
+
+AES_CTR::AES_CTR(const char*, int, const char*) { error("encrypted archives are outside this build's scope"); }
+void AES_CTR::encrypt(U32, U32, U32, U32, unsigned char*) { error("encrypted archives are outside this build's scope"); }
+void AES_CTR::encrypt(char*, int, U64) { error("encrypted archives are outside this build's scope"); }
+void stretchKey(char*, const char*, const char*) { error("encrypted archives are outside this build's scope"); }
+
+void random(char* buf, int n) {
+  FILE* f = fopen("/dev/urandom", "rb");
+  if (!f || (int)fread(buf, 1, (size_t)n, f) != n) { if (f) fclose(f); error("key generation failed"); }
+  fclose(f);
+  if (n >= 1 && (buf[0] == '7' || buf[0] == 'z')) buf[0] ^= 0x80;
 }
 
 // ------------------------------------------------------------ Decompresser
