@@ -13,14 +13,8 @@ except Exception as e:
 }
 python profiles/pipe_probe.py
 run "X=1" 1024 65536
-run "ZPAQ_AMD_PIPE_SLACK=0" 1024 65536
-run "ZPAQ_AMD_PIPE_SLACK=1" 1024 65536
-run "ZPAQ_AMD_PIPE_SLACK=6" 1024 65536
-run "ZPAQ_AMD_PIPE_CHUNK=1024" 1024 65536
-run "ZPAQ_AMD_PIPE_CHUNK=256 ZPAQ_AMD_PIPE_SLACK=6" 1024 65536
+run "ZPAQ_AMD_PIPE_MIX_SPLIT=2" 1024 65536
+run "ZPAQ_AMD_PIPE_MIX_SPLIT=2 ZPAQ_AMD_PIPE_GROUP=64" 1024 65536
+run "ZPAQ_AMD_PIPE_GROUP=16" 1024 65536
 run "X=1" 1024 1048576
-run "X=1" 2048 1048576
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_tl -o tl -- python $GRAFT_REPO_ROOT/bench.py --blocks 1024 --block-bytes 65536 --cpu-seconds 0 --warmup 0 --api-blocks 0 --verify-blocks 0 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
-python profiles/pipe_timeline.py gpurun_out/prof_tl/tl_results.db
+python -m pytest tests/test_cli.py tests/test_cpp_api.py -m gpu -q 2>&1 | tail -3

@@ -104,12 +104,16 @@ def test_method_expansion_live(zlib_, ref):
 
 
 def test_unsupported_methods_fail_loudly(zlib_):
-    d = corpus.block("text", 5000, 1)
-    for method in ["1", "2", "3", "5,128,2"]:      # need LZ77 / BWT / E8E9 pre-processing
-        xm = zlib_.expand_method(method, d)
+    """What stays outside (index-block methods of the journaling archiver, undefined pre-processor codes) fails with a
+    status, it does not produce a different archive.  (Levels 1-3 and the E8E9 hints did fail here in round 1: they
+    are implemented now, see the pre-processing tests below.)"""
+    for xm, code in [("i0,0", 8), ("x0,8", 9), ("x0,9ci1", 9)]:
         with pytest.raises(zlib_.ZpaqError) as ei:
             zlib_.method_to_header(xm)
-        assert ei.value.code == 8
+        assert ei.value.code == code, xm
+    d = corpus.block("text", 5000, 1)
+    for method in ["1", "2", "3", "5,128,2"]:
+        zlib_.method_to_header(zlib_.expand_method(method, d))
 
 
 def test_assembler_vs_reference_compiler(zlib_, ref, golden):

@@ -960,18 +960,20 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
   static_for<0, Chain::NMIXR>([&](auto rc) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r], first = Chain::MIX_FIRST[r];   // first = sum of QL of earlier roles
-    const unsigned per_group = (unsigned)QL;                                                  // wavefronts per group
-    if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + QL) * ngroups) return;
+    constexpr int SPLIT = Chain::MIX_SPLIT;        // wavefronts are 1 / SPLIT full: fewer lanes, more wavefronts
+    const unsigned per_group = (unsigned)(QL * SPLIT);                                        // wavefronts per group
+    if (wg < (unsigned)(first * SPLIT) * ngroups || wg >= (unsigned)((first + QL) * SPLIT) * ngroups) return;
     constexpr CompK c = Chain::comp[I];
     constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL, TAIL = m % 4;
+    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL / SPLIT, TAIL = m % 4;
     static_assert(BPW >= 1 && NQ <= QL, "MIX lane group");
     constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
-    const unsigned wi = wg - (unsigned)first * ngroups;
+    const unsigned wi = wg - (unsigned)(first * SPLIT) * ngroups;
     const unsigned g = wi / per_group, sub = wi % per_group;
     const unsigned bl = (unsigned)lane / QL, q = (unsigned)lane % QL;
     PipeLane<Chain> L;
     L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
+    if (bl >= (unsigned)BPW) { L.live = false; L.nb = 0; }          // lanes beyond this wavefront's blocks
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     if (!L.nb) return;
     const bool act = q < (unsigned)NQ;                               // lanes that hold weights
@@ -991,20 +993,32 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
     const unsigned k1 = L.next(0);
     unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+    // inputs of the weights a lane does not have read as 0 (masked once per byte, not once per bit)
+    auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
+      const uint4 v = L.p(tin[x], kk);
+      const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
+      return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+    };
     uint4 pv[4], pv1[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) { pv[x] = L.p(tin[x], 0); pv1[x] = L.p(tin[x], k1); }
+    for (int x = 0; x < 4; ++x) { pv[x] = inputs(x, 0); pv1[x] = inputs(x, k1); }
     uint4 w[8];
+    unsigned rowc[8];
+#pragma unroll
+    for (int B = 0; B < 8; ++B) rowc[B] = row_of(h, byte, B);
     if constexpr (batch) {
 #pragma unroll
-      for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + row_of(h, byte, B));
+      for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
     }
     for (unsigned k = 0; k < L.nb; ++k) {
       const unsigned k2 = min(k + 2u, L.nb - 1u);
       const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
       uint4 pv2[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) pv2[x] = L.p(tin[x], k2);
+      for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
+      unsigned rown[8];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
       // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint),
       // forwarded below; contexts less than 256 apart -> any position may coincide: fetched after the stores
       const bool same = h1 == h;
@@ -1013,19 +1027,19 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
       if constexpr (batch) {
         if (!late) {
 #pragma unroll
-          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + row_of(h1, byte1, B));
+          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
         }
       }
       PipeP8 out;
 #pragma unroll
       for (int B = 0; B < 8; ++B) {
-        const unsigned row = row_of(h, byte, B);
+        const unsigned row = rowc[B];
         if constexpr (!batch) w[B] = *(g_u128a4*)(L.arena + row);
         const int w0 = (int)w[B].x, w1 = (int)w[B].y, w2 = (int)w[B].z, w3 = (int)w[B].w;
-        const int p0 = have[0] ? pipe_p_get(pv[0], B) : 0, p1 = have[1] ? pipe_p_get(pv[1], B) : 0;
-        const int p2 = have[2] ? pipe_p_get(pv[2], B) : 0, p3 = have[3] ? pipe_p_get(pv[3], B) : 0;
+        const int p0 = pipe_p_get(pv[0], B), p1 = pipe_p_get(pv[1], B), p2 = pipe_p_get(pv[2], B), p3 = pipe_p_get(pv[3], B);
+        // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
         const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
-        const int pr = sp_clamp2k(pipe_group_sum<QL>(act ? dot : 0) >> 8);
+        const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
         out.set(B, pr);
         const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
         nw[B].x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
@@ -1045,17 +1059,19 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
       if constexpr (batch) {
         if (late) {
 #pragma unroll
-          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + row_of(h1, byte1, B));
+          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
         }
 #pragma unroll
         for (int B = 0; B < 8; ++B) {
           // (the tail lane's words past the row's end are never used: their inputs are 0 and they are not stored)
-          const bool fw = same && row_of(h1, byte1, B) == row_of(h, byte, B);
+          const bool fw = same && rown[B] == rowc[B];
           w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y;
           w[B].z = fw ? nw[B].z : wn[B].z; w[B].w = fw ? nw[B].w : wn[B].w;
         }
       }
       h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+#pragma unroll
+      for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
 #pragma unroll
       for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
     }

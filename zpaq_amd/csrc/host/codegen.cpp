@@ -264,6 +264,10 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
     const int g = atoi(e);
     if (g == 8 || g == 16 || g == 32 || g == 64) L.G = g;
   }
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_SPLIT")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) L.mix_split = v;
+  }
   int qforce = 0;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_LANES")) qforce = atoi(e);
   enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
@@ -289,6 +293,7 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
         while (ql < nq) ql *= 2;
         if (qforce > ql && (qforce == 2 || qforce == 4 || qforce == 8 || qforce == 16)) ql = qforce;
         if (ql > L.G) { why_not = "MIX lane group wider than the block group"; return false; }
+        while (L.mix_split > 1 && ql * L.mix_split > L.G) L.mix_split /= 2;
         L.mix.push_back(i);
         L.mix_ql.push_back(ql);
         break;
@@ -390,6 +395,7 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   for (auto& r : L.light) { lk.push_back(r.first); lc.push_back(r.second); }
   int first = 0;
   for (int q : L.mix_ql) { mf.push_back(first); first += q; }
+  o << "  static constexpr int MIX_SPLIT = " << L.mix_split << ";\n";
   o << "  static constexpr int NROWU = " << L.rows.size() << ", NLIGHT = " << L.light.size() << ", NICM = " << L.icm.size() << ", NISSE = " << L.isse.size()
     << ", NMIXR = " << L.mix.size() << ";\n";
   arr("LIGHT_KIND", lk.data(), (int)lk.size());

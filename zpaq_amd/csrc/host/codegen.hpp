@@ -39,7 +39,8 @@ struct PipeLayout {
   // may run ahead of its slowest consumer
   bool consumes[6][6] = {};
   int slack = 3;
-  int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += q; return s; }
+  int mix_split = 1;           // MIX wavefronts carry 1 / mix_split of the lanes they could (more, emptier wavefronts)
+  int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += q; return s * mix_split; }
 };
 // false + reason when the chain cannot run on the pipelined encoder (then the per-wavefront kernels code it)
 bool pipe_layout(const zpq_plan& plan, PipeLayout& out, std::string& why_not);
