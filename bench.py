@@ -72,6 +72,13 @@ def make_corpus(kind, nblocks, block_bytes, first):
     return out
 
 
+def _size_name(n):
+    for sh, u in ((20, "MiB"), (10, "KiB")):
+        if n >= 1 << sh and n % (1 << sh) == 0:
+            return f"{n >> sh} {u}"
+    return f"{n} B"
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask and cgroup CPU quota, not just nproc."""
     n = os.cpu_count() or 1
@@ -387,8 +394,9 @@ def main():
     code_s = code_ms / 1e3 / max(a.steps, 1)          # coding time per step (this rank)
     achieved = algo_bytes / 1e9 / code_s if code_s > 0 else 0.0
     line = {
+        # BASELINE.json's metric, spelled with the method / batch shape of THIS run (the default is its -m5, 1024 x 1 MiB)
         "metric": ("compress" if a.mode == "encode" else "decompress") +
-                  " MB/s + bit-identical ratio, -m5 over 1024x1 MiB blocks",
+                  f" MB/s + bit-identical ratio, -m{a.method} over {a.blocks}x{_size_name(bs)} blocks",
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",

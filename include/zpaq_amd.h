@@ -103,6 +103,13 @@ int zpq_pcomp_source(const uint8_t* code, size_t codelen, int ph, int pm, char* 
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
+/* Headers nobody prebuilt (level-5 chains whose periodic models depend on the data): compile the kernels of `n` plans
+ * with hipRTC on up to `threads` host threads at once (0 = as many as the process may use, at most 16) -- the pipelined
+ * encoder when decode == 0, the wavefront kernel otherwise -- into the code-object cache.  The engine does the same at
+ * the start of every batch that brings more than one unseen header (at most ZPAQ_AMD_MAX_JIT = 64 per call); calling
+ * it ahead of time (a caller that knows its methods) moves the cost out of the first batch.  Needs no GPU.
+ * Returns the number of code objects compiled, or < 0. */
+int zpq_precompile(const zpq_plan* const* plans, size_t n, int decode, int threads);
 /* Introspection for tools and tests: the plan as the kernels see it (device/layout.h: PlanHeader,
  * CompDesc[n], Segment[nseg], HCOMP bytes).  The pointer stays valid until zpq_plan_destroy. */
 const uint8_t* zpq_plan_blob(const zpq_plan*, size_t* len);

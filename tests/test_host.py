@@ -239,6 +239,37 @@ def test_hiprtc_compiles_a_generated_kernel_without_a_gpu(zlib_, golden):
     assert n > 10000, log.value.decode(errors="replace")[:3000]
 
 
+def test_unseen_headers_compile_side_by_side(zlib_, tmp_path, monkeypatch):
+    """A batch that brings several headers nobody prebuilt (level-5 chains with data-dependent periodic models) must not
+    pay one hipRTC compilation after the other: zpq_precompile (what the engine runs at the start of such a batch) compiles
+    them in helper processes side by side into the code-object cache, where the loaders find them.  No GPU needed."""
+    import ctypes as C
+    import os
+    import time
+    L = zlib_.lib()
+    L.zpq_precompile.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int]
+    monkeypatch.setenv("ZPAQ_AMD_SPEC_CACHE", str(tmp_path))
+    assert os.access(os.path.join(os.path.dirname(zlib_.lib()._name), "zpq_jitc"), os.X_OK), "helper not built"
+    plans = [zlib_.Plan(zlib_.method_to_header(f"x0,0ci2,1,1c0,{200 + i}m16s")[0]) for i in range(4)]
+    arr = (C.c_void_p * len(plans))(*[p._h for p in plans])
+    for decode in (0, 1):
+        t0 = time.time()
+        assert L.zpq_precompile(arr, len(plans), decode, 4) == 4, L.zpq_last_error()
+        took = time.time() - t0
+        files = sorted(os.listdir(tmp_path))
+        assert len(files) == 4 * (decode + 1) and all(f.endswith(".hsaco") for f in files), files
+        assert all(os.path.getsize(tmp_path / f) > 10000 for f in files)
+        assert took < 60
+        # the cache key the loader will look for is the one the source functions report
+        src = C.create_string_buffer(1 << 21)
+        key = C.create_string_buffer(41)
+        ln = C.c_size_t()
+        fn = L.zpq_plan_spec_source if decode else L.zpq_plan_pipe_source
+        assert fn(plans[0]._h, src, len(src), C.byref(ln), key) == 0
+        assert key.value.decode() + ".hsaco" in files
+    assert L.zpq_precompile(arr, len(plans), 0, 4) == 0          # nothing left to do
+
+
 # ---------------------------------------------------------------------------------------------------------
 # LZ77 / BWT / E8E9 on the compression side (host/preproc.cpp + the PCOMP generators of host/method.cpp):
 # levels 1-3, the hinted branches of 4, and explicit "x" methods.  SURVEY section 8(f) row 1.

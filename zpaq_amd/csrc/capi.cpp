@@ -89,6 +89,20 @@ size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
   }
 }
 
+int zpq_precompile(const zpq_plan* const* plans, size_t n, int decode, int threads) {
+  try {
+    if (!plans && n) fail(ZPQ_E_ARG, "null plans");
+    std::vector<const zpq_plan*> v(plans, plans + n);
+    const int forced = spec_variant_forced();
+    std::string log;
+    const int done = spec_precompile(v, decode == 0, forced > 0 ? forced : 0, (int)std::min<size_t>(n, 1u << 20),
+                                     threads > 0 ? threads : engine_jit_threads(), &log);
+    if (!log.empty()) set_last_error(log);
+    return done;
+  } catch (const Failure& f) { set_last_error(f.what()); return -f.code; }
+  catch (const std::exception& ex) { set_last_error(ex.what()); return -ZPQ_E_DEVICE; }
+}
+
 const uint8_t* zpq_plan_blob(const zpq_plan* p, size_t* len) {
   if (len) *len = p ? p->blob.size() : 0;
   return p ? p->blob.data() : nullptr;

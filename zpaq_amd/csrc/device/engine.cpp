@@ -3,6 +3,7 @@
 #include "engine.hpp"
 
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -119,9 +120,18 @@ void bind_device(int dev) {
   set_plan_device_index(dev);
 }
 
+// hipRTC compilations one call may spend on headers nobody compiled before (the rest of that call's unseen headers
+// run on the generic kernel and are picked up by later calls), and the host threads that compile side by side
 int jit_budget() {
   if (const char* v = getenv("ZPAQ_AMD_MAX_JIT")) return atoi(v);
-  return 16;
+  return 64;
+}
+int jit_threads() {
+  if (const char* v = getenv("ZPAQ_AMD_JIT_THREADS")) return std::max(1, atoi(v));
+  unsigned hw = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw ? hw : 1, (unsigned)CPU_COUNT(&set));
+  return (int)std::max(1u, std::min(hw, 16u));
 }
 
 void engine_init_device(Engine& e, int device);
@@ -601,10 +611,38 @@ static int kind_of_sorted(const std::vector<LaunchGroup>& groups, size_t k) {
 }
 
 // Sort `order` so that every (kernel, plan) group is contiguous, and cut it into launch groups.
+// A batch with several headers nobody has compiled yet (level-5 chains with data-dependent periodic models): their
+// kernels are compiled side by side on the host cores before the kernels are picked, so that such a batch pays about one
+// compilation time, not one per header.  The code objects land in the cache directory / the loader's in-process store;
+// kernel_kind() then finds them there.
+template <class PlanOf>
+static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vector<uint32_t>& order, PlanOf plan_of) {
+  const int want = e.kernel_choice;
+  if (want == 1 || want == 2 || e.jit_left <= 1) return;
+  const bool pipe = !decode && (want == 0 || want == 4);
+  const int forced = spec_variant_forced();
+  const int variant = forced >= 0 ? forced : (dense ? 1 : 0);
+  std::vector<const zpq_plan*> unseen;
+  const zpq_plan* last = nullptr;
+  for (uint32_t b : order) {
+    const zpq_plan* p = plan_of(b);
+    if (p == last) continue;
+    last = p;
+    if (!p->hdr().wave_ok) continue;
+    const auto& d = p->cur();
+    if (pipe ? d.pipe_state != 0 || d.spec_state[variant] > 0 : d.spec_state[variant] != 0) continue;   // loaded, or known not to work
+    if (std::find(unseen.begin(), unseen.end(), p) == unseen.end()) unseen.push_back(p);
+  }
+  if (unseen.size() < 2) return;            // a single header is compiled where it is loaded
+  e.jit_left -= spec_precompile(unseen, pipe, variant, e.jit_left, jit_threads());
+  if (e.jit_left < 1) e.jit_left = 1;       // (what was compiled is found in the cache; the budget only counts compilations)
+}
+
 template <class PlanOf, class LenOf>
 static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
   const size_t cnt = order.size();
   const bool dense = cnt > (size_t)4 * e.cus;
+  precompile_unseen(e, decode, dense, order, plan_of);
   std::vector<KernelPick> pick(cnt);
   for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode);
   std::vector<uint32_t> idx(cnt);
@@ -1035,6 +1073,8 @@ void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n,
   HIP_CHECK(hipMemcpyAsync(out, e.sha_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, e.stream));
   HIP_CHECK(hipStreamSynchronize(e.stream));
 }
+
+int engine_jit_threads() { return jit_threads(); }
 
 int engine_selftest(int32_t out[8]) {
   Engine& e = eng();

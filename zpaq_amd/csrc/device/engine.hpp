@@ -65,5 +65,6 @@ struct PcompSeg { const U8* in; U32 in_len; U64 hint; std::vector<U8>* out; };
 bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<PcompSeg>& segs, std::string& note);
 void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out);
 int engine_selftest(int32_t out[8]);
+int engine_jit_threads();      // host threads spec_precompile() uses by default (ZPAQ_AMD_JIT_THREADS)
 
 }  // namespace zpq

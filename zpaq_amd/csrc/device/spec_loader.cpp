@@ -3,7 +3,15 @@
 
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cerrno>
+
+#include <algorithm>
 
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +51,32 @@ std::string hex20(const U8* d) {
   char hex[41];
   for (int i = 0; i < 20; ++i) snprintf(hex + 2 * i, 3, "%02x", d[i]);
   return std::string(hex, 40);
+}
+
+// Code objects compiled by spec_precompile() in this process that no loader has picked up yet (and those the cache
+// directory could not take): key -> code object.
+struct MemStore {
+  std::mutex mu;
+  std::map<std::string, std::vector<char>> code;
+};
+MemStore& mem_store() {
+  static MemStore s;
+  return s;
+}
+
+bool mem_take(const std::string& key, std::vector<char>& code, bool on_disk) {
+  MemStore& m = mem_store();
+  std::lock_guard<std::mutex> g(m.mu);
+  const auto it = m.code.find(key);
+  if (it == m.code.end()) return false;
+  code = it->second;
+  if (on_disk) m.code.erase(it);          // the cache file serves later loads (other devices, later processes)
+  return true;
+}
+
+bool file_exists(const std::string& path) {
+  struct stat sb;
+  return ::stat(path.c_str(), &sb) == 0 && sb.st_size > 0;
 }
 
 }  // namespace
@@ -98,19 +132,25 @@ bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string&
   return true;
 }
 
+// -simplifycfg-sink-common=false: store sinking across the kernel's big if/else ladders
+// otherwise forces register state into scratch (see prebuild.py, same flags)
+static std::vector<std::string> jit_options() {
+  std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + spec_include_dir(), "-Wno-unused-label",
+                                "-mllvm", "-simplifycfg-sink-common=false"};
+  const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS");
+  if (defs && defs[0]) o.push_back(defs);      // a single extra option, e.g. -DZPQ_PROF
+  return o;
+}
+
 static bool compile_hiprtc(const std::string& source, std::vector<char>& code, std::string& log) {
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, source.c_str(), "zpq_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     log = "hiprtcCreateProgram failed";
     return false;
   }
-  const std::string inc = "-I" + spec_include_dir();
-  // -simplifycfg-sink-common=false: store sinking across the kernel's big if/else ladders
-  // otherwise forces register state into scratch (see prebuild.py, same flags)
-  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str(), "-Wno-unused-label",
-                                   "-mllvm", "-simplifycfg-sink-common=false"};
-  const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS");
-  if (defs && defs[0]) opts.push_back(defs);   // a single extra option, e.g. -DZPQ_PROF
+  const std::vector<std::string> o = jit_options();
+  std::vector<const char*> opts;
+  for (const std::string& x : o) opts.push_back(x.c_str());
   const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
@@ -124,6 +164,151 @@ static bool compile_hiprtc(const std::string& source, std::vector<char>& code, s
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
   return true;
+}
+
+static bool write_cache_file(const std::string& key, const std::vector<char>& code) {
+  ::mkdir(spec_cache_dir().c_str(), 0755);
+  const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
+  // (a name of its own per writer: two threads or processes may compile the same key at the same time)
+  char suffix[64];
+  snprintf(suffix, sizeof suffix, ".tmp%ld_%p", (long)getpid(), (const void*)&code);
+  std::ofstream f(path + suffix, std::ios::binary);
+  if (!f) return false;
+  f.write(code.data(), (std::streamsize)code.size());
+  f.close();
+  if (!f) { ::unlink((path + suffix).c_str()); return false; }
+  return ::rename((path + suffix).c_str(), path.c_str()) == 0;
+}
+
+extern "C" char** environ;
+
+struct JitItem { std::string source, key; };
+
+// hipRTC compiles one program at a time per process, so several headers are compiled by several helper processes
+// (zpq_jitc, next to the library): sources and code objects travel through a scratch directory.  Returns the number of
+// code objects made, or -1 when the helper is not there.
+static int precompile_in_processes(const std::vector<JitItem>& todo, int procs, std::string* log) {
+  const std::string helper = lib_dir() + "/zpq_jitc";
+  if (::access(helper.c_str(), X_OK) != 0) return -1;
+  const char* tmp = getenv("TMPDIR");
+  std::string dir = std::string(tmp && tmp[0] ? tmp : "/tmp") + "/zpq_jit_XXXXXX";
+  if (!::mkdtemp(&dir[0])) return -1;
+  const std::vector<std::string> o = jit_options();
+  struct Child { pid_t pid = -1; size_t item = 0; };
+  std::vector<Child> running;
+  size_t next = 0;
+  int done = 0;
+  auto src_of = [&](size_t i) { return dir + "/" + todo[i].key + ".hip"; };
+  auto out_of = [&](size_t i) { return dir + "/" + todo[i].key + ".hsaco"; };
+  auto err_of = [&](size_t i) { return dir + "/" + todo[i].key + ".log"; };
+  auto reap = [&](const Child& c, int status) {
+    std::string blob;
+    // (status -1: the host application ignores SIGCHLD, the exit status is gone -- the helper renames its output into
+    // place only when it is complete, so the file says whether it worked)
+    if ((status == -1 || (WIFEXITED(status) && WEXITSTATUS(status) == 0)) && read_file(out_of(c.item), blob) && !blob.empty()) {
+      std::vector<char> code(blob.begin(), blob.end());
+      (void)write_cache_file(todo[c.item].key, code);
+      MemStore& m = mem_store();
+      std::lock_guard<std::mutex> g(m.mu);
+      m.code[todo[c.item].key] = std::move(code);
+      ++done;
+    } else if (log) {
+      std::string l;
+      read_file(err_of(c.item), l);
+      *log += todo[c.item].key + ": " + l.substr(0, 2000) + "\n";
+    }
+    ::unlink(src_of(c.item).c_str());
+    ::unlink(out_of(c.item).c_str());
+    ::unlink(err_of(c.item).c_str());
+  };
+  while (next < todo.size() || !running.empty()) {
+    while (next < todo.size() && (int)running.size() < procs) {
+      const size_t i = next++;
+      { std::ofstream f(src_of(i), std::ios::binary); f.write(todo[i].source.data(), (std::streamsize)todo[i].source.size()); }
+      const std::string src = src_of(i), out = out_of(i), err = err_of(i);
+      std::vector<char*> argv = {(char*)helper.c_str(), (char*)src.c_str(), (char*)out.c_str()};
+      for (const std::string& x : o) argv.push_back((char*)x.c_str());
+      argv.push_back(nullptr);
+      posix_spawn_file_actions_t fa;
+      posix_spawn_file_actions_init(&fa);
+      posix_spawn_file_actions_addopen(&fa, 2, err.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+      Child c;
+      c.item = i;
+      const int rc = posix_spawn(&c.pid, helper.c_str(), &fa, nullptr, argv.data(), environ);
+      posix_spawn_file_actions_destroy(&fa);
+      if (rc != 0) {
+        if (log) *log += todo[i].key + ": cannot start " + helper + "\n";
+        ::unlink(src.c_str());
+        continue;
+      }
+      running.push_back(c);
+    }
+    if (running.empty()) break;
+    // wait for ONE OF OURS (the host application may have children of its own: never wait for "any child")
+    bool reaped = false;
+    for (size_t k = 0; k < running.size(); ++k) {
+      int status = 0;
+      const pid_t r = ::waitpid(running[k].pid, &status, WNOHANG);
+      if (r == running[k].pid || (r < 0 && errno != EINTR)) {
+        reap(running[k], r < 0 ? -1 : status);
+        running.erase(running.begin() + (long)k);
+        reaped = true;
+        break;
+      }
+    }
+    if (!reaped) ::usleep(5000);
+  }
+  ::rmdir(dir.c_str());
+  return done;
+}
+
+int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int variant, int max_compiles, int threads,
+                    std::string* log) {
+  std::vector<JitItem> todo;
+  std::vector<std::string> seen;
+  const bool no_pipe = getenv("ZPAQ_AMD_NO_PIPE") != nullptr, no_spec = getenv("ZPAQ_AMD_NO_SPEC") != nullptr;
+  for (const zpq_plan* p : plans) {
+    if ((int)todo.size() >= max_compiles) break;
+    if (!p || !p->hdr().wave_ok) continue;
+    JitItem it;
+    std::string why;
+    bool have = false;
+    if (pipe && !no_pipe) have = pipe_source_and_key(*p, it.source, it.key, why);
+    if (!have && !no_spec) have = spec_source_and_key(*p, variant, it.source, it.key, why);
+    if (!have) continue;
+    bool dup = false;
+    for (const std::string& k : seen) dup = dup || k == it.key;
+    if (dup) continue;
+    seen.push_back(it.key);
+    if (file_exists(spec_cache_dir() + "/" + it.key + ".hsaco")) continue;
+    {
+      MemStore& m = mem_store();
+      std::lock_guard<std::mutex> g(m.mu);
+      if (m.code.count(it.key)) continue;
+    }
+    todo.push_back(std::move(it));
+  }
+  if (todo.empty()) return 0;
+  if (todo.size() > 1 && threads > 1) {
+    const int n = precompile_in_processes(todo, threads, log);
+    if (n >= 0) return n;                   // (< 0: no helper here -- compile in this process, one after the other)
+  }
+  int done = 0;
+  for (const JitItem& it : todo) {
+    std::vector<char> code;
+    std::string l;
+    if (!compile_hiprtc(it.source, code, l)) {
+      if (log) *log += it.key + ": " + l.substr(0, 2000) + "\n";
+      continue;                           // the loader will try again on its own and report the failure in the plan's note
+    }
+    (void)write_cache_file(it.key, code);
+    MemStore& m = mem_store();
+    std::lock_guard<std::mutex> g(m.mu);
+    m.code[it.key] = std::move(code);
+    ++done;
+  }
+  return done;
 }
 
 size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log) {
@@ -146,7 +331,9 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   std::string origin;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
   std::string blob;
-  if (read_file(path, blob) && !blob.empty()) {
+  if (mem_take(key, code, file_exists(path))) {
+    origin = "hiprtc";                      // compiled by spec_precompile() in this process
+  } else if (read_file(path, blob) && !blob.empty()) {
     code.assign(blob.begin(), blob.end());
     origin = "cache:" + key;
   } else {
@@ -200,7 +387,9 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
   std::vector<char> code;
   std::string origin, blob;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
-  if (read_file(path, blob) && !blob.empty()) {
+  if (mem_take(key, code, file_exists(path))) {
+    origin = "hiprtc";                      // compiled by spec_precompile() in this process
+  } else if (read_file(path, blob) && !blob.empty()) {
     code.assign(blob.begin(), blob.end());
     origin = "cache:" + key;
   } else {

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <string>
+#include <vector>
 
 #include "plan.hpp"
 
@@ -52,6 +53,12 @@ bool pcomp_source_and_key(const U8* code, size_t len, int ph, int pm, std::strin
 bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not);
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
 size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log);
+// Compiles (hipRTC, no device needed) the code objects the listed plans would need -- the pipelined encoder when
+// `pipe` (and the chain has one), the wavefront kernel of `variant` otherwise -- that are neither in the cache directory nor compiled
+// earlier in this process, on up to `threads` host threads at once, at most `max_compiles` of them.  Results go to the
+// cache directory (when writable) and to an in-process store the loaders look into first.  Returns the number compiled.
+int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int variant, int max_compiles, int threads,
+                    std::string* log = nullptr);
 std::string spec_include_dir();
 std::string spec_cache_dir();
 
