@@ -184,3 +184,40 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
     rep = bytes(np.random.default_rng(5).integers(0, 256, 97, dtype=np.uint8)) * 40
     more = [rep, corpus.block("text", 1500, 3).tobytes() * 3, bytes(3000), b"abcabcabd" * 400, corpus.block("records", 4000, 8).tobytes()]
     _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256)
+
+
+def test_pipe_encoder_mix_bit_lanes(zlib_, oracle, golden):
+    """ZPAQ_AMD_PIPE_MIX_BITS=1: the MIX unit with a lane per (block, bit position, weight quad) and rows fetched
+    MIX_DEPTH bytes ahead (pipe_kernel.h::pipe_mix_bits_body).  Same bytes as the oracle for the -m5 chain at every
+    depth, for the legacy models (lane groups of 2 and 4: several blocks per wavefront), for other group widths, and
+    for the stress chain whose 256-row MIX makes every pair of different contexts collide (the fetch-again path) while
+    equal contexts exercise the lane's own history."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    for depth in (1, 2, 3, 4):
+        assert "MIX_BITS = 1, MIX_DEPTH = %d" % depth in emu.pipe_source(h5, 64, None, None, 1, depth)
+        _pipe_check(oracle, h5, ragged + [b""], chunk=64, mix_bits=1, mix_depth=depth)
+    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, mix_bits=1)
+    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, mix_bits=1, mix_depth=2)
+    # legacy mid / max models and the nine-type config
+    seen = set()
+    for e in [golden["config_cases"][0]] + golden["level_cases"]:
+        header = bytes.fromhex(e["header"])
+        if header in seen or not header[6] or header[6] > 64:
+            continue
+        seen.add(header)
+        if "MIX_BITS = 1" not in emu.pipe_source(header, 64, None, None, 1, 3):
+            continue                            # no MIX, or one that does not keep the whole partial byte in its row index
+        d = gen_input(e).tobytes()
+        if len(d) < 64:
+            d = corpus.block("records", 600, 3).tobytes()
+        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, mix_bits=1)
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
+             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
+    for depth in (2, 4):
+        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mix_bits=1, mix_depth=depth)

@@ -949,8 +949,154 @@ __device__ __forceinline__ int pipe_group_sum(int v) {
   return v;
 }
 
+// MIX with a lane per (block, BIT POSITION, weight quad).  A MIX whose context mask keeps the whole partial byte
+// (c.a5 == 255, at least 256 rows) selects a different weight row for each of a byte's 8 bits -- c8 is part of the row
+// index -- and training touches the selected row only, so with all bits known the 8 bits of a byte are independent:
+// 8 x QL lanes work on one byte at a time, the per-byte chain is one bit's ~70 instructions instead of eight bits' ~1000,
+// and the unit runs 8 x the wavefronts.  All bit positions of a block sit in ONE wavefront (workgroups of 64 threads,
+// QL <= 8), so two bytes whose rows coincide through DIFFERENT contexts are ordered by the wavefront's instruction
+// order.  Rows, inputs and contexts are fetched MIX_DEPTH bytes ahead; a row rewritten since its fetch is taken from
+// the lane's own history (same context: same bit position, same lane) or fetched again (contexts less than a byte's
+// row range apart: any lane may have written it).
+template <class Chain>
+__device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
+  __shared__ PipeSquash squash;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  squash.load(a.tb, lane);
+  __syncthreads();
+  static_for<0, Chain::NMIXR>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r], first = Chain::MIX_FIRST[r];   // first: wavefronts per group of earlier roles
+    constexpr int PPW = 64 / QL, BPW = PPW / 8;                  // (block, bit) pairs and blocks per wavefront
+    static_assert(QL <= 8 && BPW >= 1 && (int)Chain::PIPE_G % BPW == 0, "MIX bit lanes: a block's 8 positions share a wavefront");
+    constexpr int WPG = (int)Chain::PIPE_G / BPW;                // wavefronts per group
+    if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + WPG) * ngroups) return;
+    constexpr CompK c = Chain::comp[I];
+    constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
+    constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D > 1 ? D - 1 : 1;
+    static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "MIX bit lanes need the 8 rows of a byte to be distinct");
+    const unsigned wi = wg - (unsigned)first * ngroups;
+    const unsigned g = wi / (unsigned)WPG, sub = wi % (unsigned)WPG;
+    const unsigned pair = (unsigned)lane / QL, q = (unsigned)lane % QL, B = pair & 7u;
+    PipeLane<Chain> L;
+    L.open(a, g * Chain::PIPE_G + sub * BPW + (pair >> 3), Chain::P_LEVEL[I]);
+    if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+    if (!L.nb) return;
+    const bool act = q < (unsigned)NQ;                               // lanes that hold weights
+    const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+    const unsigned qoff = 16u * (act ? q : 0u);
+    bool have[4];
+    int tin[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int t = (int)q * 4 + x;
+      have[x] = t < m;
+      tin[x] = J + (have[x] ? t : 0);
+    }
+    auto row_of = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
+      const unsigned c8 = (1u << B) | (bytev >> (8u - B));           // pipe_c8 for a lane's own position
+      return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)m) + qoff;
+    };
+    auto input = [&](int x, unsigned kk) __attribute__((always_inline)) -> int {      // this position's half-word of the stream element
+      const int v = (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
+      return have[x] ? v : 0;
+    };
+    const unsigned last = L.nb - 1u;
+    // window of the next D bytes: row address, weights as fetched, inputs, context, the position's bit
+    unsigned rq[D], hc[D], yq[D];
+    uint4 wq[D];
+    int pq[D][4];
+    unsigned hq[D], bq[D];                  // context and input byte of the D bytes after the window
+    // the last D - 1 bytes done: row, context, weights as stored
+    unsigned hr[HN], hh[HN];
+    uint4 hw[HN];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
+      const unsigned hv = L.ctx(ci, kk), bv = L.byte_at(kk);
+      hc[j] = hv;
+      rq[j] = row_of(hv, bv);
+      yq[j] = (bv >> (7u - B)) & 1u;
+      wq[j] = *(g_u128a4*)(L.arena + rq[j]);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) pq[j][x] = input(x, kk);
+      hq[j] = L.ctx(ci, k2);
+      bq[j] = L.byte_at(k2);
+    }
+#pragma unroll
+    for (int i = 0; i < HN; ++i) { hr[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hw[i] = make_uint4(0u, 0u, 0u, 0u); }
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const unsigned k = kb + (unsigned)j;
+        const bool on = k < L.nb;
+        uint4 w = wq[j];
+        if constexpr (D > 1) {
+          bool late = false;
+#pragma unroll
+          for (int i = HN - 1; i >= 0; --i) {                       // oldest first: the most recent store wins
+            const bool fw = rq[j] == hr[i];
+            w.x = fw ? hw[i].x : w.x; w.y = fw ? hw[i].y : w.y; w.z = fw ? hw[i].z : w.z; w.w = fw ? hw[i].w : w.w;
+            late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & c.mask0) < 256u || ((hh[i] - hc[j]) & c.mask0) < 256u));
+          }
+          if (pipe_any(late)) {
+            if (late) w = *(g_u128a4*)(L.arena + rq[j]);            // after every store so far, in this wavefront's order
+          }
+        }
+        const int w0 = (int)w.x, w1 = (int)w.y, w2 = (int)w.z, w3 = (int)w.w;
+        const int p0 = pq[j][0], p1 = pq[j][1], p2 = pq[j][2], p3 = pq[j][3];
+        // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
+        const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
+        const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
+        const int err = __mul24((int)yq[j] * 32767 - squash(pr), (int)c.a4) >> 4;
+        uint4 nw;
+        nw.x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
+        nw.y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
+        nw.z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
+        nw.w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
+        const unsigned row = rq[j];
+        if (on) {
+          if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
+          if constexpr (TAIL != 0) {
+            if (tail) {
+              L.A32(row) = nw.x;
+              if constexpr (TAIL >= 2) L.A32(row + 4u) = nw.y;
+              if constexpr (TAIL >= 3) L.A32(row + 8u) = nw.z;
+            }
+          }
+          if (q == 0) *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
+        }
+        if constexpr (D > 1) {
+#pragma unroll
+          for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
+          hr[0] = row; hh[0] = hc[j]; hw[0] = nw;
+        }
+        // the slot now serves byte k + D
+        {
+          const unsigned hv = hq[j], bv = bq[j];
+          const unsigned kd = min(k + (unsigned)D, last), k2 = min(k + 2u * (unsigned)D, last);
+          hc[j] = hv;
+          rq[j] = row_of(hv, bv);
+          yq[j] = (bv >> (7u - B)) & 1u;
+          wq[j] = *(g_u128a4*)(L.arena + rq[j]);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) pq[j][x] = input(x, kd);
+          hq[j] = L.ctx(ci, k2);
+          bq[j] = L.byte_at(k2);
+        }
+      }
+    }
+  });
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
+  if constexpr (Chain::MIX_BITS != 0) {
+    pipe_mix_bits_body<Chain>(a);
+    return;
+  } else {
   __shared__ PipeSquash squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
@@ -1076,6 +1222,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
       for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
     }
   });
+  }
 }
 
 }  // namespace zpq

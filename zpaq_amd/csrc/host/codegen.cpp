@@ -270,6 +270,10 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   }
   int qforce = 0;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_LANES")) qforce = atoi(e);
+  bool want_mix_bits = false;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_BITS")) want_mix_bits = atoi(e) != 0;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.mix_depth = v; }
+  bool mix_bits_ok = true;
   enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
   for (int i = 0; i < n; ++i) {
     const CompDesc& c = comp[i];
@@ -296,12 +300,15 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
         while (L.mix_split > 1 && ql * L.mix_split > L.G) L.mix_split /= 2;
         L.mix.push_back(i);
         L.mix_ql.push_back(ql);
+        // a lane per bit position: the 8 rows of a byte must be distinct and a block's 8 x ql lanes fit one wavefront
+        mix_bits_ok = mix_bits_ok && c.a5 == 255u && c.mask0 >= 255u && ql <= 8 && L.G * ql % 8 == 0;
         break;
       }
       default: why_not = "unknown component type"; return false;
     }
     L.level[i] = lv;
   }
+  if (want_mix_bits && mix_bits_ok && !L.mix.empty()) { L.mix_bits = 1; L.mix_split = 1; }
   // ROW units (level 1) have a kernel of their own; the light kernel: the components in COMP order, then the coder
   for (int i = 0; i < n; ++i) if (L.row[i] >= 0) L.rows.push_back(i);
   L.light.push_back({K_CODER, n - 1});
@@ -394,8 +401,9 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   std::vector<int> lk, lc, mf;
   for (auto& r : L.light) { lk.push_back(r.first); lc.push_back(r.second); }
   int first = 0;
-  for (int q : L.mix_ql) { mf.push_back(first); first += q; }
-  o << "  static constexpr int MIX_SPLIT = " << L.mix_split << ";\n";
+  // MIX_FIRST: lane groups of earlier MIX roles (x MIX_SPLIT = wavefronts per group); with bit lanes: their wavefronts per group
+  for (int q : L.mix_ql) { mf.push_back(first); first += L.mix_bits ? L.mix_waves_of(q) : q; }
+  o << "  static constexpr int MIX_SPLIT = " << L.mix_split << ", MIX_BITS = " << L.mix_bits << ", MIX_DEPTH = " << L.mix_depth << ";\n";
   o << "  static constexpr int NROWU = " << L.rows.size() << ", NLIGHT = " << L.light.size() << ", NICM = " << L.icm.size() << ", NISSE = " << L.isse.size()
     << ", NMIXR = " << L.mix.size() << ";\n";
   arr("LIGHT_KIND", lk.data(), (int)lk.size());

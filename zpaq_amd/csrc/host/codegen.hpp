@@ -40,7 +40,14 @@ struct PipeLayout {
   bool consumes[6][6] = {};
   int slack = 3;
   int mix_split = 1;           // MIX wavefronts carry 1 / mix_split of the lanes they could (more, emptier wavefronts)
-  int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += q; return s * mix_split; }
+  // MIX with a lane per (block, bit position, weight quad) -- pipe_kernel.h::pipe_mix_bits_body; needs every MIX of the
+  // chain to keep the whole partial byte in its row index and at most 32 inputs (ZPAQ_AMD_PIPE_MIX_BITS=1; off by default:
+  // emulator-exact, not yet measured on the MI355X)
+  int mix_bits = 0;
+  int mix_depth = 3;           // bytes a bit-lane MIX fetches ahead (ZPAQ_AMD_PIPE_MIX_DEPTH, 1..4)
+  int mix_waves_of(int ql) const { return mix_bits ? G * ql / 8 : ql * mix_split; }       // wavefronts per group of one MIX
+  int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += mix_waves_of(q); return s; }
+  int mix_threads() const { return mix_bits ? 64 : G; }                                   // workgroup size of the mix kernel
 };
 // false + reason when the chain cannot run on the pipelined encoder (then the per-wavefront kernels code it)
 bool pipe_layout(const zpq_plan& plan, PipeLayout& out, std::string& why_not);
