@@ -1,0 +1,46 @@
+#!/bin/bash
+# First GPU call of the next round: A/B of the bit-lane units built at the end of round 2 (emulator-exact, never run on
+# the MI355X; off by default).  Parity first (a wrong kernel is not worth timing), then the headline with each knob.
+#   gpurun --timeout 2400 -- 'bash profiles/r03_ab_bits.sh'
+# Knobs (host/codegen.cpp, part of the generated source and therefore of the cache key; unseen variants go through hipRTC):
+#   ZPAQ_AMD_PIPE_MIX_BITS=1     MIX with a lane per (block, bit position, weight quad)   ZPAQ_AMD_PIPE_MIX_DEPTH=1..4 (3)
+#   ZPAQ_AMD_PIPE_LIGHT_BITS=m   1 CM | 2 MIX2 | 4 SSE with a lane per (block, bit position)   ZPAQ_AMD_PIPE_LIGHT_DEPTH=1..4 (3)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03ab
+mkdir -p $O
+cd $R
+export ZPAQ_AMD_MAX_JIT=256
+PAR="tests/test_gpu_parity.py -m gpu -q -x -k 'golden or nine or legacy or large or records or mixed or ragged or zeros'"
+echo "== parity with every bit-lane unit on" | tee $O/summary.txt
+ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 timeout 1200 bash -c "python -m pytest $PAR" > $O/parity_bits.txt 2>&1
+tail -3 $O/parity_bits.txt | tee -a $O/summary.txt
+BENCH="python bench.py --cpu-seconds 0 --api-blocks 0 --steps 1 --warmup 1"
+run() {   # name, env...
+  local name=$1; shift
+  env "$@" timeout 600 $BENCH > $O/bench_$name.json 2> $O/bench_$name.err
+  python - <<PY | tee -a $O/summary.txt
+import json
+try:
+    j = json.loads(open("$O/bench_$name.json").read().strip().splitlines()[-1])
+    print("%-28s value=%7.1f MB/s code_ms=%8.1f frac=%.4f ok=%s verified=%s origin=%s" % ("$name", j["value"], j["kernel_ms"]["code"],
+          j["roofline"]["frac"], j["all_status_ok"], j["roundtrip_verified_blocks"], j["roofline"]["kernel_origin"][:14]))
+except Exception as e:
+    print("$name FAILED", e, open("$O/bench_$name.err").read()[-400:])
+PY
+}
+run default
+for d in 1 2 3 4; do run mix_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d; done
+run light_cm ZPAQ_AMD_PIPE_LIGHT_BITS=1
+run light_mix2 ZPAQ_AMD_PIPE_LIGHT_BITS=2
+run light_sse ZPAQ_AMD_PIPE_LIGHT_BITS=4
+run light_all ZPAQ_AMD_PIPE_LIGHT_BITS=7
+for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d; done
+# per-kernel durations of the best candidate and of the default, for the timeline
+cd /tmp && export TMPDIR=/tmp
+for v in default all; do
+  E=""; [ $v = all ] && E="ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7"
+  env $E timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$v -o p -- python $R/bench.py --cpu-seconds 0 --api-blocks 0 --verify-blocks 0 --warmup 0 --steps 1 > $O/prof_$v.log 2>&1
+  python $R/profiles/pipe_timeline.py $O/prof_$v/p_results.db > $O/timeline_$v.txt 2>&1
+  rm -f $O/prof_$v/*.db
+  echo "== timeline $v"; head -12 $O/timeline_$v.txt
+done | tee -a $O/summary.txt

@@ -221,3 +221,38 @@ def test_pipe_encoder_mix_bit_lanes(zlib_, oracle, golden):
              corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
     for depth in (2, 4):
         _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mix_bits=1, mix_depth=depth)
+
+
+def test_pipe_encoder_light_bit_lanes(zlib_, oracle, golden):
+    """ZPAQ_AMD_PIPE_LIGHT_BITS=7 (1 CM | 2 MIX2 | 4 SSE): CM, MIX2 and SSE with a lane per (block, bit position), 8 workgroups per group and
+    unit, table words fetched LIGHT_DEPTH bytes ahead (pipe_kernel.h::pipe_cm_bits / pipe_mix2_bits / pipe_sse_bits) --
+    alone and together with the bit-lane MIX, on the -m5 chain, the legacy models and the stress chain whose tiny tables
+    make words of different contexts collide."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    src = emu.pipe_source(h5, 64, None, None, None, None, 7, 2)
+    assert "NLIGHT = 27" in src and "LIGHT_DEPTH = 2" in src           # CM, MIX2 (20) and SSE as 8 workgroups each
+    for depth in (1, 2, 3, 4):
+        _pipe_check(oracle, h5, ragged + [b""], chunk=64, light_bits=7, light_depth=depth)
+    _pipe_check(oracle, h5, ragged, chunk=64, light_bits=7, light_depth=3, mix_bits=1, mix_depth=3)
+    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, light_bits=7, mix_bits=1)
+    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, light_bits=7, light_depth=2)
+    seen = set()
+    for e in [golden["config_cases"][0]] + golden["level_cases"]:
+        header = bytes.fromhex(e["header"])
+        if header in seen or not header[6] or header[6] > 64:
+            continue
+        seen.add(header)
+        d = gen_input(e).tobytes()
+        if len(d) < 64:
+            d = corpus.block("records", 600, 3).tobytes()
+        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, light_bits=7, mix_bits=1)
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
+             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
+    for depth in (2, 4):
+        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, light_bits=7, light_depth=depth, mix_bits=1, mix_depth=depth)

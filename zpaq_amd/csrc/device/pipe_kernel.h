@@ -60,13 +60,22 @@ namespace zpq {
 typedef __attribute__((address_space(1))) short g_i16;
 typedef __attribute__((address_space(1))) unsigned short g_u16;
 
-enum PipeKind : int { PK_ROW = 1, PK_CONS, PK_CM, PK_MATCH, PK_AVG, PK_MIX2, PK_SSE, PK_CODER };
+enum PipeKind : int { PK_ROW = 1, PK_CONS, PK_CM, PK_MATCH, PK_AVG, PK_MIX2, PK_SSE, PK_CODER,
+                      PK_CM_BITS, PK_MIX2_BITS, PK_SSE_BITS };      // ..._BITS: a lane per (block, bit position), 8 workgroups per group
 
 __device__ __forceinline__ bool pipe_any(bool x) {
 #ifdef ZPQ_EMU
   return emu::wave_any(x);
 #else
   return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#endif
+}
+
+// Before a lane fetches a word ANOTHER lane of its wavefront may have stored: wait until the wavefront's stores have
+// been acknowledged (the bit-lane units' rare re-fetch path; everything else reads only what the lane itself wrote).
+__device__ __forceinline__ void pipe_stores_done() {
+#ifndef ZPQ_EMU
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #endif
 }
 
@@ -671,6 +680,226 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
   }
 }
 
+// ---- CM / MIX2 / SSE with a lane per (block, BIT POSITION) (ZPAQ_AMD_PIPE_LIGHT_BITS) ------------------------------
+// Same idea as pipe_mix_bits_body: the table word a bit uses is indexed by the bit's position in the byte (hmap4 / c8
+// are part of the index) and training touches that word only, so with all bits known the 8 bits of a byte are
+// independent.  8 lanes per block, the 8 positions of a block in ONE wavefront (a workgroup = PIPE_G lanes = PIPE_G / 8
+// blocks; a unit = 8 workgroups per group), table words / inputs / contexts fetched LIGHT_DEPTH bytes ahead, a word
+// rewritten since its fetch taken from the lane's own history (same context) or fetched again (contexts close enough
+// for DIFFERENT positions to meet).
+template <int D>
+struct PipeBitsWin {
+  static constexpr int HN = D;      // bytes whose stores a fetched word may have missed: the D - 1 done since its fetch
+                                    // and the one stored just before it (another lane's store is ordered only by the re-fetch)
+};
+
+__device__ __forceinline__ unsigned pipe_hmap4_at(unsigned byte, unsigned B) {
+  const unsigned hi = byte >> 4, lo = byte & 15u;
+  return B < 4u ? ((1u << B) | (hi >> (4u - B))) : (256u + 16u * hi + ((1u << (B - 4u)) | (lo >> (8u - B))));
+}
+__device__ __forceinline__ unsigned pipe_c8_at(unsigned byte, unsigned B) { return (1u << B) | (byte >> (8u - B)); }
+
+template <class Chain, int I, class DT>
+__device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, const PipeStretch& stretch, const DT& dt) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  static_assert(c.mask0 >= 511u, "CM bit lanes need the 8 words of a byte to be distinct");
+  if (!L.nb) return;
+  const unsigned last = L.nb - 1u;
+  auto addr = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * ((hh ^ pipe_hmap4_at(bytev, B)) & c.mask0);
+  };
+  unsigned aq[D], vq[D], hc[D], yq[D], hq[D], bq[D];
+  unsigned ha[HN], hh[HN], hv[HN];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
+    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
+    hc[j] = hv0; aq[j] = addr(hv0, bv); yq[j] = (bv >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
+    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+  }
+#pragma unroll
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const unsigned k = kb + (unsigned)j;
+      const bool on = k < L.nb;
+      unsigned v = vq[j];
+      {
+        bool late = false;
+#pragma unroll
+        for (int i = HN - 1; i >= 0; --i) {
+          v = aq[j] == ha[i] ? hv[i] : v;
+          late = late || (hc[j] != hh[i] && ((hc[j] ^ hh[i]) & c.mask0) < 512u);
+        }
+        if (pipe_any(late)) { pipe_stores_done(); if (late) v = L.A32(aq[j]); }
+      }
+      const int pr = stretch(v >> 17);
+      const unsigned nv = pipe_train(v, (int)yq[j], (unsigned)dt[v & 0x3ffu], c.limit);
+      if (on) {
+        L.A32(aq[j]) = nv;
+        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
+      }
+      {
+#pragma unroll
+        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+        ha[0] = aq[j]; hh[0] = hc[j]; hv[0] = nv;
+      }
+      {
+        const unsigned h2 = hq[j], b2 = bq[j];
+        const unsigned k2 = min(k + 2u * (unsigned)D, last);
+        hc[j] = h2; aq[j] = addr(h2, b2); yq[j] = (b2 >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
+        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+      }
+    }
+  }
+}
+
+template <class Chain, int I>
+__device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, const PipeSquash& squash) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  static_assert(c.a5 == 255u && c.mask0 >= 255u, "MIX2 bit lanes need the 8 weights of a byte to be distinct");
+  if (!L.nb) return;
+  const unsigned last = L.nb - 1u;
+  auto addr = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * ((hh + pipe_c8_at(bytev, B)) & c.mask0);
+  };
+  auto input = [&](int t, unsigned kk) __attribute__((always_inline)) -> int {
+    return (int)*(const g_i16*)((const g_u8*)&L.p(t, kk) + 2u * B);
+  };
+  unsigned aq[D], vq[D], hc[D], yq[D], hq[D], bq[D];
+  int pj[D], pk[D];
+  unsigned ha[HN], hh[HN], hv[HN];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
+    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
+    hc[j] = hv0; aq[j] = addr(hv0, bv); yq[j] = (bv >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
+    pj[j] = input((int)c.a2, kk); pk[j] = input((int)c.a3, kk);
+    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+  }
+#pragma unroll
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const unsigned k = kb + (unsigned)j;
+      const bool on = k < L.nb;
+      unsigned v = vq[j];
+      {
+        bool late = false;
+#pragma unroll
+        for (int i = HN - 1; i >= 0; --i) {
+          v = aq[j] == ha[i] ? hv[i] : v;
+          late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & c.mask0) < 256u || ((hh[i] - hc[j]) & c.mask0) < 256u));
+        }
+        if (pipe_any(late)) { pipe_stores_done(); if (late) v = L.A32(aq[j]); }
+      }
+      const int w = (int)v;
+      const int pr = (__mul24(w, pj[j]) + __mul24(65536 - w, pk[j])) >> 16;   // 17-bit x 12-bit
+      const int err = __mul24((int)yq[j] * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
+      const unsigned nv = (unsigned)min(max(w + ((__mul24(err, pj[j] - pk[j]) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
+      if (on) {
+        L.A32(aq[j]) = nv;
+        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
+      }
+      {
+#pragma unroll
+        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+        ha[0] = aq[j]; hh[0] = hc[j]; hv[0] = nv;
+      }
+      {
+        const unsigned h2 = hq[j], b2 = bq[j];
+        const unsigned kd = min(k + (unsigned)D, last), k2 = min(k + 2u * (unsigned)D, last);
+        hc[j] = h2; aq[j] = addr(h2, b2); yq[j] = (b2 >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
+        pj[j] = input((int)c.a2, kd); pk[j] = input((int)c.a3, kd);
+        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+      }
+    }
+  }
+}
+
+template <class Chain, int I, class DT>
+__device__ __forceinline__ void pipe_sse_bits(PipeLane<Chain>& L, unsigned B, const PipeStretch& stretch, const DT& dt) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  constexpr unsigned rowmask = c.mask0 >> 5;                         // rows of 32 entries
+  static_assert(c.mask0 >= 32u * 256u - 1u, "SSE bit lanes need the 8 rows of a byte to be distinct");
+  if (!L.nb) return;
+  const unsigned last = L.nb - 1u;
+  // entry pair read for this position: index of the lower one and the interpolation weight (libzpaq.cpp:1935-1939)
+  auto index = [&](unsigned hh, unsigned bytev, int pin, unsigned& wt) __attribute__((always_inline)) -> unsigned {
+    const int pq = min(max(pin + 992, 0), 1983);
+    wt = (unsigned)pq & 63u;
+    return (((hh + pipe_c8_at(bytev, B)) * 32u) & c.mask0) + (unsigned)(pq >> 6);
+  };
+  auto input = [&](unsigned kk) __attribute__((always_inline)) -> int {
+    return (int)*(const g_i16*)((const g_u8*)&L.p((int)c.a2, kk) + 2u * B);
+  };
+  unsigned ix[D], wt[D], e0[D], e1[D], hc[D], yq[D], hq[D], bq[D];
+  int iq[D];                                 // input of the byte D after the window's (the index depends on it)
+  unsigned ha[HN], hh[HN], hv[HN];           // entry trained (index), context, value stored
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
+    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
+    hc[j] = hv0; yq[j] = (bv >> (7u - B)) & 1u;
+    ix[j] = index(hv0, bv, input(kk), wt[j]);
+    e0[j] = L.A32((unsigned)c.t0 + 4u * (ix[j] & c.mask0));
+    e1[j] = L.A32((unsigned)c.t0 + 4u * ((ix[j] + 1u) & c.mask0));
+    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2); iq[j] = input(k2);
+  }
+#pragma unroll
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const unsigned k = kb + (unsigned)j;
+      const bool on = k < L.nb;
+      const unsigned i0 = ix[j] & c.mask0, i1 = (ix[j] + 1u) & c.mask0;
+      unsigned v0 = e0[j], v1 = e1[j];
+      {
+        bool late = false;
+#pragma unroll
+        for (int i = HN - 1; i >= 0; --i) {
+          v0 = i0 == ha[i] ? hv[i] : v0;
+          v1 = i1 == ha[i] ? hv[i] : v1;
+          late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & rowmask) < 256u || ((hh[i] - hc[j]) & rowmask) < 256u));
+        }
+        if (pipe_any(late)) {
+          pipe_stores_done();
+          if (late) { v0 = L.A32((unsigned)c.t0 + 4u * i0); v1 = L.A32((unsigned)c.t0 + 4u * i1); }
+        }
+      }
+      const unsigned w = wt[j];
+      const int pr = stretch((__umul24(v0 >> 10, 64u - w) + __umul24(v1 >> 10, w)) >> 13);
+      const unsigned tv = (w >> 5) ? v1 : v0;
+      const unsigned ti = (w >> 5) ? i1 : i0;
+      const unsigned nv = pipe_train(tv, (int)yq[j], (unsigned)dt[tv & 0x3ffu], c.limit);
+      if (on) {
+        L.A32((unsigned)c.t0 + 4u * ti) = nv;
+        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
+      }
+      {
+#pragma unroll
+        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+        ha[0] = ti; hh[0] = hc[j]; hv[0] = nv;
+      }
+      {
+        const unsigned h2 = hq[j], b2 = bq[j];
+        const unsigned k2 = min(k + 2u * (unsigned)D, last);
+        hc[j] = h2; yq[j] = (b2 >> (7u - B)) & 1u;
+        ix[j] = index(h2, b2, iq[j], wt[j]);
+        e0[j] = L.A32((unsigned)c.t0 + 4u * (ix[j] & c.mask0));
+        e1[j] = L.A32((unsigned)c.t0 + 4u * ((ix[j] + 1u) & c.mask0));
+        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2); iq[j] = input(k2);
+      }
+    }
+  }
+}
+
 // CODER: Encoder::compress / encode (libzpaq.cpp:2402-2447) fed by the last component's stream.
 template <class Chain>
 __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a, const PipeSquash& squash) {
@@ -776,6 +1005,29 @@ __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
     constexpr int kind = Chain::LIGHT_KIND[r], I = Chain::LIGHT_COMP[r];
     constexpr int level = kind == PK_CODER ? Chain::CODER_LEVEL : Chain::P_LEVEL[I];
     PipeLane<Chain> L;
+    if constexpr (kind >= PK_CM_BITS) {
+      // workgroup LIGHT_SUB[r] of the unit's 8: PIPE_G / 8 blocks, lane = (block, bit position)
+      constexpr unsigned BPW = Chain::PIPE_G / 8u;
+      L.open(a, g * Chain::PIPE_G + (unsigned)Chain::LIGHT_SUB[r] * BPW + ((unsigned)lane >> 3), level);
+      if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+      const unsigned B = (unsigned)lane & 7u;
+      if constexpr (kind == PK_CM_BITS) {
+        for (int i = lane; i < 1024; i += (int)blockDim.x) dt[i] = a.tb->dt[i];
+        stretch.load(a.tb, lane);
+        __syncthreads();
+        pipe_cm_bits<Chain, I>(L, B, stretch, dt);
+      } else if constexpr (kind == PK_MIX2_BITS) {
+        squash.load(a.tb, lane);
+        __syncthreads();
+        pipe_mix2_bits<Chain, I>(L, B, squash);
+      } else {
+        for (int i = lane; i < 1024; i += (int)blockDim.x) dt[i] = a.tb->dt[i];
+        stretch.load(a.tb, lane);
+        __syncthreads();
+        pipe_sse_bits<Chain, I>(L, B, stretch, dt);
+      }
+      return;
+    }
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, level);
     if (L.chunk < 0) return;
     if constexpr (kind != PK_CODER) { if (!pipe_any(L.nb > 0)) return; }
@@ -975,7 +1227,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
     if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + WPG) * ngroups) return;
     constexpr CompK c = Chain::comp[I];
     constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-    constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D > 1 ? D - 1 : 1;
+    constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D;
     static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "MIX bit lanes need the 8 rows of a byte to be distinct");
     const unsigned wi = wg - (unsigned)first * ngroups;
     const unsigned g = wi / (unsigned)WPG, sub = wi % (unsigned)WPG;
@@ -1033,7 +1285,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
         const unsigned k = kb + (unsigned)j;
         const bool on = k < L.nb;
         uint4 w = wq[j];
-        if constexpr (D > 1) {
+        {
           bool late = false;
 #pragma unroll
           for (int i = HN - 1; i >= 0; --i) {                       // oldest first: the most recent store wins
@@ -1042,6 +1294,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
             late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & c.mask0) < 256u || ((hh[i] - hc[j]) & c.mask0) < 256u));
           }
           if (pipe_any(late)) {
+            pipe_stores_done();
             if (late) w = *(g_u128a4*)(L.arena + rq[j]);            // after every store so far, in this wavefront's order
           }
         }
@@ -1068,7 +1321,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
           }
           if (q == 0) *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
         }
-        if constexpr (D > 1) {
+        {
 #pragma unroll
           for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
           hr[0] = row; hh[0] = hc[j]; hw[0] = nw;

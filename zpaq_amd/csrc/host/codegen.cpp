@@ -268,26 +268,35 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) L.mix_split = v;
   }
+  enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
   int qforce = 0;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_LANES")) qforce = atoi(e);
   bool want_mix_bits = false;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_BITS")) want_mix_bits = atoi(e) != 0;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.mix_depth = v; }
   bool mix_bits_ok = true;
-  enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_LIGHT_BITS")) L.light_bits = L.G % 8 == 0 ? atoi(e) & 7 : 0;     // 1 CM | 2 MIX2 | 4 SSE
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_LIGHT_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.light_depth = v; }
+  enum { K_CM_BITS = 9, K_MIX2_BITS, K_SSE_BITS };
+  // a light unit: one workgroup per group, or -- a lane per bit position -- eight
+  auto light_unit = [&](int kind, int bits_kind, bool bits_ok, int i) {
+    if (bits_ok && (L.light_bits >> (bits_kind - K_CM_BITS) & 1)) { for (int sub = 0; sub < 8; ++sub) { L.light.push_back({bits_kind, i}); L.light_sub.push_back(sub); } }
+    else { L.light.push_back({kind, i}); L.light_sub.push_back(0); }
+  };
   for (int i = 0; i < n; ++i) {
     const CompDesc& c = comp[i];
     L.ctx[i] = L.row[i] = L.state[i] = -1;
     int lv = 1;
     switch (c.type) {
-      case C_CONS: L.light.push_back({K_CONS, i}); break;
-      case C_CM: L.ctx[i] = L.nctx++; L.light.push_back({K_CM, i}); break;
-      case C_MATCH: L.ctx[i] = L.nctx++; L.state[i] = L.nstate; L.nstate += 8; L.light.push_back({K_MATCH, i}); break;
+      case C_CONS: light_unit(K_CONS, K_CM_BITS, false, i); break;
+      case C_CM: L.ctx[i] = L.nctx++; light_unit(K_CM, K_CM_BITS, c.mask0 >= 511u, i); break;
+      case C_MATCH: L.ctx[i] = L.nctx++; L.state[i] = L.nstate; L.nstate += 8; light_unit(K_MATCH, K_CM_BITS, false, i); break;
       case C_ICM: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = 2; L.icm.push_back(i); break;
       case C_ISSE: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = std::max(2, L.level[c.a2] + 1); L.isse.push_back(i); break;
-      case C_AVG: lv = std::max(L.level[c.a1], L.level[c.a2]) + 1; L.light.push_back({K_AVG, i}); break;
-      case C_MIX2: L.ctx[i] = L.nctx++; lv = std::max(L.level[c.a2], L.level[c.a3]) + 1; L.light.push_back({K_MIX2, i}); break;
-      case C_SSE: L.ctx[i] = L.nctx++; lv = L.level[c.a2] + 1; L.light.push_back({K_SSE, i}); break;
+      case C_AVG: lv = std::max(L.level[c.a1], L.level[c.a2]) + 1; light_unit(K_AVG, K_CM_BITS, false, i); break;
+      case C_MIX2: L.ctx[i] = L.nctx++; lv = std::max(L.level[c.a2], L.level[c.a3]) + 1;
+        light_unit(K_MIX2, K_MIX2_BITS, c.a5 == 255u && c.mask0 >= 255u, i); break;
+      case C_SSE: L.ctx[i] = L.nctx++; lv = L.level[c.a2] + 1; light_unit(K_SSE, K_SSE_BITS, c.mask0 >= 32u * 256u - 1u, i); break;
       case C_MIX: {
         if (c.a3 > 64) { why_not = "MIX with more than 64 inputs"; return false; }
         L.ctx[i] = L.nctx++;
@@ -311,7 +320,7 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   if (want_mix_bits && mix_bits_ok && !L.mix.empty()) { L.mix_bits = 1; L.mix_split = 1; }
   // ROW units (level 1) have a kernel of their own; the light kernel: the components in COMP order, then the coder
   for (int i = 0; i < n; ++i) if (L.row[i] >= 0) L.rows.push_back(i);
-  L.light.push_back({K_CODER, n - 1});
+  light_unit(K_CODER, K_CM_BITS, false, n - 1);
   L.coder_level = L.level[n - 1] + 1;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 16) L.slack = v; }
   L.S = L.coder_level + 1 + L.slack;
@@ -408,6 +417,8 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
     << ", NMIXR = " << L.mix.size() << ";\n";
   arr("LIGHT_KIND", lk.data(), (int)lk.size());
   arr("LIGHT_COMP", lc.data(), (int)lc.size());
+  arr("LIGHT_SUB", L.light_sub.data(), (int)L.light_sub.size());
+  o << "  static constexpr int LIGHT_DEPTH = " << L.light_depth << ";\n";
   arr("ROW_COMP", L.rows.data(), (int)L.rows.size());
   arr("ICM_COMP", L.icm.data(), (int)L.icm.size());
   arr("ISSE_COMP", L.isse.data(), (int)L.isse.size());

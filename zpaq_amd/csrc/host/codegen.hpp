@@ -33,6 +33,7 @@ struct PipeLayout {
   bool hcomp_h_lds = false;    // H staged in LDS
   std::vector<std::pair<int, int>> light;   // (PipeKind, component): CONS, CM, MATCH, AVG, MIX2, SSE units and the coder
   std::vector<int> rows, icm, isse, mix, mix_ql;
+  std::vector<int> light_sub;  // per light unit: which eighth of the group's blocks (units with a lane per bit position), else 0
   uint64_t off_ctx = 0, off_bh = 0, off_p = 0, off_state = 0, group_bytes = 0;
   // kernel-level dataflow (0 hcomp, 1 rows, 2 light, 3 icm, 4 isse, 5 mix): consumes[c][p] = some unit of kernel c reads a
   // stream some unit of kernel p writes; slack = ring slots beyond the minimum, i.e. how many steps a producer kernel
@@ -45,6 +46,10 @@ struct PipeLayout {
   // emulator-exact, not yet measured on the MI355X)
   int mix_bits = 0;
   int mix_depth = 3;           // bytes a bit-lane MIX fetches ahead (ZPAQ_AMD_PIPE_MIX_DEPTH, 1..4)
+  // CM / MIX2 / SSE with a lane per (block, bit position): 8 workgroups per group and unit (ZPAQ_AMD_PIPE_LIGHT_BITS=7; off
+  // by default: emulator-exact, not yet measured on the MI355X)
+  int light_bits = 0;          // 1 CM | 2 MIX2 | 4 SSE
+  int light_depth = 3;         // bytes such a unit fetches ahead (ZPAQ_AMD_PIPE_LIGHT_DEPTH, 1..4)
   int mix_waves_of(int ql) const { return mix_bits ? G * ql / 8 : ql * mix_split; }       // wavefronts per group of one MIX
   int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += mix_waves_of(q); return s; }
   int mix_threads() const { return mix_bits ? 64 : G; }                                   // workgroup size of the mix kernel
