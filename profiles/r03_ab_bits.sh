@@ -5,6 +5,7 @@
 # Knobs (host/codegen.cpp, part of the generated source and therefore of the cache key; unseen variants go through hipRTC):
 #   ZPAQ_AMD_PIPE_MIX_BITS=1     MIX with a lane per (block, bit position, weight quad)   ZPAQ_AMD_PIPE_MIX_DEPTH=1..4 (3)
 #   ZPAQ_AMD_PIPE_LIGHT_BITS=m   1 CM | 2 MIX2 | 4 SSE with a lane per (block, bit position)   ZPAQ_AMD_PIPE_LIGHT_DEPTH=1..4 (3)
+#   ZPAQ_AMD_PIPE_ROW_NIBBLES=1  ROW units with a lane per (block, nibble)                  ZPAQ_AMD_PIPE_ROW_DEPTH=1..4 (2)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r03ab
 mkdir -p $O
@@ -12,7 +13,7 @@ cd $R
 export ZPAQ_AMD_MAX_JIT=256
 PAR="tests/test_gpu_parity.py -m gpu -q -x -k 'golden or nine or legacy or large or records or mixed or ragged or zeros'"
 echo "== parity with every bit-lane unit on" | tee $O/summary.txt
-ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 timeout 1200 bash -c "python -m pytest $PAR" > $O/parity_bits.txt 2>&1
+ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1 timeout 1200 bash -c "python -m pytest $PAR" > $O/parity_bits.txt 2>&1
 tail -3 $O/parity_bits.txt | tee -a $O/summary.txt
 BENCH="python bench.py --cpu-seconds 0 --api-blocks 0 --steps 1 --warmup 1"
 run() {   # name, env...
@@ -30,15 +31,17 @@ PY
 }
 run default
 for d in 1 2 3 4; do run mix_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d; done
+for d in 1 2 3; do run rows_d$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=$d; done
 run light_cm ZPAQ_AMD_PIPE_LIGHT_BITS=1
 run light_mix2 ZPAQ_AMD_PIPE_LIGHT_BITS=2
 run light_sse ZPAQ_AMD_PIPE_LIGHT_BITS=4
 run light_all ZPAQ_AMD_PIPE_LIGHT_BITS=7
-for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d; done
+run mix_rows ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
+for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1; done
 # per-kernel durations of the best candidate and of the default, for the timeline
 cd /tmp && export TMPDIR=/tmp
 for v in default all; do
-  E=""; [ $v = all ] && E="ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7"
+  E=""; [ $v = all ] && E="ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1"
   env $E timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$v -o p -- python $R/bench.py --cpu-seconds 0 --api-blocks 0 --verify-blocks 0 --warmup 0 --steps 1 > $O/prof_$v.log 2>&1
   python $R/profiles/pipe_timeline.py $O/prof_$v/p_results.db > $O/timeline_$v.txt 2>&1
   rm -f $O/prof_$v/*.db

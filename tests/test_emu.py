@@ -256,3 +256,38 @@ def test_pipe_encoder_light_bit_lanes(zlib_, oracle, golden):
              corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
     for depth in (2, 4):
         _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, light_bits=7, light_depth=depth, mix_bits=1, mix_depth=depth)
+
+
+def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
+    """ZPAQ_AMD_PIPE_ROW_NIBBLES=1: the ROW units with a lane per (block, nibble), candidate rows fetched ROW_DEPTH bytes
+    ahead (pipe_kernel.h::pipe_row_nibbles) -- alone and with every other experimental unit on.  The stress chain's hash
+    tables of 2 and 4 lines make the two nibbles of a byte share a line (second pass) and nearly every fetch stale; zeros
+    and the repeated patterns keep the context constant (fetch-again path on every byte)."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    assert "ROW_NIBBLES = 1, ROW_DEPTH = 3" in emu.pipe_source(h5, 64, row_nibbles=1, row_depth=3)
+    for depth in (1, 2, 3, 4):
+        _pipe_check(oracle, h5, ragged + [b""], chunk=64, row_nibbles=1, row_depth=depth)
+    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7)
+    _pipe_check(oracle, h5, ragged, chunk=64, **everything)
+    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, row_nibbles=1, row_depth=2)
+    seen = set()
+    for e in [golden["config_cases"][0]] + golden["level_cases"]:
+        header = bytes.fromhex(e["header"])
+        if header in seen or not header[6] or header[6] > 64:
+            continue
+        seen.add(header)
+        d = gen_input(e).tobytes()
+        if len(d) < 64:
+            d = corpus.block("records", 600, 3).tobytes()
+        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, **everything)
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
+             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
+    for depth in (1, 3):
+        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, row_nibbles=1, row_depth=depth)
+    _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, **everything)

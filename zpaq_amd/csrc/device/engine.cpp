@@ -374,6 +374,7 @@ struct PipeRun {
   uint32_t ngroups;
   uint32_t threads;          // lanes per workgroup of every kernel but hcomp and mix (= blocks per group)
   uint32_t mix_threads;      // ... of the mix kernel (= threads unless its lanes are per bit position)
+  uint32_t rows_threads;     // ... of the rows kernel (= threads unless its lanes are per nibble)
   bool consumes[6][6];
   int slack;
 };
@@ -396,7 +397,7 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
           HIP_CHECK(hipEventCreate(&rec.a));
           HIP_CHECK(hipEventCreate(&rec.b));
           HIP_CHECK(hipEventRecord(rec.a, st));
-          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : r.threads), 1, 1, 0, st, args, nullptr));
+          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads)), 1, 1, 0, st, args, nullptr));
           HIP_CHECK(hipEventRecord(rec.b, st));
           recs.push_back(rec);
         }
@@ -491,11 +492,11 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
             a2.wg0 = w0;
             void* args2[1] = {(void*)&a2};
             hipStream_t su = split_stream(e, (size_t)k * 64 + ui, e.pstream[k]);
-            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, k == 5 ? r.mix_threads : r.threads, 1, 1, 0, su, args2, nullptr));
+            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads), 1, 1, 0, su, args2, nullptr));
           }
           continue;
         }
-        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : r.threads), 1, 1, 0, e.pstream[k], args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads)), 1, 1, 0, e.pstream[k], args, nullptr));
       }
       if (split) split_join(e);
       HIP_CHECK(hipEventRecord(*ev[k][step % R], e.pstream[k]));
@@ -539,6 +540,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.ngroups = ng;
     r.threads = (uint32_t)L.G;
     r.mix_threads = (uint32_t)L.mix_threads();
+    r.rows_threads = (uint32_t)L.rows_threads();
     memcpy(r.consumes, L.consumes, sizeof(r.consumes));
     r.slack = L.slack;
     r.grid[0] = (g.count + (uint32_t)L.hcomp_lanes - 1) / (uint32_t)L.hcomp_lanes;

@@ -368,6 +368,82 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
   }
 }
 
+// ROW unit with a lane per (block, NIBBLE) (ZPAQ_AMD_PIPE_ROW_NIBBLES).  Both rows of a byte are known when the byte
+// starts -- the second one's context is the first's plus the high nibble, which the encoder has -- so two lanes do the two
+// finds and the 2 x 4 bit-history steps side by side: a wavefront of 64 lanes serves 32 blocks with ~100 instructions per
+// byte where the one-lane unit needs ~600 for the same 32 blocks.  Candidates are fetched ROW_DEPTH bytes ahead; a lane
+// knows every line its block wrote since (it can compute the partner's addresses itself), and fetches its three
+// candidates again when one of them is its own line.  The rare second nibble that shares a line with its byte's first
+// nibble (tiny tables) runs in a second pass, after the first nibble's store.
+template <class Chain, int I, class NS>
+__device__ __forceinline__ void pipe_row_nibbles(PipeLane<Chain>& L, unsigned nib, const NS& ns) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
+  constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I], D = Chain::ROW_DEPTH;
+  if (!L.nb) return;
+  const unsigned last = L.nb - 1u;
+  // context of a nibble's row: c8 = 1 for the first, 16 + the high nibble for the second
+  auto cx_of = [&](unsigned hh, unsigned bytev, unsigned which) __attribute__((always_inline)) -> unsigned {
+    return hh + (which ? 16u * (16u + (bytev >> 4)) : 16u);
+  };
+  auto row_of = [&](unsigned cx) __attribute__((always_inline)) -> unsigned { return (cx * 16u) & (rmask - 15u); };
+  unsigned hq[D], bq[D];                       // context and input byte of the D bytes after the window
+  unsigned cxq[D], rq[D], oq[D], nq[D];        // window: own context, own first candidate, the partner's line, the nibble
+  uint4 c0[D], c1[D], c2[D];                   // the three candidates as fetched
+  unsigned hl0[D], hl1[D];                     // lines the block wrote for the last D bytes (first / second nibble)
+  auto fill = [&](int j, unsigned hv, unsigned bv) __attribute__((always_inline)) {
+    const unsigned cx = cx_of(hv, bv, nib);
+    cxq[j] = cx;
+    rq[j] = row_of(cx);
+    oq[j] = row_of(cx_of(hv, bv, 1u - nib)) & ~63u;
+    nq[j] = nib ? (bv & 15u) : (bv >> 4);
+    c0[j] = L.A128(ht + rq[j]); c1[j] = L.A128(ht + (rq[j] ^ 16u)); c2[j] = L.A128(ht + (rq[j] ^ 32u));
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
+    fill(j, L.ctx(ci, kk), L.byte_at(kk));
+    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+    hl0[j] = 0xFFFFFFFFu; hl1[j] = 0xFFFFFFFFu;
+  }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const unsigned k = kb + (unsigned)j;
+      const bool on = k < L.nb;
+      const unsigned line = rq[j] & ~63u, pline = oq[j];
+      bool stale = false;
+#pragma unroll
+      for (int i = 0; i < D; ++i) stale = stale || line == hl0[i] || line == hl1[i];
+      const bool defer = nib != 0u && line == pline;              // this byte's first nibble rewrites the line first
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !pipe_any(on && defer)) break;
+        const bool mine = on && (defer == (pass == 1));
+        const bool again = mine && (stale || pass == 1);
+        if (pipe_any(again)) {
+          pipe_stores_done();
+          if (again) { c0[j] = L.A128(ht + rq[j]); c1[j] = L.A128(ht + (rq[j] ^ 16u)); c2[j] = L.A128(ht + (rq[j] ^ 32u)); }
+        }
+        if (mine) {
+          PipeRow r = pipe_find(c0[j], c1[j], c2[j], (cxq[j] >> sizebits) & 255u, rq[j]);
+          const unsigned o = pipe_row_bits(r, nq[j], ns);
+          L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
+          *(g_u32*)((g_u8*)&L.bh(ri, k) + 4u * nib) = o;
+        }
+      }
+#pragma unroll
+      for (int i = D - 1; i > 0; --i) { hl0[i] = hl0[i - 1]; hl1[i] = hl1[i - 1]; }
+      hl0[0] = nib ? pline : line;
+      hl1[0] = nib ? line : pline;
+      {
+        const unsigned k2 = min(k + 2u * (unsigned)D, last);
+        fill(j, hq[j], bq[j]);
+        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+      }
+    }
+  }
+}
+
 // CONS: a constant stream, so that consumers need no special case
 template <class Chain, int I>
 __device__ __forceinline__ void pipe_cons(PipeLane<Chain>& L) {
@@ -981,6 +1057,13 @@ __device__ __forceinline__ void pipe_rows_body(const PipeArgs& a) {
     constexpr int r = decltype(rc)::value;
     if (role != (unsigned)r) return;
     PipeLane<Chain> L;
+    if constexpr (Chain::ROW_NIBBLES != 0) {
+      // workgroup = 2 x PIPE_G lanes: lane = (block, nibble)
+      L.open(a, g * Chain::PIPE_G + ((unsigned)lane >> 1), 1);
+      if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
+      pipe_row_nibbles<Chain, Chain::ROW_COMP[r]>(L, (unsigned)lane & 1u, ns);
+      return;
+    }
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, 1);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     pipe_row<Chain, Chain::ROW_COMP[r]>(L, ns);

@@ -50,6 +50,11 @@ struct PipeLayout {
   // by default: emulator-exact, not yet measured on the MI355X)
   int light_bits = 0;          // 1 CM | 2 MIX2 | 4 SSE
   int light_depth = 3;         // bytes such a unit fetches ahead (ZPAQ_AMD_PIPE_LIGHT_DEPTH, 1..4)
+  // ROW units with a lane per (block, nibble): workgroups of 2 x G lanes (ZPAQ_AMD_PIPE_ROW_NIBBLES=1, G <= 32; off by default:
+  // emulator-exact, not yet measured on the MI355X)
+  int row_nibbles = 0;
+  int row_depth = 2;           // bytes such a unit fetches its candidate rows ahead (ZPAQ_AMD_PIPE_ROW_DEPTH, 1..4)
+  int rows_threads() const { return row_nibbles ? 2 * G : G; }                            // workgroup size of the rows kernel
   int mix_waves_of(int ql) const { return mix_bits ? G * ql / 8 : ql * mix_split; }       // wavefronts per group of one MIX
   int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += mix_waves_of(q); return s; }
   int mix_threads() const { return mix_bits ? 64 : G; }                                   // workgroup size of the mix kernel
