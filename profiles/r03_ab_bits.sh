@@ -47,3 +47,12 @@ for v in default all; do
   rm -f $O/prof_$v/*.db
   echo "== timeline $v"; head -12 $O/timeline_$v.txt
 done | tee -a $O/summary.txt
+# where every wavefront of a step ran and for how long (kernels built -DZPQ_TRACE; records -> profiles/pipe_trace.py)
+cd $R
+for v in default all; do
+  E=""; [ $v = all ] && E="ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1"
+  env $E ZPAQ_AMD_SPEC_DEFS=-DZPQ_TRACE ZPAQ_AMD_PIPE_TRACE=$O/trace_$v.bin timeout 600 python bench.py --blocks 1024 --block-bytes 65536 \
+      --cpu-seconds 0 --api-blocks 0 --verify-blocks 0 --warmup 0 --steps 1 > $O/trace_$v.json 2> $O/trace_$v.err
+  echo "== placement $v"; python profiles/pipe_trace.py $O/trace_$v.bin 2>&1 | head -24
+  rm -f $O/trace_$v.bin
+done | tee -a $O/summary.txt

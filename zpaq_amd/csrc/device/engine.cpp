@@ -466,6 +466,24 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
   }
   bool used[6] = {};
   for (auto& r : runs) for (int k = 0; k < 6; ++k) used[k] = used[k] || r.grid[k] != 0;
+  // ZPAQ_AMD_PIPE_TRACE=<file> (with kernels built -DZPQ_TRACE, e.g. ZPAQ_AMD_SPEC_DEFS=-DZPQ_TRACE): one record of four
+  // 64-bit words per workgroup and launch -- [kernel << 56 | step << 32 | workgroup], [XCC_ID << 32 | HW_ID], entry and exit
+  // on the 100 MHz reference clock -- written to the file when the sequence has finished (profiles/pipe_trace.py)
+  const char* trace_path = getenv("ZPAQ_AMD_PIPE_TRACE");
+  unsigned long long* d_trace = nullptr;
+  uint64_t trace_records = 0;
+  std::vector<uint64_t> trace_run_base;                  // first record of each run
+  if (trace_path && trace_path[0]) {
+    for (auto& r : runs) {
+      trace_run_base.push_back(trace_records);
+      uint64_t per_step = 0;
+      for (int k = 0; k < 6; ++k) per_step += r.grid[k];
+      trace_records += per_step * r.nsteps;
+    }
+    if (trace_records >= (1ull << 32)) fail(ZPQ_E_ARG, "ZPAQ_AMD_PIPE_TRACE: too many launches for one trace");
+    HIP_CHECK(hipMalloc((void**)&d_trace, trace_records * 32));
+    HIP_CHECK(hipMemset(d_trace, 0, trace_records * 32));
+  }
   const int R = slack + 2;                               // events kept per kernel
   std::vector<std::unique_ptr<Event>> ev[6];
   for (int k = 0; k < 6; ++k) for (int i = 0; i < R; ++i) ev[k].emplace_back(new Event());
@@ -483,6 +501,12 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
       for (auto& r : runs) {
         if (step >= r.nsteps || !r.grid[k]) continue;
         r.args.step = (int32_t)step;
+        if (d_trace) {
+          uint64_t per_step = 0, before = 0;
+          for (int q = 0; q < 6; ++q) { if (q < k) before += r.grid[q]; per_step += r.grid[q]; }
+          r.args.trace = d_trace;
+          r.args.trace_base = (uint32_t)(trace_run_base[(size_t)(&r - &runs[0])] + per_step * step + before);
+        }
         void* args[1] = {(void*)&r.args};
         if (split && k != 0) {
           // ZPAQ_AMD_PIPE_SPLIT=1 (profiling aid): one launch per unit type, on streams of their own, so that a kernel
@@ -504,6 +528,17 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
   }
   for (int k = 0; k < 6; ++k)
     if (used[k] && nsteps) HIP_CHECK(hipStreamWaitEvent(st, *ev[k][(nsteps - 1) % R], 0));
+  if (d_trace) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> host(trace_records * 4);
+    HIP_CHECK(hipMemcpy(host.data(), d_trace, trace_records * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d_trace);
+    if (FILE* f = fopen(trace_path, "wb")) {
+      fwrite(host.data(), 32, trace_records, f);
+      fclose(f);
+      fprintf(stderr, "[zpq pipe trace] %llu records -> %s\n", (unsigned long long)trace_records, trace_path);
+    }
+  }
 }
 
 // Launch init + coding kernels for jobs already resident on the device, grouped

@@ -139,6 +139,11 @@ struct PipeArgs {
   uint8_t* pipe;            // stream + state buffer, PIPE_GROUP_BYTES per group
   int32_t step;             // a unit of dataflow level L works on chunk step - L
   uint32_t wg0;             // added to blockIdx.x: lets a launch cover a sub-range of a kernel's units
+  // Placement / timing trace (kernels built with -DZPQ_TRACE, engine run with ZPAQ_AMD_PIPE_TRACE=<file>): four 64-bit
+  // words per workgroup and launch, record index = trace_base + blockIdx.x; null otherwise
+  unsigned long long* trace;
+  uint32_t trace_base;
+  uint32_t reserved;
 };
 
 // LDS plan of the specialised kernel (spec_kernel.h), known to the host code

@@ -60,6 +60,33 @@ namespace zpq {
 typedef __attribute__((address_space(1))) short g_i16;
 typedef __attribute__((address_space(1))) unsigned short g_u16;
 
+// -DZPQ_TRACE: every workgroup of every launch records where it ran (HW_ID: SE / CU / SIMD / wave slot, XCC_ID) and when
+// (the 100 MHz reference clock at entry and at exit) -- profiles/pipe_trace.py turns the records into the occupancy of
+// every SIMD over a step.  Compiled out otherwise (the kernels' ISA is the same as without this block).
+#ifdef ZPQ_TRACE
+struct PipeTraceScope {
+  unsigned long long* rec;
+  __device__ __forceinline__ PipeTraceScope(const PipeArgs& a, int kernel) : rec(nullptr) {
+    if (a.trace && threadIdx.x == 0) {
+      rec = a.trace + 4ull * ((unsigned long long)a.trace_base + blockIdx.x);
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      rec[0] = ((unsigned long long)(unsigned)kernel << 56) | ((unsigned long long)((unsigned)a.step & 0xFFFFFFu) << 32) |
+               (unsigned long long)(blockIdx.x + a.wg0);
+      rec[1] = ((unsigned long long)xcc << 32) | hw;
+      rec[2] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  __device__ __forceinline__ ~PipeTraceScope() {
+    if (rec) rec[3] = __builtin_amdgcn_s_memrealtime();
+  }
+};
+#define ZPQ_PIPE_TRACE(a, k) zpq::PipeTraceScope zpq_trace_scope(a, k)
+#else
+#define ZPQ_PIPE_TRACE(a, k)
+#endif
+
 enum PipeKind : int { PK_ROW = 1, PK_CONS, PK_CM, PK_MATCH, PK_AVG, PK_MIX2, PK_SSE, PK_CODER,
                       PK_CM_BITS, PK_MIX2_BITS, PK_SSE_BITS };      // ..._BITS: a lane per (block, bit position), 8 workgroups per group
 

@@ -432,9 +432,10 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   o << "};\n"
        "}  // namespace zpq_gen\n";
   const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
-  for (const char* nm : names)
-    o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << nm << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp: 64)
-         "  zpq::pipe_" << nm << "_body<zpq_gen::Chain>(a);\n}\n";
+  for (int k = 0; k < 6; ++k)
+    o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << names[k] << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp: 64)
+         "  ZPQ_PIPE_TRACE(a, " << k << ");\n"
+         "  zpq::pipe_" << names[k] << "_body<zpq_gen::Chain>(a);\n}\n";
   source = o.str();
   return true;
 }
