@@ -94,7 +94,7 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * [3] units in the light kernel, [4] ICM maps, [5] ISSE maps, [6] MIX wavefronts per group, [7] blocks per HCOMP
  * workgroup, [8] highest dataflow level (a batch of L-byte blocks takes ceil(L / chunk) + out[8] steps),
  * [9] blocks per group (= threads per workgroup of every kernel but hcomp, which has 64), [10] ROW units,
- * [11] threads per workgroup of the mix kernel, [12] of the rows kernel. */
+ * [11] threads per workgroup of the mix kernel, [12] of the rows kernel, [13] of the light kernel. */
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
 /* The same for a block's PCOMP post-processing program (device/pcomp_kernel.h: LZ77 / BWT / E8E9 inverses run one

@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
   const uint64_t group_bytes = lay[0];
   const unsigned C = (unsigned)lay[2], nlight = (unsigned)lay[3], nicm = (unsigned)lay[4], nisse = (unsigned)lay[5],
                  mixw = (unsigned)lay[6], hl = (unsigned)lay[7], maxlevel = (unsigned)lay[8], G = (unsigned)lay[9], nrows = (unsigned)lay[10],
-                 mixt = (unsigned)lay[11], rowt = (unsigned)lay[12];
+                 mixt = (unsigned)lay[11], rowt = (unsigned)lay[12], lightt = (unsigned)lay[13];
 
   static zpq::DeviceTables tb;
   int32_t dt2k[256];
@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     Launch l{0, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, (int)step, 0u}};
     for (int which = 5; which >= 0; --which) {
       l.which = which;
-      for (unsigned wg = grids[which]; wg-- > 0;) emu::run_workgroup(kernel_thunk, &l, which == 0 ? 64 : (which == 5 ? mixt : (which == 1 ? rowt : G)), wg);
+      for (unsigned wg = grids[which]; wg-- > 0;) emu::run_workgroup(kernel_thunk, &l, which == 0 ? 64 : (which == 5 ? mixt : (which == 1 ? rowt : (which == 2 ? lightt : G))), wg);
     }
   }
   for (unsigned b = 0; b < nb; ++b) {

@@ -224,7 +224,7 @@ def test_pipe_encoder_mix_bit_lanes(zlib_, oracle, golden):
 
 
 def test_pipe_encoder_light_bit_lanes(zlib_, oracle, golden):
-    """ZPAQ_AMD_PIPE_LIGHT_BITS=7 (1 CM | 2 MIX2 | 4 SSE): CM, MIX2 and SSE with a lane per (block, bit position), 8 workgroups per group and
+    """ZPAQ_AMD_PIPE_LIGHT_BITS=7 (1 CM | 2 MIX2 | 4 SSE): CM, MIX2 and SSE with a lane per (block, bit position), workgroups of 8 blocks x 8 positions,
     unit, table words fetched LIGHT_DEPTH bytes ahead (pipe_kernel.h::pipe_cm_bits / pipe_mix2_bits / pipe_sse_bits) --
     alone and together with the bit-lane MIX, on the -m5 chain, the legacy models and the stress chain whose tiny tables
     make words of different contexts collide."""
@@ -233,7 +233,7 @@ def test_pipe_encoder_light_bit_lanes(zlib_, oracle, golden):
     kinds = ["text", "lcg", "zeros", "records", "pattern"]
     ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
     src = emu.pipe_source(h5, 64, None, None, None, None, 7, 2)
-    assert "NLIGHT = 27" in src and "LIGHT_DEPTH = 2" in src           # CM, MIX2 (20) and SSE as 8 workgroups each
+    assert "NLIGHT = 15" in src and "LIGHT_DEPTH = 2" in src           # CM, MIX2 (20) and SSE as 4 workgroups of 64 lanes each
     for depth in (1, 4):
         _pipe_check(oracle, h5, ragged + [b""], chunk=64, light_bits=7, light_depth=depth)
     _pipe_check(oracle, h5, ragged, chunk=64, light_bits=7, light_depth=3, mix_bits=1, mix_depth=3)

@@ -143,7 +143,7 @@ int zpq_plan_pipe_layout(const zpq_plan* p, uint64_t out[16]) {
   out[0] = L.group_bytes; out[1] = (uint64_t)L.S; out[2] = (uint64_t)L.C; out[3] = L.light.size();
   out[4] = L.icm.size(); out[5] = L.isse.size(); out[6] = (uint64_t)L.mix_waves_per_group();
   out[7] = (uint64_t)L.hcomp_lanes; out[8] = (uint64_t)L.coder_level; out[9] = (uint64_t)L.G; out[10] = L.rows.size();
-  out[11] = (uint64_t)L.mix_threads(); out[12] = (uint64_t)L.rows_threads();
+  out[11] = (uint64_t)L.mix_threads(); out[12] = (uint64_t)L.rows_threads(); out[13] = (uint64_t)L.light_threads();
   return ZPQ_OK;
   ZPQ_CATCH
 }

@@ -375,6 +375,7 @@ struct PipeRun {
   uint32_t threads;          // lanes per workgroup of every kernel but hcomp and mix (= blocks per group)
   uint32_t mix_threads;      // ... of the mix kernel (= threads unless its lanes are per bit position)
   uint32_t rows_threads;     // ... of the rows kernel (= threads unless its lanes are per nibble)
+  uint32_t light_threads;    // ... of the light kernel (= threads unless some of its units have a lane per bit position)
   bool consumes[6][6];
   int slack;
 };
@@ -397,7 +398,7 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
           HIP_CHECK(hipEventCreate(&rec.a));
           HIP_CHECK(hipEventCreate(&rec.b));
           HIP_CHECK(hipEventRecord(rec.a, st));
-          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads)), 1, 1, 0, st, args, nullptr));
+          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads))), 1, 1, 0, st, args, nullptr));
           HIP_CHECK(hipEventRecord(rec.b, st));
           recs.push_back(rec);
         }
@@ -516,11 +517,11 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
             a2.wg0 = w0;
             void* args2[1] = {(void*)&a2};
             hipStream_t su = split_stream(e, (size_t)k * 64 + ui, e.pstream[k]);
-            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads), 1, 1, 0, su, args2, nullptr));
+            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads)), 1, 1, 0, su, args2, nullptr));
           }
           continue;
         }
-        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : r.threads)), 1, 1, 0, e.pstream[k], args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads))), 1, 1, 0, e.pstream[k], args, nullptr));
       }
       if (split) split_join(e);
       HIP_CHECK(hipEventRecord(*ev[k][step % R], e.pstream[k]));
@@ -576,6 +577,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.threads = (uint32_t)L.G;
     r.mix_threads = (uint32_t)L.mix_threads();
     r.rows_threads = (uint32_t)L.rows_threads();
+    r.light_threads = (uint32_t)L.light_threads();
     memcpy(r.consumes, L.consumes, sizeof(r.consumes));
     r.slack = L.slack;
     r.grid[0] = (g.count + (uint32_t)L.hcomp_lanes - 1) / (uint32_t)L.hcomp_lanes;

@@ -787,7 +787,7 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
 // Same idea as pipe_mix_bits_body: the table word a bit uses is indexed by the bit's position in the byte (hmap4 / c8
 // are part of the index) and training touches that word only, so with all bits known the 8 bits of a byte are
 // independent.  8 lanes per block, the 8 positions of a block in ONE wavefront (a workgroup = PIPE_G lanes = PIPE_G / 8
-// blocks; a unit = 8 workgroups per group), table words / inputs / contexts fetched LIGHT_DEPTH bytes ahead, a word
+// blocks; a unit = several workgroups per group), table words / inputs / contexts fetched LIGHT_DEPTH bytes ahead, a word
 // rewritten since its fetch taken from the lane's own history (same context) or fetched again (contexts close enough
 // for DIFFERENT positions to meet).
 template <int D>
@@ -1116,8 +1116,8 @@ __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
     constexpr int level = kind == PK_CODER ? Chain::CODER_LEVEL : Chain::P_LEVEL[I];
     PipeLane<Chain> L;
     if constexpr (kind >= PK_CM_BITS) {
-      // workgroup LIGHT_SUB[r] of the unit's 8: PIPE_G / 8 blocks, lane = (block, bit position)
-      constexpr unsigned BPW = Chain::PIPE_G / 8u;
+      // workgroup LIGHT_SUB[r] of the unit's: LIGHT_THREADS / 8 blocks, lane = (block, bit position)
+      constexpr unsigned BPW = (unsigned)Chain::LIGHT_THREADS / 8u;
       L.open(a, g * Chain::PIPE_G + (unsigned)Chain::LIGHT_SUB[r] * BPW + ((unsigned)lane >> 3), level);
       if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
       const unsigned B = (unsigned)lane & 7u;
@@ -1139,6 +1139,10 @@ __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
       return;
     }
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, level);
+    if constexpr ((unsigned)Chain::LIGHT_THREADS > Chain::PIPE_G) {
+      // (workgroups sized for the bit-lane units: a lane-per-block unit uses the first PIPE_G lanes)
+      if ((unsigned)lane >= Chain::PIPE_G) { L.live = false; L.nb = 0; L.len = 0; }
+    }
     if (L.chunk < 0) return;
     if constexpr (kind != PK_CODER) { if (!pipe_any(L.nb > 0)) return; }
     if constexpr (kind == PK_CONS) {

@@ -282,7 +282,7 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   enum { K_CM_BITS = 9, K_MIX2_BITS, K_SSE_BITS };
   // a light unit: one workgroup per group, or -- a lane per bit position -- eight
   auto light_unit = [&](int kind, int bits_kind, bool bits_ok, int i) {
-    if (bits_ok && (L.light_bits >> (bits_kind - K_CM_BITS) & 1)) { for (int sub = 0; sub < 8; ++sub) { L.light.push_back({bits_kind, i}); L.light_sub.push_back(sub); } }
+    if (bits_ok && (L.light_bits >> (bits_kind - K_CM_BITS) & 1)) { for (int sub = 0; sub < L.G * 8 / L.light_threads(); ++sub) { L.light.push_back({bits_kind, i}); L.light_sub.push_back(sub); } }
     else { L.light.push_back({kind, i}); L.light_sub.push_back(0); }
   };
   for (int i = 0; i < n; ++i) {
@@ -420,6 +420,7 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   arr("LIGHT_KIND", lk.data(), (int)lk.size());
   arr("LIGHT_COMP", lc.data(), (int)lc.size());
   arr("LIGHT_SUB", L.light_sub.data(), (int)L.light_sub.size());
+  o << "  static constexpr int LIGHT_THREADS = " << L.light_threads() << ";\n";
   o << "  static constexpr int LIGHT_DEPTH = " << L.light_depth << ", ROW_NIBBLES = " << L.row_nibbles << ", ROW_DEPTH = " << L.row_depth << ";\n";
   arr("ROW_COMP", L.rows.data(), (int)L.rows.size());
   arr("ICM_COMP", L.icm.data(), (int)L.icm.size());

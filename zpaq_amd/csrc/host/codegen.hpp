@@ -46,7 +46,7 @@ struct PipeLayout {
   // emulator-exact, not yet measured on the MI355X)
   int mix_bits = 0;
   int mix_depth = 3;           // bytes a bit-lane MIX fetches ahead (ZPAQ_AMD_PIPE_MIX_DEPTH, 1..4)
-  // CM / MIX2 / SSE with a lane per (block, bit position): 8 workgroups per group and unit (ZPAQ_AMD_PIPE_LIGHT_BITS=7; off
+  // CM / MIX2 / SSE with a lane per (block, bit position): workgroups of 64 lanes = 8 blocks, G / 8 of them per group and unit (ZPAQ_AMD_PIPE_LIGHT_BITS=7; off
   // by default: emulator-exact, not yet measured on the MI355X)
   int light_bits = 0;          // 1 CM | 2 MIX2 | 4 SSE
   int light_depth = 3;         // bytes such a unit fetches ahead (ZPAQ_AMD_PIPE_LIGHT_DEPTH, 1..4)
@@ -54,6 +54,7 @@ struct PipeLayout {
   // emulator-exact, not yet measured on the MI355X)
   int row_nibbles = 0;
   int row_depth = 2;           // bytes such a unit fetches its candidate rows ahead (ZPAQ_AMD_PIPE_ROW_DEPTH, 1..4)
+  int light_threads() const { return light_bits ? 64 : G; }                               // workgroup size of the light kernel
   int rows_threads() const { return row_nibbles ? 2 * G : G; }                            // workgroup size of the rows kernel
   int mix_waves_of(int ql) const { return mix_bits ? G * ql / 8 : ql * mix_split; }       // wavefronts per group of one MIX
   int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += mix_waves_of(q); return s; }
