@@ -671,7 +671,7 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
     last = p;
     if (!p->hdr().wave_ok) continue;
     const auto& d = p->cur();
-    if (pipe ? d.pipe_state != 0 || d.spec_state[variant] > 0 : d.spec_state[variant] != 0) continue;   // loaded, or known not to work
+    if (pipe ? d.pipe_state != 0 : d.spec_state[variant] != 0) continue;        // loaded, or known not to work
     if (std::find(unseen.begin(), unseen.end(), p) == unseen.end()) unseen.push_back(p);
   }
   if (unseen.size() < 2) return;            // a single header is compiled where it is loaded
