@@ -1,7 +1,9 @@
 """CPU, world_size 2, gloo: the N > 1 path of the framework -- block sharding, scatter of the
-corpus, gather of variable-length archives in block order, max-over-ranks timing.  The coder is
-replaced by a stand-in (zlib) because there is no GPU here; what is tested is exactly what runs
-between ranks on the 8-GPU node."""
+corpus, gather of variable-length archives in block order, max-over-ranks timing.  Every rank runs the PRODUCT's
+compress_blocks on its shard with method "2" (LZ77 without a context model: that path is host-only, so it works
+without a GPU) and rank 0 checks the gathered archives, in block order, against a single-process run, against a round
+trip and -- when oracle/_ref is built -- against the reference's compressBlock.  What runs between the ranks is exactly
+what runs on the 8-GPU node; there the method is "5" and the coder the device."""
 import os
 import socket
 import subprocess
@@ -25,21 +27,22 @@ def test_shard_range_covers_everything():
 
 
 WORKER = textwrap.dedent("""
-    import os, sys, zlib, time
+    import os, sys, time
     import numpy as np
     import torch.distributed as dist
     sys.path.insert(0, os.environ["ZROOT"])
+    import zpaq_amd as z
     from zpaq_amd import corpus, dist as zd
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    NB, BS = 7, 3000                       # odd count: ranks get different numbers of blocks
+    NB, BS = 7, 30000                      # odd count: ranks get different numbers of blocks
     blocks = corpus.corpus("text", NB, BS) if rank == 0 else None
     mine = zd.scatter_blocks(blocks, NB, BS)
     b, e = zd.shard_range(NB, rank, world)
     assert mine.shape == (e - b, BS)
     ref = corpus.corpus("text", NB, BS)[b:e]
     assert (mine.numpy() == ref).all(), "scatter delivered the wrong slice"
-    archives = [zlib.compress(row.tobytes()) + bytes([rank]) * (i + 1) for i, row in enumerate(mine.numpy())]
+    archives = z.compress_blocks([row for row in mine.numpy()], "2")
     zd.barrier()
     t = zd.max_over_ranks(0.5 + rank)
     assert abs(t - (world - 0.5)) < 1e-9
@@ -47,15 +50,18 @@ WORKER = textwrap.dedent("""
     if rank == 0:
         assert len(got) == NB
         full = corpus.corpus("text", NB, BS)
-        k = 0
-        for r in range(world):
-            rb, re = zd.shard_range(NB, r, world)
-            for i in range(re - rb):
-                a = got[k]
-                tail = i + 1
-                assert a[-tail:] == bytes([r]) * tail
-                assert zlib.decompress(a[:-tail]) == full[k].tobytes(), "archives out of block order"
-                k += 1
+        alone = z.compress_blocks([row for row in full], "2")
+        for k in range(NB):
+            assert got[k] == alone[k], "archives out of block order"
+            assert z.decompress(got[k], BS + 16) == full[k].tobytes()
+        assert len(set(got)) == NB and max(len(a) for a in got) < BS          # distinct blocks, really compressed
+        sys.path.insert(0, os.path.join(os.environ["ZROOT"]))
+        from oracle.oracle_py import Ref, have_ref
+        if have_ref():
+            r = Ref()
+            for k in range(NB):
+                assert got[k] == r.compress_block(full[k].tobytes(), "2"), "not the reference's archive"
+            print("REFERENCE_OK")
         print("RANK0_OK")
     else:
         assert got is None
@@ -78,6 +84,9 @@ def test_two_rank_scatter_gather_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
     assert "RANK0_OK" in outs[0]
+    from oracle.oracle_py import have_ref
+    if have_ref():
+        assert "REFERENCE_OK" in outs[0]
 
 
 def test_torch_corpus_generator_on_cpu():
