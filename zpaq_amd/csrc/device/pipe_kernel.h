@@ -106,6 +106,24 @@ __device__ __forceinline__ void pipe_stores_done() {
 #endif
 }
 
+// A value the compiler must treat as per-lane data.  When all lanes of a wavefront serve one block the compiler proves
+// stream addresses uniform, moves every loaded context into a scalar register with v_readfirstlane right behind the load
+// -- and so waits for a fetch that was issued bytes ahead precisely in order not to be waited for.
+__device__ __forceinline__ unsigned pipe_opaque(unsigned x) {
+#ifndef ZPQ_EMU
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
+// A value fetched on a rarely taken path inside a pipelined loop: consuming it inside the branch keeps the wait for it
+// inside the branch.  (vmcnt counts in order: where the branch joins the main path the compiler would otherwise wait for
+// the branch's fetch -- the youngest -- on every iteration, and with it for every fetch issued ahead.)
+__device__ __forceinline__ uint4 pipe_settle(uint4 v) {
+  v.x = pipe_opaque(v.x); v.y = pipe_opaque(v.y); v.z = pipe_opaque(v.z); v.w = pipe_opaque(v.w);
+  return v;
+}
+
 typedef __attribute__((address_space(1))) uint2 g_u64v;
 
 // One lane's view of its block, its chunk and the group's streams.
@@ -414,46 +432,49 @@ __device__ __forceinline__ void pipe_row_nibbles(PipeLane<Chain>& L, unsigned ni
     return hh + (which ? 16u * (16u + (bytev >> 4)) : 16u);
   };
   auto row_of = [&](unsigned cx) __attribute__((always_inline)) -> unsigned { return (cx * 16u) & (rmask - 15u); };
-  unsigned hq[D], bq[D];                       // context and input byte of the D bytes after the window
-  unsigned cxq[D], rq[D], oq[D], nq[D];        // window: own context, own first candidate, the partner's line, the nibble
-  uint4 c0[D], c1[D], c2[D];                   // the three candidates as fetched
+  // ring of W = 2 D slots (slot = byte index mod W, fixed registers): context and byte fetched W bytes ahead, the three
+  // candidate rows D bytes ahead
+  constexpr int W = 2 * D;
+  unsigned hx[W], bx[W], rq[W];                // context, input byte, own first candidate
+  uint4 c0[W], c1[W], c2[W];                   // the three candidates as fetched
   unsigned hl0[D], hl1[D];                     // lines the block wrote for the last D bytes (first / second nibble)
-  auto fill = [&](int j, unsigned hv, unsigned bv) __attribute__((always_inline)) {
-    const unsigned cx = cx_of(hv, bv, nib);
-    cxq[j] = cx;
-    rq[j] = row_of(cx);
-    oq[j] = row_of(cx_of(hv, bv, 1u - nib)) & ~63u;
-    nq[j] = nib ? (bv & 15u) : (bv >> 4);
-    c0[j] = L.A128(ht + rq[j]); c1[j] = L.A128(ht + (rq[j] ^ 16u)); c2[j] = L.A128(ht + (rq[j] ^ 32u));
+  auto near = [&](int sl) __attribute__((always_inline)) {
+    rq[sl] = row_of(cx_of(hx[sl], bx[sl], nib));
+    c0[sl] = L.A128(ht + rq[sl]); c1[sl] = L.A128(ht + (rq[sl] ^ 16u)); c2[sl] = L.A128(ht + (rq[sl] ^ 32u));
   };
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
-    fill(j, L.ctx(ci, kk), L.byte_at(kk));
-    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
-    hl0[j] = 0xFFFFFFFFu; hl1[j] = 0xFFFFFFFFu;
-  }
-  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+  for (int sl = 0; sl < W; ++sl) { const unsigned kk = min((unsigned)sl, last); hx[sl] = L.ctx(ci, kk); bx[sl] = L.byte_at(kk); }
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const unsigned k = kb + (unsigned)j;
+  for (int sl = 0; sl < D; ++sl) near(sl);
+#pragma unroll
+  for (int i = 0; i < D; ++i) { hl0[i] = 0xFFFFFFFFu; hl1[i] = 0xFFFFFFFFu; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned k = kb + (unsigned)sl;
       const bool on = k < L.nb;
-      const unsigned line = rq[j] & ~63u, pline = oq[j];
+      const unsigned hcur = hx[sl], bcur = bx[sl], row = rq[sl];
+      const unsigned cx = cx_of(hcur, bcur, nib);
+      const unsigned line = row & ~63u, pline = row_of(cx_of(hcur, bcur, 1u - nib)) & ~63u;
+      const unsigned bits4 = nib ? (bcur & 15u) : (bcur >> 4);
       bool stale = false;
 #pragma unroll
       for (int i = 0; i < D; ++i) stale = stale || line == hl0[i] || line == hl1[i];
       const bool defer = nib != 0u && line == pline;              // this byte's first nibble rewrites the line first
+#pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && !pipe_any(on && defer)) break;
         const bool mine = on && (defer == (pass == 1));
         const bool again = mine && (stale || pass == 1);
         if (pipe_any(again)) {
           pipe_stores_done();
-          if (again) { c0[j] = L.A128(ht + rq[j]); c1[j] = L.A128(ht + (rq[j] ^ 16u)); c2[j] = L.A128(ht + (rq[j] ^ 32u)); }
+          if (again) {
+            c0[sl] = pipe_settle(L.A128(ht + row)); c1[sl] = pipe_settle(L.A128(ht + (row ^ 16u))); c2[sl] = pipe_settle(L.A128(ht + (row ^ 32u)));
+          }
         }
         if (mine) {
-          PipeRow r = pipe_find(c0[j], c1[j], c2[j], (cxq[j] >> sizebits) & 255u, rq[j]);
-          const unsigned o = pipe_row_bits(r, nq[j], ns);
+          PipeRow r = pipe_find(c0[sl], c1[sl], c2[sl], (cx >> sizebits) & 255u, row);
+          const unsigned o = pipe_row_bits(r, bits4, ns);
           L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
           *(g_u32*)((g_u8*)&L.bh(ri, k) + 4u * nib) = o;
         }
@@ -463,9 +484,9 @@ __device__ __forceinline__ void pipe_row_nibbles(PipeLane<Chain>& L, unsigned ni
       hl0[0] = nib ? pline : line;
       hl1[0] = nib ? line : pline;
       {
-        const unsigned k2 = min(k + 2u * (unsigned)D, last);
-        fill(j, hq[j], bq[j]);
-        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+        const unsigned kw = min(k + (unsigned)W, last);
+        hx[sl] = L.ctx(ci, kw); bx[sl] = L.byte_at(kw);
+        near((sl + D) % W);
       }
     }
   }
@@ -805,55 +826,54 @@ __device__ __forceinline__ unsigned pipe_c8_at(unsigned byte, unsigned B) { retu
 template <class Chain, int I, class DT>
 __device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, const PipeStretch& stretch, const DT& dt) {
   constexpr CompK c = Chain::comp[I];
-  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN, W = 2 * D;
   static_assert(c.mask0 >= 511u, "CM bit lanes need the 8 words of a byte to be distinct");
   if (!L.nb) return;
   const unsigned last = L.nb - 1u;
-  auto addr = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
-    return (unsigned)c.t0 + 4u * ((hh ^ pipe_hmap4_at(bytev, B)) & c.mask0);
-  };
-  unsigned aq[D], vq[D], hc[D], yq[D], hq[D], bq[D];
+  // ring of W = 2 D slots (slot = byte index mod W, fixed registers): context and byte fetched W bytes ahead, the table
+  // word D bytes ahead
+  unsigned hx[W], bx[W], aq[W], vq[W];
   unsigned ha[HN], hh[HN], hv[HN];
+  auto near = [&](int sl) __attribute__((always_inline)) {
+    aq[sl] = (unsigned)c.t0 + 4u * ((hx[sl] ^ pipe_hmap4_at(bx[sl], B)) & c.mask0);
+    vq[sl] = L.A32(aq[sl]);
+  };
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
-    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
-    hc[j] = hv0; aq[j] = addr(hv0, bv); yq[j] = (bv >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
-    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
-  }
+  for (int sl = 0; sl < W; ++sl) { const unsigned kk = min((unsigned)sl, last); hx[sl] = L.ctx(ci, kk); bx[sl] = L.byte_at(kk); }
 #pragma unroll
-  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
-  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+  for (int sl = 0; sl < D; ++sl) near(sl);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const unsigned k = kb + (unsigned)j;
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned k = kb + (unsigned)sl;
       const bool on = k < L.nb;
-      unsigned v = vq[j];
+      const unsigned hcur = hx[sl], addr = aq[sl];
+      const int y = (int)((bx[sl] >> (7u - B)) & 1u);
+      unsigned v = vq[sl];
       {
         bool late = false;
 #pragma unroll
         for (int i = HN - 1; i >= 0; --i) {
-          v = aq[j] == ha[i] ? hv[i] : v;
-          late = late || (hc[j] != hh[i] && ((hc[j] ^ hh[i]) & c.mask0) < 512u);
+          v = addr == ha[i] ? hv[i] : v;
+          late = late || (hcur != hh[i] && ((hcur ^ hh[i]) & c.mask0) < 512u);
         }
-        if (pipe_any(late)) { pipe_stores_done(); if (late) v = L.A32(aq[j]); }
+        if (pipe_any(late)) { pipe_stores_done(); if (late) v = pipe_opaque(L.A32(addr)); }
       }
       const int pr = stretch(v >> 17);
-      const unsigned nv = pipe_train(v, (int)yq[j], (unsigned)dt[v & 0x3ffu], c.limit);
+      const unsigned nv = pipe_train(v, y, (unsigned)dt[v & 0x3ffu], c.limit);
       if (on) {
-        L.A32(aq[j]) = nv;
+        L.A32(addr) = nv;
         *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
       }
-      {
 #pragma unroll
-        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
-        ha[0] = aq[j]; hh[0] = hc[j]; hv[0] = nv;
-      }
+      for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+      ha[0] = addr; hh[0] = hcur; hv[0] = nv;
       {
-        const unsigned h2 = hq[j], b2 = bq[j];
-        const unsigned k2 = min(k + 2u * (unsigned)D, last);
-        hc[j] = h2; aq[j] = addr(h2, b2); yq[j] = (b2 >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
-        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+        const unsigned kw = min(k + (unsigned)W, last);
+        hx[sl] = L.ctx(ci, kw); bx[sl] = L.byte_at(kw);
+        near((sl + D) % W);
       }
     }
   }
@@ -862,63 +882,59 @@ __device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, con
 template <class Chain, int I>
 __device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, const PipeSquash& squash) {
   constexpr CompK c = Chain::comp[I];
-  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN, W = 2 * D;
   static_assert(c.a5 == 255u && c.mask0 >= 255u, "MIX2 bit lanes need the 8 weights of a byte to be distinct");
   if (!L.nb) return;
   const unsigned last = L.nb - 1u;
-  auto addr = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
-    return (unsigned)c.t0 + 4u * ((hh + pipe_c8_at(bytev, B)) & c.mask0);
-  };
   auto input = [&](int t, unsigned kk) __attribute__((always_inline)) -> int {
     return (int)*(const g_i16*)((const g_u8*)&L.p(t, kk) + 2u * B);
   };
-  unsigned aq[D], vq[D], hc[D], yq[D], hq[D], bq[D];
-  int pj[D], pk[D];
+  unsigned hx[W], bx[W], aq[W], vq[W];
+  int pj[W], pk[W];
   unsigned ha[HN], hh[HN], hv[HN];
+  auto near = [&](int sl, unsigned kk) __attribute__((always_inline)) {
+    aq[sl] = (unsigned)c.t0 + 4u * ((hx[sl] + pipe_c8_at(bx[sl], B)) & c.mask0);
+    vq[sl] = L.A32(aq[sl]);
+    pj[sl] = input((int)c.a2, kk); pk[sl] = input((int)c.a3, kk);
+  };
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
-    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
-    hc[j] = hv0; aq[j] = addr(hv0, bv); yq[j] = (bv >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
-    pj[j] = input((int)c.a2, kk); pk[j] = input((int)c.a3, kk);
-    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
-  }
+  for (int sl = 0; sl < W; ++sl) { const unsigned kk = min((unsigned)sl, last); hx[sl] = L.ctx(ci, kk); bx[sl] = L.byte_at(kk); }
 #pragma unroll
-  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
-  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+  for (int sl = 0; sl < D; ++sl) near(sl, min((unsigned)sl, last));
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const unsigned k = kb + (unsigned)j;
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned k = kb + (unsigned)sl;
       const bool on = k < L.nb;
-      unsigned v = vq[j];
+      const unsigned hcur = hx[sl], addr = aq[sl];
+      const int y = (int)((bx[sl] >> (7u - B)) & 1u);
+      unsigned v = vq[sl];
       {
         bool late = false;
 #pragma unroll
         for (int i = HN - 1; i >= 0; --i) {
-          v = aq[j] == ha[i] ? hv[i] : v;
-          late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & c.mask0) < 256u || ((hh[i] - hc[j]) & c.mask0) < 256u));
+          v = addr == ha[i] ? hv[i] : v;
+          late = late || (hcur != hh[i] && (((hcur - hh[i]) & c.mask0) < 256u || ((hh[i] - hcur) & c.mask0) < 256u));
         }
-        if (pipe_any(late)) { pipe_stores_done(); if (late) v = L.A32(aq[j]); }
+        if (pipe_any(late)) { pipe_stores_done(); if (late) v = pipe_opaque(L.A32(addr)); }
       }
-      const int w = (int)v;
-      const int pr = (__mul24(w, pj[j]) + __mul24(65536 - w, pk[j])) >> 16;   // 17-bit x 12-bit
-      const int err = __mul24((int)yq[j] * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
-      const unsigned nv = (unsigned)min(max(w + ((__mul24(err, pj[j] - pk[j]) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
+      const int w = (int)v, qj = pj[sl], qk = pk[sl];
+      const int pr = (__mul24(w, qj) + __mul24(65536 - w, qk)) >> 16;   // 17-bit x 12-bit
+      const int err = __mul24(y * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
+      const unsigned nv = (unsigned)min(max(w + ((__mul24(err, qj - qk) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
       if (on) {
-        L.A32(aq[j]) = nv;
+        L.A32(addr) = nv;
         *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
       }
-      {
 #pragma unroll
-        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
-        ha[0] = aq[j]; hh[0] = hc[j]; hv[0] = nv;
-      }
+      for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+      ha[0] = addr; hh[0] = hcur; hv[0] = nv;
       {
-        const unsigned h2 = hq[j], b2 = bq[j];
-        const unsigned kd = min(k + (unsigned)D, last), k2 = min(k + 2u * (unsigned)D, last);
-        hc[j] = h2; aq[j] = addr(h2, b2); yq[j] = (b2 >> (7u - B)) & 1u; vq[j] = L.A32(aq[j]);
-        pj[j] = input((int)c.a2, kd); pk[j] = input((int)c.a3, kd);
-        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2);
+        const unsigned kw = min(k + (unsigned)W, last);
+        hx[sl] = L.ctx(ci, kw); bx[sl] = L.byte_at(kw);
+        near((sl + D) % W, min(k + (unsigned)D, last));
       }
     }
   }
@@ -927,77 +943,73 @@ __device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, c
 template <class Chain, int I, class DT>
 __device__ __forceinline__ void pipe_sse_bits(PipeLane<Chain>& L, unsigned B, const PipeStretch& stretch, const DT& dt) {
   constexpr CompK c = Chain::comp[I];
-  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN;
+  constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN, W = 2 * D;
   constexpr unsigned rowmask = c.mask0 >> 5;                         // rows of 32 entries
   static_assert(c.mask0 >= 32u * 256u - 1u, "SSE bit lanes need the 8 rows of a byte to be distinct");
   if (!L.nb) return;
   const unsigned last = L.nb - 1u;
-  // entry pair read for this position: index of the lower one and the interpolation weight (libzpaq.cpp:1935-1939)
-  auto index = [&](unsigned hh, unsigned bytev, int pin, unsigned& wt) __attribute__((always_inline)) -> unsigned {
-    const int pq = min(max(pin + 992, 0), 1983);
-    wt = (unsigned)pq & 63u;
-    return (((hh + pipe_c8_at(bytev, B)) * 32u) & c.mask0) + (unsigned)(pq >> 6);
-  };
   auto input = [&](unsigned kk) __attribute__((always_inline)) -> int {
     return (int)*(const g_i16*)((const g_u8*)&L.p((int)c.a2, kk) + 2u * B);
   };
-  unsigned ix[D], wt[D], e0[D], e1[D], hc[D], yq[D], hq[D], bq[D];
-  int iq[D];                                 // input of the byte D after the window's (the index depends on it)
+  // the entry pair depends on the input prediction, so that travels with the context: all three W bytes ahead
+  unsigned hx[W], bx[W], ix[W], wt[W], e0[W], e1[W];
+  int px[W];
   unsigned ha[HN], hh[HN], hv[HN];           // entry trained (index), context, value stored
+  // entry pair read for this position: index of the lower one and the interpolation weight (libzpaq.cpp:1935-1939)
+  auto near = [&](int sl) __attribute__((always_inline)) {
+    const int pq = min(max(px[sl] + 992, 0), 1983);
+    wt[sl] = (unsigned)pq & 63u;
+    ix[sl] = (((hx[sl] + pipe_c8_at(bx[sl], B)) * 32u) & c.mask0) + (unsigned)(pq >> 6);
+    e0[sl] = L.A32((unsigned)c.t0 + 4u * (ix[sl] & c.mask0));
+    e1[sl] = L.A32((unsigned)c.t0 + 4u * ((ix[sl] + 1u) & c.mask0));
+  };
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
-    const unsigned hv0 = L.ctx(ci, kk), bv = L.byte_at(kk);
-    hc[j] = hv0; yq[j] = (bv >> (7u - B)) & 1u;
-    ix[j] = index(hv0, bv, input(kk), wt[j]);
-    e0[j] = L.A32((unsigned)c.t0 + 4u * (ix[j] & c.mask0));
-    e1[j] = L.A32((unsigned)c.t0 + 4u * ((ix[j] + 1u) & c.mask0));
-    hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2); iq[j] = input(k2);
+  for (int sl = 0; sl < W; ++sl) {
+    const unsigned kk = min((unsigned)sl, last);
+    hx[sl] = L.ctx(ci, kk); bx[sl] = L.byte_at(kk); px[sl] = input(kk);
   }
 #pragma unroll
-  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hv[i] = 0u; }
-  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+  for (int sl = 0; sl < D; ++sl) near(sl);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const unsigned k = kb + (unsigned)j;
+  for (int i = 0; i < HN; ++i) { ha[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hv[i] = 0u; }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned k = kb + (unsigned)sl;
       const bool on = k < L.nb;
-      const unsigned i0 = ix[j] & c.mask0, i1 = (ix[j] + 1u) & c.mask0;
-      unsigned v0 = e0[j], v1 = e1[j];
+      const unsigned hcur = hx[sl];
+      const int y = (int)((bx[sl] >> (7u - B)) & 1u);
+      const unsigned i0 = ix[sl] & c.mask0, i1 = (ix[sl] + 1u) & c.mask0;
+      unsigned v0 = e0[sl], v1 = e1[sl];
       {
         bool late = false;
 #pragma unroll
         for (int i = HN - 1; i >= 0; --i) {
           v0 = i0 == ha[i] ? hv[i] : v0;
           v1 = i1 == ha[i] ? hv[i] : v1;
-          late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & rowmask) < 256u || ((hh[i] - hc[j]) & rowmask) < 256u));
+          late = late || (hcur != hh[i] && (((hcur - hh[i]) & rowmask) < 256u || ((hh[i] - hcur) & rowmask) < 256u));
         }
         if (pipe_any(late)) {
           pipe_stores_done();
-          if (late) { v0 = L.A32((unsigned)c.t0 + 4u * i0); v1 = L.A32((unsigned)c.t0 + 4u * i1); }
+          if (late) { v0 = pipe_opaque(L.A32((unsigned)c.t0 + 4u * i0)); v1 = pipe_opaque(L.A32((unsigned)c.t0 + 4u * i1)); }
         }
       }
-      const unsigned w = wt[j];
+      const unsigned w = wt[sl];
       const int pr = stretch((__umul24(v0 >> 10, 64u - w) + __umul24(v1 >> 10, w)) >> 13);
       const unsigned tv = (w >> 5) ? v1 : v0;
       const unsigned ti = (w >> 5) ? i1 : i0;
-      const unsigned nv = pipe_train(tv, (int)yq[j], (unsigned)dt[tv & 0x3ffu], c.limit);
+      const unsigned nv = pipe_train(tv, y, (unsigned)dt[tv & 0x3ffu], c.limit);
       if (on) {
         L.A32((unsigned)c.t0 + 4u * ti) = nv;
         *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
       }
-      {
 #pragma unroll
-        for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
-        ha[0] = ti; hh[0] = hc[j]; hv[0] = nv;
-      }
+      for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
+      ha[0] = ti; hh[0] = hcur; hv[0] = nv;
       {
-        const unsigned h2 = hq[j], b2 = bq[j];
-        const unsigned k2 = min(k + 2u * (unsigned)D, last);
-        hc[j] = h2; yq[j] = (b2 >> (7u - B)) & 1u;
-        ix[j] = index(h2, b2, iq[j], wt[j]);
-        e0[j] = L.A32((unsigned)c.t0 + 4u * (ix[j] & c.mask0));
-        e1[j] = L.A32((unsigned)c.t0 + 4u * ((ix[j] + 1u) & c.mask0));
-        hq[j] = L.ctx(ci, k2); bq[j] = L.byte_at(k2); iq[j] = input(k2);
+        const unsigned kw = min(k + (unsigned)W, last);
+        hx[sl] = L.ctx(ci, kw); bx[sl] = L.byte_at(kw); px[sl] = input(kw);
+        near((sl + D) % W);
       }
     }
   }
@@ -1347,7 +1359,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
     const unsigned g = wi / (unsigned)WPG, sub = wi % (unsigned)WPG;
     const unsigned pair = (unsigned)lane / QL, q = (unsigned)lane % QL, B = pair & 7u;
     PipeLane<Chain> L;
-    L.open(a, g * Chain::PIPE_G + sub * BPW + (pair >> 3), Chain::P_LEVEL[I]);
+    L.open(a, pipe_opaque(g * Chain::PIPE_G + sub * BPW + (pair >> 3)), Chain::P_LEVEL[I]);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     if (!L.nb) return;
     const bool act = q < (unsigned)NQ;                               // lanes that hold weights
@@ -1366,64 +1378,68 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
       return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)m) + qoff;
     };
     auto input = [&](int x, unsigned kk) __attribute__((always_inline)) -> int {      // this position's half-word of the stream element
-      const int v = (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
-      return have[x] ? v : 0;
+      return (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
     };
     const unsigned last = L.nb - 1u;
-    // window of the next D bytes: row address, weights as fetched, inputs, context, the position's bit
-    unsigned rq[D], hc[D], yq[D];
-    uint4 wq[D];
-    int pq[D][4];
-    unsigned hq[D], bq[D];                  // context and input byte of the D bytes after the window
-    // the last D - 1 bytes done: row, context, weights as stored
+    // Ring of W = 2 D slots, slot = byte index mod W, every slot a fixed set of registers (the loop is unrolled W times):
+    // a byte's context and value are fetched W bytes ahead, its row address / weights / inputs D bytes ahead.  A register is
+    // written by one fetch and read D or more bytes later -- nothing is copied while a fetch is in flight.
+    constexpr int W = 2 * D;
+    unsigned hx[W], bx[W];                  // context, input byte
+    unsigned rq[W];                         // row address of this lane's quad
+    uint4 wq[W];                            // weights as fetched
+    int pq[W][4];                           // inputs as fetched (masked when used)
+    // the last D bytes done: row, context, weights as stored
     unsigned hr[HN], hh[HN];
     uint4 hw[HN];
+    auto near = [&](int sl, unsigned kk) __attribute__((always_inline)) {
+      rq[sl] = row_of(hx[sl], bx[sl]);
+      wq[sl] = *(g_u128a4*)(L.arena + rq[sl]);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const unsigned kk = min((unsigned)j, last), k2 = min((unsigned)(j + D), last);
-      const unsigned hv = L.ctx(ci, kk), bv = L.byte_at(kk);
-      hc[j] = hv;
-      rq[j] = row_of(hv, bv);
-      yq[j] = (bv >> (7u - B)) & 1u;
-      wq[j] = *(g_u128a4*)(L.arena + rq[j]);
+      for (int x = 0; x < 4; ++x) pq[sl][x] = input(x, kk);
+    };
 #pragma unroll
-      for (int x = 0; x < 4; ++x) pq[j][x] = input(x, kk);
-      hq[j] = L.ctx(ci, k2);
-      bq[j] = L.byte_at(k2);
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned kk = min((unsigned)sl, last);
+      hx[sl] = L.ctx(ci, kk);
+      bx[sl] = L.byte_at(kk);
     }
 #pragma unroll
-    for (int i = 0; i < HN; ++i) { hr[i] = 0xFFFFFFFFu; hh[i] = hc[0]; hw[i] = make_uint4(0u, 0u, 0u, 0u); }
-    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)D) {
+    for (int sl = 0; sl < D; ++sl) near(sl, min((unsigned)sl, last));
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const unsigned k = kb + (unsigned)j;
+    for (int i = 0; i < HN; ++i) { hr[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hw[i] = make_uint4(0u, 0u, 0u, 0u); }
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+      for (int sl = 0; sl < W; ++sl) {
+        const unsigned k = kb + (unsigned)sl;
         const bool on = k < L.nb;
-        uint4 w = wq[j];
+        const unsigned hcur = hx[sl], bcur = bx[sl], row = rq[sl];
+        uint4 w = wq[sl];
         {
           bool late = false;
 #pragma unroll
           for (int i = HN - 1; i >= 0; --i) {                       // oldest first: the most recent store wins
-            const bool fw = rq[j] == hr[i];
+            const bool fw = row == hr[i];
             w.x = fw ? hw[i].x : w.x; w.y = fw ? hw[i].y : w.y; w.z = fw ? hw[i].z : w.z; w.w = fw ? hw[i].w : w.w;
-            late = late || (hc[j] != hh[i] && (((hc[j] - hh[i]) & c.mask0) < 256u || ((hh[i] - hc[j]) & c.mask0) < 256u));
+            late = late || (hcur != hh[i] && (((hcur - hh[i]) & c.mask0) < 256u || ((hh[i] - hcur) & c.mask0) < 256u));
           }
           if (pipe_any(late)) {
             pipe_stores_done();
-            if (late) w = *(g_u128a4*)(L.arena + rq[j]);            // after every store so far, in this wavefront's order
+            if (late) w = pipe_settle(*(g_u128a4*)(L.arena + row));   // after every store so far, in this wavefront's order
           }
         }
         const int w0 = (int)w.x, w1 = (int)w.y, w2 = (int)w.z, w3 = (int)w.w;
-        const int p0 = pq[j][0], p1 = pq[j][1], p2 = pq[j][2], p3 = pq[j][3];
         // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
+        const int p0 = have[0] ? pq[sl][0] : 0, p1 = have[1] ? pq[sl][1] : 0, p2 = have[2] ? pq[sl][2] : 0, p3 = have[3] ? pq[sl][3] : 0;
         const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
         const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
-        const int err = __mul24((int)yq[j] * 32767 - squash(pr), (int)c.a4) >> 4;
+        const int y = (int)((bcur >> (7u - B)) & 1u);
+        const int err = __mul24(y * 32767 - squash(pr), (int)c.a4) >> 4;
         uint4 nw;
         nw.x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
         nw.y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
         nw.z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
         nw.w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
-        const unsigned row = rq[j];
         if (on) {
           if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
           if constexpr (TAIL != 0) {
@@ -1435,23 +1451,15 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
           }
           if (q == 0) *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
         }
-        {
 #pragma unroll
-          for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
-          hr[0] = row; hh[0] = hc[j]; hw[0] = nw;
-        }
-        // the slot now serves byte k + D
+        for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
+        hr[0] = row; hh[0] = hcur; hw[0] = nw;
+        // this slot now takes byte k + W; the slot D ahead gets its row, weights and inputs (its context came D bytes ago)
         {
-          const unsigned hv = hq[j], bv = bq[j];
-          const unsigned kd = min(k + (unsigned)D, last), k2 = min(k + 2u * (unsigned)D, last);
-          hc[j] = hv;
-          rq[j] = row_of(hv, bv);
-          yq[j] = (bv >> (7u - B)) & 1u;
-          wq[j] = *(g_u128a4*)(L.arena + rq[j]);
-#pragma unroll
-          for (int x = 0; x < 4; ++x) pq[j][x] = input(x, kd);
-          hq[j] = L.ctx(ci, k2);
-          bq[j] = L.byte_at(k2);
+          const unsigned kw = min(k + (unsigned)W, last);
+          hx[sl] = L.ctx(ci, kw);
+          bx[sl] = L.byte_at(kw);
+          near((sl + D) % W, min(k + (unsigned)D, last));
         }
       }
     }
