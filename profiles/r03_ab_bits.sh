@@ -1,6 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round: A/B of the bit-lane units built at the end of round 2 (emulator-exact, never run on
 # the MI355X; off by default).  Parity first (a wrong kernel is not worth timing), then the headline with each knob.
+#   bash profiles/r03_prebuild_variants.sh          (here, CPU: the variants' code objects, so the GPU call never waits for hipRTC)
 #   gpurun --timeout 2400 -- 'bash profiles/r03_ab_bits.sh'
 # Knobs (host/codegen.cpp, part of the generated source and therefore of the cache key; unseen variants go through hipRTC):
 #   ZPAQ_AMD_PIPE_MIX_BITS=1     MIX with a lane per (block, bit position, weight quad)   ZPAQ_AMD_PIPE_MIX_DEPTH=1..4 (3)
@@ -11,7 +12,7 @@ O=$R/gpurun_out/r03ab
 mkdir -p $O
 cd $R
 export ZPAQ_AMD_MAX_JIT=256
-PAR="tests/test_gpu_parity.py -m gpu -q -x -k 'golden or nine or legacy or large or records or mixed or ragged or zeros'"
+PAR="tests/test_gpu_parity.py -m gpu -q -x -k 'nine or legacy or large or records or mixed or ragged or zeros or compress_blocks'"
 echo "== parity with every bit-lane unit on" | tee $O/summary.txt
 ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1 timeout 1200 bash -c "python -m pytest $PAR" > $O/parity_bits.txt 2>&1
 tail -3 $O/parity_bits.txt | tee -a $O/summary.txt
