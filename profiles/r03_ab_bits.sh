@@ -57,3 +57,17 @@ for v in default all; do
   echo "== placement $v"; python profiles/pipe_trace.py $O/trace_$v.bin 2>&1 | head -24
   rm -f $O/trace_$v.bin
 done | tee -a $O/summary.txt
+# host-buffer API with the page-locked staging buffer (ZPAQ_AMD_PINNED_STAGE=1, experimental): the `api` object of bench.py
+cd $R
+for v in pageable pinned; do
+  E=""; [ $v = pinned ] && E="ZPAQ_AMD_PINNED_STAGE=1"
+  env $E timeout 600 python bench.py --cpu-seconds 0 --steps 1 --warmup 1 > $O/api_$v.json 2> $O/api_$v.err
+  python - <<PY | tee -a $O/summary.txt
+import json
+try:
+    j = json.loads(open("$O/api_$v.json").read().strip().splitlines()[-1])
+    print("api %-9s %.1f MB/s  ms=%s" % ("$v", j["api"]["value"], {k: round(x, 1) for k, x in j["api"]["ms"].items()}))
+except Exception as e:
+    print("api $v FAILED", e, open("$O/api_$v.err").read()[-400:])
+PY
+done

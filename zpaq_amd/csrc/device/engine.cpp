@@ -47,6 +47,21 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Page-locked host memory (ZPAQ_AMD_PINNED_STAGE): the staging buffer of host-buffer batches, DMA-able at link speed
+struct HostPinned {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {                 // false: not available (the caller stages through pageable memory)
+    if (n <= cap) return true;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = (n + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+    cap = want;
+    return true;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // hipEvent_t that cannot leak when a HIP_CHECK throws between create and destroy
 struct Event {
   hipEvent_t ev = nullptr;
@@ -71,6 +86,7 @@ struct Engine {
   DevBuf segs;                         // segment tables of multi-segment blocks
   DevBuf sha_jobs, sha_out;            // SHA-1 of the staged inputs (sha1_blocks_kernel)
   DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
+  HostPinned pin_in;                   // staging of host inputs (ZPAQ_AMD_PINNED_STAGE=1; experimental, off by default)
   hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
@@ -229,7 +245,7 @@ void engine_shutdown() {
     if (!e.ready) continue;
     (void)hipSetDevice(e.device);
     (void)hipStreamSynchronize(e.stream);
-    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release();
+    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release(); e.pin_in.release();
     for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
     for (auto& ss : e.side) (void)hipStreamDestroy(ss);
     e.side.clear();
@@ -855,7 +871,14 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
         e, decode, order, [&](uint32_t b) { return blocks[b].plan; },
         [&](uint32_t b) { return blocks[b].in_len + blocks[b].prefix_len; });
     std::vector<BlockJob> jobs(cnt);
-    std::vector<uint8_t> stage(in_bytes + 64);
+    // inputs are gathered into one buffer and sent with one copy: pageable memory by default; with
+    // ZPAQ_AMD_PINNED_STAGE=1 a page-locked buffer kept by the engine, filled by several threads (experimental)
+    std::vector<uint8_t> stage_vec;
+    uint8_t* stage = nullptr;
+    const bool pinned = getenv("ZPAQ_AMD_PINNED_STAGE") != nullptr && e.pin_in.ensure(in_bytes + 64);
+    if (pinned) stage = (uint8_t*)e.pin_in.p;
+    else { stage_vec.resize(in_bytes + 64); stage = stage_vec.data(); }
+    std::vector<uint64_t> in_off_of(cnt);
     std::vector<uint64_t> out_off(cnt);
     // segment tables of the blocks that have several segments
     std::vector<SegRange> segtab;
@@ -892,14 +915,32 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
       j.in_len = hb.in_len + hb.prefix_len;
       j.out_cap = hb.out_cap;
       j.res_slot = (uint32_t)k;
-      if (hb.prefix_len) memcpy(stage.data() + i_off, hb.prefix, hb.prefix_len);
-      if (hb.in_len) memcpy(stage.data() + i_off + hb.prefix_len, hb.in, hb.in_len);
+      in_off_of[k] = i_off;
+      if (!pinned) {
+        if (hb.prefix_len) memcpy(stage + i_off, hb.prefix, hb.prefix_len);
+        if (hb.in_len) memcpy(stage + i_off + hb.prefix_len, hb.in, hb.in_len);
+      }
       out_off[k] = o_off;
       a_off += hb.plan->hdr().arena_bytes;
       i_off += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
       o_off += ((uint64_t)hb.out_cap + 63) & ~63ull;
     }
-    HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage.data(), in_bytes, hipMemcpyHostToDevice, e.stream));
+    if (pinned) {
+      // the gather itself is a gigabyte of memcpy for a full batch: spread it over a few threads
+      const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, cnt, (size_t)(in_bytes >> 24) + 1}));
+      auto gather = [&](size_t t) {
+        for (size_t k = t; k < cnt; k += nt) {
+          const HostBlock& hb = blocks[order[k]];
+          if (hb.prefix_len) memcpy(stage + in_off_of[k], hb.prefix, hb.prefix_len);
+          if (hb.in_len) memcpy(stage + in_off_of[k] + hb.prefix_len, hb.in, hb.in_len);
+        }
+      };
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < nt; ++t) pool.emplace_back(gather, t);
+      gather(0);
+      for (auto& th : pool) th.join();
+    }
+    HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, in_bytes, hipMemcpyHostToDevice, e.stream));
     HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
     // SHA-1 of the blocks whose caller asked for it: one lane per block, on a side stream beside the coder
     std::vector<Sha1Job> shj;
