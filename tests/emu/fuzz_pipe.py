@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- random COMP chains and HCOMP programs through the pipelined encoder under the wavefront emulator,
 with every experimental unit switched on (bit-lane MIX / CM / MIX2 / SSE, nibble-lane ROW units, random fetch depths), compared
 with the oracle byte for byte.  Not collected by pytest (minutes of g++): run by hand after touching pipe_kernel.h --
-    python tests/emu/fuzz_pipe.py <seed> <cases>          (600 chains passed at the end of round 2)"""
+    python tests/emu/fuzz_pipe.py <seed> <cases> [default]       (600 chains passed at the end of round 2; `default` = knobs off)"""
 import sys, random, numpy as np, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,6 +59,7 @@ for case in range(ncase):
         continue
     inputs = [b"\0" + make_data(r, case * 10 + i) for i in range(r.choice([1, 3, 5]))] + ([b""] if r.random() < 0.3 else [])
     kw = dict(chunk=64, mix_bits=1, mix_depth=r.choice([1, 2, 3]), light_bits=7, light_depth=r.choice([1, 2, 3]), row_nibbles=1, row_depth=r.choice([1, 2, 3]))
+    if len(sys.argv) > 3 and sys.argv[3] == "default": kw = dict(chunk=64)          # the product's own configuration
     if r.random() < 0.2: kw["group"] = r.choice([8, 16])
     try:
         res = emu.pipe_run(header, inputs, **kw)
