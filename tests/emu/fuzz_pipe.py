@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE -- random COMP chains and HCOMP programs through the pipelined encoder under the wavefront emulator,
 with every experimental unit switched on (bit-lane MIX / CM / MIX2 / SSE, nibble-lane ROW units, random fetch depths), compared
 with the oracle byte for byte.  Not collected by pytest (minutes of g++): run by hand after touching pipe_kernel.h --
-    python tests/emu/fuzz_pipe.py <seed> <cases> [default]       (600 chains passed at the end of round 2; `default` = knobs off)"""
+    python tests/emu/fuzz_pipe.py <seed> <cases> [default]       (600 chains passed at the end of round 2; `default` = knobs off,
+                                                                  `wavefront` = spec_kernel.h, encoder and decoder)"""
 import sys, random, numpy as np, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,6 +60,19 @@ for case in range(ncase):
         continue
     inputs = [b"\0" + make_data(r, case * 10 + i) for i in range(r.choice([1, 3, 5]))] + ([b""] if r.random() < 0.3 else [])
     kw = dict(chunk=64, mix_bits=1, mix_depth=r.choice([1, 2, 3]), light_bits=7, light_depth=r.choice([1, 2, 3]), row_nibbles=1, row_depth=r.choice([1, 2, 3]))
+    if len(sys.argv) > 3 and sys.argv[3] == "wavefront":
+        # the per-header wavefront kernel (spec_kernel.h) in both directions instead: encode == oracle, decode(oracle) == input
+        waves = r.choice([4, 8])
+        try:
+            enc = emu.run(header, inputs, decode=False, waves=waves)
+            coded = [oracle.encode(header, x) for x in inputs]
+            dec = emu.run(header, [cd + b"\0\0\0\0" for cd in coded], decode=True, waves=waves, out_cap=max(len(x) for x in inputs) + 8)
+        except Exception as e:
+            print("CASE", seed0, case, "emulator error:", str(e)[-300:]); bad += 1; continue
+        ok = all(e[0] == cd and e[1] == 0 for e, cd in zip(enc, coded)) and all(d[0] == x and d[1] == 0 for d, x in zip(dec, inputs))
+        if not ok: print("CASE", seed0, case, "MISMATCH (wavefront kernel)"); print(cfg)
+        bad += not ok; done += 1
+        continue
     if len(sys.argv) > 3 and sys.argv[3] == "default": kw = dict(chunk=64)          # the product's own configuration
     if r.random() < 0.2: kw["group"] = r.choice([8, 16])
     try:
