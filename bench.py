@@ -404,7 +404,9 @@ def main():
                                f"(BASELINE configs[2] when 1024 x 1 MiB text on one GPU; configs[3] when 'mixed' on 8 GPUs)",
                    "blocks_per_gpu": nb, "blocks_total": total_blocks, "block_bytes": bs, "corpus": a.kind,
                    "method": a.method, "plans": len(groups), "ncomp": [g[0].ncomp for g in groups],
-                   "parallelism": f"blocks/{world}gpu", "state_GiB_per_gpu": state_bytes / 2 ** 30},
+                   "parallelism": f"blocks/{world}gpu", "state_GiB_per_gpu": state_bytes / 2 ** 30,
+                   # code-generation / engine knobs in force (none = the product's defaults)
+                   "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ZPAQ_AMD_")}},
         "ratio": coded_total / (float(nb) * bs) if nb else None,
         "all_status_ok": ok, "roundtrip_verified_blocks": verified,
         "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
