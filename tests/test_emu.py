@@ -270,7 +270,8 @@ def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
     assert "ROW_NIBBLES = 1, ROW_DEPTH = 3" in emu.pipe_source(h5, 64, row_nibbles=1, row_depth=3)
     for depth in (1, 4):
         _pipe_check(oracle, h5, ragged + [b""], chunk=64, row_nibbles=1, row_depth=depth)
-    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7)
+    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
+    _pipe_check(oracle, h5, ragged[:4], chunk=64, full_squash=1)            # ZPAQ_AMD_PIPE_FULL_SQUASH alone: whole squash table in LDS
     _pipe_check(oracle, h5, ragged, chunk=64, **everything)
     _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, row_nibbles=1, row_depth=2)
     seen = set()

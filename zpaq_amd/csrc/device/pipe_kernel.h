@@ -234,6 +234,20 @@ struct PipeSquash {
   }
 };
 
+// ... or through all 4096 entries (ZPAQ_AMD_PIPE_FULL_SQUASH=1: 8 KB of LDS instead of 2.7, one add and one read
+// instead of two clamps, the read and two selects on every unit's per-bit chain; arguments are clamped to -2047..2047)
+struct PipeSquashFull {
+  unsigned short all[4096];
+  __device__ __forceinline__ void load(const DeviceTables* tb, int lane) {
+    for (int i = lane; i < 4096; i += (int)blockDim.x) all[i] = tb->squash[i];
+  }
+  __device__ __forceinline__ int operator()(int p) const { return all[(unsigned)(p + 2048) & 4095u]; }
+};
+template <class Chain, bool Full = (Chain::FULL_SQUASH != 0)>
+struct PipeSquashFor { typedef PipeSquash type; };
+template <class Chain>
+struct PipeSquashFor<Chain, true> { typedef PipeSquashFull type; };
+
 // Predictor::train (libzpaq.h:1151-1157)
 __device__ __forceinline__ unsigned pipe_train(unsigned v, int y, unsigned dtv, unsigned limit) {
   const unsigned count = v & 0x3ffu;
@@ -654,8 +668,8 @@ __device__ __forceinline__ void pipe_avg(PipeLane<Chain>& L) {
 }
 
 // MIX2 (libzpaq.cpp:1898-1908, 2010-2021).  Device layout: one weight per dword.
-template <class Chain, int I>
-__device__ __forceinline__ void pipe_mix2(PipeLane<Chain>& L, const PipeSquash& squash) {
+template <class Chain, int I, class SQ>
+__device__ __forceinline__ void pipe_mix2(PipeLane<Chain>& L, const SQ& squash) {
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I];
   constexpr bool single = c.mask0 == 0u;                          // one weight: it stays in a register
@@ -879,8 +893,8 @@ __device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, con
   }
 }
 
-template <class Chain, int I>
-__device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, const PipeSquash& squash) {
+template <class Chain, int I, class SQ>
+__device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, const SQ& squash) {
   constexpr CompK c = Chain::comp[I];
   constexpr int ci = Chain::P_CTX[I], D = Chain::LIGHT_DEPTH, HN = PipeBitsWin<D>::HN, W = 2 * D;
   static_assert(c.a5 == 255u && c.mask0 >= 255u, "MIX2 bit lanes need the 8 weights of a byte to be distinct");
@@ -1016,8 +1030,8 @@ __device__ __forceinline__ void pipe_sse_bits(PipeLane<Chain>& L, unsigned B, co
 }
 
 // CODER: Encoder::compress / encode (libzpaq.cpp:2402-2447) fed by the last component's stream.
-template <class Chain>
-__device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a, const PipeSquash& squash) {
+template <class Chain, class SQ>
+__device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a, const SQ& squash) {
   constexpr int sw = Chain::CODER_STATE;
   const unsigned nchunks = max((L.len + (unsigned)Chain::PIPE_C - 1u) / (unsigned)Chain::PIPE_C, 1u);
   const bool active = L.live && L.chunk >= 0 && (unsigned)L.chunk < nchunks;
@@ -1115,7 +1129,7 @@ template <class Chain>
 __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
   __shared__ int dt[1024];
   __shared__ unsigned short dt2k[256];
-  __shared__ PipeSquash squash;
+  __shared__ typename PipeSquashFor<Chain>::type squash;
   __shared__ PipeStretch stretch;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
@@ -1252,7 +1266,7 @@ template <class Chain>
 __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
   constexpr unsigned G = Chain::PIPE_G;
   __shared__ unsigned tab[512 * G];
-  __shared__ PipeSquash squash;
+  __shared__ typename PipeSquashFor<Chain>::type squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
@@ -1338,7 +1352,7 @@ __device__ __forceinline__ int pipe_group_sum(int v) {
 // row range apart: any lane may have written it).
 template <class Chain>
 __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
-  __shared__ PipeSquash squash;
+  __shared__ typename PipeSquashFor<Chain>::type squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
@@ -1472,7 +1486,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     pipe_mix_bits_body<Chain>(a);
     return;
   } else {
-  __shared__ PipeSquash squash;
+  __shared__ typename PipeSquashFor<Chain>::type squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
