@@ -41,6 +41,13 @@ run light_sse ZPAQ_AMD_PIPE_LIGHT_BITS=4
 run light_all ZPAQ_AMD_PIPE_LIGHT_BITS=7
 run mix_rows ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
 for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1; done
+# BASELINE configs[1] (-m3, 256 x 256 KiB LCG: ICM + ISSE, 256 lanes per unit -- the latency-bound small-batch regime, where
+# the fetch depth of the ROW units should matter most)
+BENCH="python bench.py --method 3 --kind lcg --blocks 256 --block-bytes 262144 --cpu-seconds 0 --steps 3 --warmup 1"
+run c1_default
+for d in 2 3 4; do run c1_rows_d$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=$d; done
+run c1_rows_squash ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=3 ZPAQ_AMD_PIPE_FULL_SQUASH=1
+BENCH="python bench.py --cpu-seconds 0 --api-blocks 0 --steps 1 --warmup 1"
 # per-kernel durations of the best candidate and of the default, for the timeline
 cd /tmp && export TMPDIR=/tmp
 for v in default all; do
