@@ -269,7 +269,7 @@ def test_unseen_headers_compile_side_by_side(zlib_, tmp_path, monkeypatch):
         assert key.value.decode() + ".hsaco" in files
     assert L.zpq_precompile(arr, len(plans), 0, 4) == 0          # nothing left to do
     # one thread = no helper processes: the same code objects from hipRTC inside this process
-    more = [zlib_.Plan(zlib_.method_to_header(f"x0,0ci2,1,1c0,{300 + i}m16s")[0]) for i in range(2)]
+    more = [zlib_.Plan(zlib_.method_to_header(f"x0,0ci2,1,1c0,{100 + i}m16s")[0]) for i in range(2)]
     arr2 = (C.c_void_p * len(more))(*[p._h for p in more])
     assert L.zpq_precompile(arr2, len(more), 0, 1) == 2, L.zpq_last_error()
     assert len(os.listdir(tmp_path)) == 10
