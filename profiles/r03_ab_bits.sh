@@ -41,6 +41,9 @@ run light_sse ZPAQ_AMD_PIPE_LIGHT_BITS=4
 run light_all ZPAQ_AMD_PIPE_LIGHT_BITS=7
 run mix_rows ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
 for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1; done
+# fewer, longer steps once the kernels are short (launch / event overhead per step is fixed)
+run all_d3_c1024 ZPAQ_AMD_PIPE_CHUNK=1024 ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
+run default_c1024 ZPAQ_AMD_PIPE_CHUNK=1024
 # BASELINE configs[1] (-m3, 256 x 256 KiB LCG: ICM + ISSE, 256 lanes per unit -- the latency-bound small-batch regime, where
 # the fetch depth of the ROW units should matter most)
 BENCH="python bench.py --method 3 --kind lcg --blocks 256 --block-bytes 262144 --cpu-seconds 0 --steps 3 --warmup 1"
