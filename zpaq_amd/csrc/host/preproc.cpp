@@ -17,53 +17,54 @@ namespace zpq {
 
 namespace {
 
-int bit_length(unsigned x) { int r = 0; while (x) { ++r; x >>= 1; } return r; }   // lg() of the reference
+int bit_length(unsigned x) { return x ? 32 - __builtin_clz(x) : 0; }   // lg() of the reference
 
 // ---------------------------------------------------------------------------------------------------------
 // Suffix array by induced sorting (SA-IS, Nong / Zhang / Chan).  The reference calls divsufsort; any correct
 // suffix sorter yields the same array.  `s` ends with a unique smallest symbol 0.
-void sais(const int* s, int* sa, int n, int K) {
+template <class T>
+void sais(const T* s, int* sa, int n, int K) {
   if (n == 1) { sa[0] = 0; return; }
   if (n == 2) { sa[0] = 1; sa[1] = 0; return; }
-  std::vector<char> stype((size_t)n);                      // 1 = S-type suffix
-  stype[(size_t)n - 1] = 1;
-  for (int i = n - 2; i >= 0; --i) stype[(size_t)i] = s[i] < s[i + 1] || (s[i] == s[i + 1] && stype[(size_t)i + 1]);
-  auto lms = [&](int i) { return i > 0 && stype[(size_t)i] && !stype[(size_t)i - 1]; };
-  std::vector<int> bkt((size_t)K);
+  // suffix types: bit 0 = S-type, bit 1 = leftmost S-type (LMS)
+  std::vector<unsigned char> ty((size_t)n);
+  ty[(size_t)n - 1] = 1;
+  for (int i = n - 2; i >= 0; --i) ty[(size_t)i] = (unsigned char)(s[i] < s[i + 1] || (s[i] == s[i + 1] && (ty[(size_t)i + 1] & 1)));
+  for (int i = 1; i < n; ++i) if ((ty[(size_t)i] & 1) && !(ty[(size_t)i - 1] & 1)) ty[(size_t)i] |= 2;
+  std::vector<int> cnt((size_t)K, 0), bkt((size_t)K);
+  for (int i = 0; i < n; ++i) ++cnt[(size_t)s[i]];
   auto buckets = [&](bool ends) {
-    std::fill(bkt.begin(), bkt.end(), 0);
-    for (int i = 0; i < n; ++i) ++bkt[(size_t)s[i]];
     int sum = 0;
-    for (int c = 0; c < K; ++c) { sum += bkt[(size_t)c]; bkt[(size_t)c] = ends ? sum : sum - bkt[(size_t)c]; }
+    for (int c = 0; c < K; ++c) { sum += cnt[(size_t)c]; bkt[(size_t)c] = ends ? sum : sum - cnt[(size_t)c]; }
   };
   auto induce = [&]() {
     buckets(false);
     for (int i = 0; i < n; ++i) {
       const int j = sa[i] - 1;
-      if (sa[i] > 0 && !stype[(size_t)j]) sa[bkt[(size_t)s[j]]++] = j;
+      if (j >= 0 && !(ty[(size_t)j] & 1)) sa[bkt[(size_t)s[j]]++] = j;
     }
     buckets(true);
     for (int i = n - 1; i >= 0; --i) {
       const int j = sa[i] - 1;
-      if (sa[i] > 0 && stype[(size_t)j]) sa[--bkt[(size_t)s[j]]] = j;
+      if (j >= 0 && (ty[(size_t)j] & 1)) sa[--bkt[(size_t)s[j]]] = j;
     }
   };
   // 1. sort the LMS substrings
   std::fill(sa, sa + n, -1);
   buckets(true);
-  for (int i = 1; i < n; ++i) if (lms(i)) sa[--bkt[(size_t)s[i]]] = i;
+  for (int i = 1; i < n; ++i) if (ty[(size_t)i] & 2) sa[--bkt[(size_t)s[i]]] = i;
   induce();
   // 2. name them
   int n1 = 0;
-  for (int i = 0; i < n; ++i) if (lms(sa[i])) sa[n1++] = sa[i];
+  for (int i = 0; i < n; ++i) if (sa[i] > 0 && (ty[(size_t)sa[i]] & 2)) sa[n1++] = sa[i];
   std::fill(sa + n1, sa + n, -1);
   int names = 0, prev = -1;
   for (int i = 0; i < n1; ++i) {
     const int pos = sa[i];
     bool diff = prev < 0;
     for (int d = 0; !diff; ++d) {
-      if (s[pos + d] != s[prev + d] || stype[(size_t)pos + d] != stype[(size_t)prev + d]) diff = true;
-      else if (d > 0 && (lms(pos + d) || lms(prev + d))) break;
+      if (s[pos + d] != s[prev + d] || ty[(size_t)pos + d] != ty[(size_t)prev + d]) diff = true;
+      else if (d > 0 && ((ty[(size_t)pos + d] & 2) || (ty[(size_t)prev + d] & 2))) break;
     }
     if (diff) { ++names; prev = pos; }
     sa[n1 + pos / 2] = names - 1;
@@ -74,7 +75,7 @@ void sais(const int* s, int* sa, int n, int K) {
   if (names < n1) sais(s1.data(), sa1.data(), n1, names);
   else for (int i = 0; i < n1; ++i) sa1[(size_t)s1[(size_t)i]] = i;
   // 4. induce the full array from the sorted LMS suffixes
-  for (int i = 1, j = 0; i < n; ++i) if (lms(i)) s1[(size_t)j++] = i;          // LMS positions in text order
+  for (int i = 1, j = 0; i < n; ++i) if (ty[(size_t)i] & 2) s1[(size_t)j++] = i;          // LMS positions in text order
   for (int i = 0; i < n1; ++i) sa1[(size_t)i] = s1[(size_t)sa1[(size_t)i]];
   std::fill(sa, sa + n, -1);
   buckets(true);
@@ -88,8 +89,9 @@ void sais(const int* s, int* sa, int n, int K) {
 std::vector<U32> suffix_array(const U8* in, U32 n) {
   std::vector<U32> out(n);
   if (!n) return out;
-  std::vector<int> s((size_t)n + 1), sa((size_t)n + 1);
-  for (U32 i = 0; i < n; ++i) s[i] = (int)in[i] + 1;
+  std::vector<unsigned short> s((size_t)n + 1);           // byte + 1, the end of the string as the unique smallest symbol
+  std::vector<int> sa((size_t)n + 1);
+  for (U32 i = 0; i < n; ++i) s[i] = (unsigned short)(in[i] + 1u);
   s[n] = 0;
   sais(s.data(), sa.data(), (int)n + 1, 257);
   for (U32 i = 0; i < n; ++i) out[i] = (U32)sa[(size_t)i + 1];                  // sa[0] is the sentinel
@@ -156,7 +158,7 @@ class Lz77 {
               unsigned p;
               if (at_q < n_ && (p = sa_[at_q] - h) < i) {
                 unsigned l, l1;
-                for (l = h; i + l < n_ && l < kMaxMatch && in_[p + l] == in_[i + l]; ++l) {}
+                l = h < std::min(n_ - i, kMaxMatch) ? match_end(p, i, h, std::min(n_ - i, kMaxMatch)) : h;
                 for (l1 = h; l1 > 0 && in_[p + l1 - 1] == in_[i + l1 - 1]; --l1) {}
                 int score = (int)(l - l1) * 8 - bit_length(i - p) - 4 * (lit == 0 && l1 > 0) - 11;
                 for (unsigned a = 0; a < h; ++a) score = score * 5 / 8;
@@ -175,7 +177,7 @@ class Lz77 {
               p >>= checkbits_;
               if (p < i && i + blen <= n_ && in_[p + blen - 1] == in_[i + blen - 1]) {
                 unsigned l;
-                for (l = lookahead_; i + l < n_ && l < kMaxMatch && in_[p + l] == in_[i + l]; ++l) {}
+                l = lookahead_ < std::min(n_ - i, kMaxMatch) ? match_end(p, i, lookahead_, std::min(n_ - i, kMaxMatch)) : lookahead_;
                 if (l >= min_match2_ + lookahead_) {
                   int l1;
                   for (l1 = (int)lookahead_; l1 > 0 && in_[p + l1 - 1] == in_[i + l1 - 1]; --l1) {}
@@ -194,7 +196,7 @@ class Lz77 {
               p >>= checkbits_;
               if (p < i && i + blen <= n_ && in_[p + blen - 1] == in_[i + blen - 1]) {
                 unsigned l;
-                for (l = 0; i + l < n_ && l < kMaxMatch && in_[p + l] == in_[i + l]; ++l) {}
+                l = match_end(p, i, 0, std::min(n_ - i, kMaxMatch));
                 const int score = (int)l * 8 - bit_length(i - p) - 2 * (lit > 0) - 11;
                 if (score > bscore) { blen = l; bp = p; blit = 0; bscore = score; }
               }
@@ -238,6 +240,19 @@ class Lz77 {
   }
 
  private:
+  // first l >= from with in[p + l] != in[i + l], at most `limit` (p < i, i + limit <= n): 8 bytes per step
+  unsigned match_end(unsigned p, unsigned i, unsigned from, unsigned limit) const {
+    unsigned l = from;
+    while (l + 8 <= limit) {
+      unsigned long long a, b;
+      memcpy(&a, in_ + p + l, 8);
+      memcpy(&b, in_ + i + l, 8);
+      if (a != b) return l + (unsigned)(__builtin_ctzll(a ^ b) >> 3);
+      l += 8;
+    }
+    while (l < limit && in_[p + l] == in_[i + l]) ++l;
+    return l;
+  }
   void putb(unsigned x, int k) {                                  // k bits of x, least significant first
     x &= (1u << k) - 1u;
     bits_ |= x << nbits_;
