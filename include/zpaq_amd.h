@@ -101,6 +101,10 @@ int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
  * lane per segment on the device when a batch has enough of them): code = the PCOMP bytes without their 2-byte
  * length, ph / pm = header bytes 4 and 5. */
 int zpq_pcomp_source(const uint8_t* code, size_t codelen, int ph, int pm, char* src, size_t cap, size_t* len, char key41[41]);
+/* Host post-processing (PostProcessor::write, libzpaq.cpp:2195-2241): 1 when this PCOMP program (bytes as for
+ * zpq_pcomp_source) is one of those compressBlock's own methods generate, which the host runs as C++ translated at build time
+ * (the counterpart of the reference's x86 JIT, libzpaq.cpp:3231-3811); 0 when it will be interpreted. */
+int zpq_pcomp_is_translated(const uint8_t* code, size_t codelen, int ph, int pm);
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);

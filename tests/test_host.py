@@ -396,3 +396,84 @@ def test_host_batches_shard_contiguously_over_devices(zlib_):
                 assert (lo.value, hi.value) == tuple(zd.shard_range(n, k, parts))
                 prev = hi.value
             assert prev == n
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Host post-processing: the standard PCOMP programs run as C++ translated at build time (tools/gen_pcomp_std.cpp);
+# ZPAQ_AMD_PCOMP_INTERPRET=1 forces the interpreter.  Both must produce the same bytes, for valid and for damaged streams.
+
+def _stored_block(header, segments):
+    """A block without a model (n = 0) by hand: `segments` are the payloads (the first one starts with the PP header)."""
+    out = bytearray(b"7kSt\xa01\x83\xd3\x8c\xb2\x28\xb0\xd3zPQ\x02\x01") + header
+    for k, payload in enumerate(segments):
+        out += b"\x01" + b"s%d" % k + b"\x00\x00\x00"          # segment, filename, empty comment, reserved 0
+        for at in range(0, len(payload), 65536):
+            chunk = payload[at:at + 65536]
+            out += len(chunk).to_bytes(4, "big") + chunk
+        out += b"\x00\x00\x00\x00" + b"\xfe"                      # end of the stored payload, no checksum
+    return bytes(out + b"\xff")
+
+
+def test_translated_pcomp_programs_equal_the_interpreter(zlib_, ref, monkeypatch):
+    import ctypes as C
+    L = zlib_.lib()
+    L.zpq_preprocess_block.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+
+    def stream(xm, data):
+        buf = np.frombuffer(bytes(data), np.uint8).copy()
+        out = np.empty(len(data) * 2 + 4096, np.uint8)
+        ln = C.c_size_t(0)
+        assert L.zpq_preprocess_block(xm.encode(), buf.ctypes.data, buf.size, out.ctypes.data, out.size, C.byref(ln)) == 0
+        return out[:ln.value].tobytes()
+
+    def both(archive, cap):
+        monkeypatch.delenv("ZPAQ_AMD_PCOMP_INTERPRET", raising=False)
+        res = []
+        for interp in (False, True):
+            if interp:
+                monkeypatch.setenv("ZPAQ_AMD_PCOMP_INTERPRET", "1")
+            try:
+                res.append(zlib_.decompress(archive, cap))
+            except zlib_.ZpaqError as e:
+                res.append(("error", e.code))
+        monkeypatch.delenv("ZPAQ_AMD_PCOMP_INTERPRET", raising=False)
+        return res
+
+    rng = np.random.default_rng(11)
+    datas = [corpus.block(k, n, 7 + i).tobytes() for i, (k, n) in enumerate([("text", 70000), ("records", 50000), ("zeros", 30000),
+                                                                              ("lcg", 20000), ("pattern", 40000), ("text", 1)])]
+    datas.append(bytes(_exe_like(60000, 3)))
+    n_native = 0
+    for xm in ("x0,1,4,0,3,20", "x0,5,4,0,3,20", "x0,2,12,0,7,21", "x0,6,5,0,7,21", "x1,1,4,0,3,21", "x0,4"):
+        h, pc, _ = zlib_.method_to_header(xm)
+        assert h[6] == 0 and pc                                   # no model: the block is stored, the program does the work
+        assert L.zpq_pcomp_is_translated(bytes(pc[2:]), len(pc) - 2, h[4], h[5]) == 1, xm
+        for d in datas:
+            s = stream(xm, d) if xm != "x0,4" else None
+            if s is None:                                           # E8E9 only: the filtered input itself
+                buf = np.frombuffer(d, np.uint8).copy()
+                out = np.empty(len(d) + 4096, np.uint8); ln = C.c_size_t(0)
+                L.zpq_preprocess_block(xm.encode(), buf.ctypes.data, buf.size, out.ctypes.data, out.size, C.byref(ln))
+                s = buf.tobytes()
+            arc = _stored_block(h, [b"\x01" + pc + s])
+            a, b = both(arc, len(d) + 64)
+            assert a == b == d, (xm, len(d))
+            assert ref.decompress(arc, len(d) + 64) == d
+            n_native += 1
+            # damaged streams: whatever the interpreter makes of them, the translated program makes the same
+            for _ in range(3):
+                t = bytearray(s)
+                if len(t) > 8:
+                    for _ in range(3):
+                        t[int(rng.integers(0, len(t)))] ^= 1 << int(rng.integers(0, 8))
+                    t = t[:int(rng.integers(len(t) // 2, len(t)))]
+                x, y = both(_stored_block(h, [b"\x01" + pc + bytes(t)]), len(d) * 4 + 4096)
+                assert x == y, (xm, "damaged")
+        # two segments in one block share the machine: the first runs translated, the second makes the interpreter catch up
+        d1, d2 = datas[0][:30000], datas[1][:20000]
+        if xm != "x0,4":
+            arc = _stored_block(h, [b"\x01" + pc + stream(xm, d1), stream(xm, d2)])
+            a, b = both(arc, 60000)
+            assert a == b == ref.decompress(arc, 60000), xm
+    assert n_native >= 40
+    assert L.zpq_pcomp_is_translated(b"\x38\x00", 2, 0, 20) == 0          # anything else is interpreted

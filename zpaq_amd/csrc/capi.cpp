@@ -89,6 +89,10 @@ size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
   }
 }
 
+int zpq_pcomp_is_translated(const uint8_t* code, size_t codelen, int ph, int pm) {
+  return code && pcomp_is_translated(code, codelen, ph, pm) ? 1 : 0;
+}
+
 int zpq_precompile(const zpq_plan* const* plans, size_t n, int decode, int threads) {
   try {
     if (!plans && n) fail(ZPQ_E_ARG, "null plans");

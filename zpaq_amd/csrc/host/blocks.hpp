@@ -68,6 +68,9 @@ class PostProcessor {
   Impl* impl_;
 };
 
+// whether the host runs this PCOMP program (code without its 2 length bytes) as C++ translated at build time
+bool pcomp_is_translated(const U8* code, size_t len, int ph, int pm);
+
 // The same for a block of ONE segment: turns a decoded segment (PP header + payload) into the
 // segment's data -- either passing it through or running the PCOMP program it carries.
 void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data);

@@ -3,11 +3,16 @@
 // is the data) or 1 len16 program[len] (PROG: the rest is fed byte by byte, then EOF, to that ZPAQL
 // program, whose OUT instructions produce the data).  The program travels inside the archive, so
 // any archive written by the reference's LZ77 / BWT / E8E9 methods decodes here without this
-// library knowing those programs.
+// library knowing those programs.  The programs compressBlock's own methods generate are, in addition, translated
+// to C++ at build time (tools/gen_pcomp_std.cpp, by the translator that serves the device): a block whose program is
+// byte for byte one of those runs natively -- the reference gets the same effect from its x86 JIT
+// (libzpaq.cpp:3231-3811) -- and anything else is interpreted.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
 #include "blocks.hpp"
+#include "pcomp_host.h"
 
 namespace zpq {
 
@@ -136,8 +141,38 @@ struct PostProcessor::Impl {
   size_t want = 0;
   std::vector<U8> prog;          // PCOMP code as carried by the first segment
   std::vector<U8> sink;
-  std::unique_ptr<PcompVm> vm;
+  std::unique_ptr<PcompVm> vm;   // the interpreter's machine, made when first needed
+  // The block's first segment through a translated program: the interpreter's machine has not seen it.  Blocks of several
+  // segments share one machine, so the segment is kept and replayed into the interpreter if a second one arrives.
+  size_t segments = 0;
+  bool native_first = false;
+  std::vector<U8> replay;
+  PcompVm& machine() {
+    if (!vm) vm.reset(new PcompVm(prog.data(), prog.size(), ph, pm, sink));
+    return *vm;
+  }
 };
+
+namespace {
+const PcompStd* translated(const std::vector<U8>& prog, int ph, int pm) {
+  if (getenv("ZPAQ_AMD_PCOMP_INTERPRET")) return nullptr;
+  for (const PcompStd* e = kPcompStd; e->code; ++e)
+    if (e->len == prog.size() && e->ph == ph && e->pm == pm && memcmp(e->code, prog.data(), prog.size()) == 0) return e;
+  return nullptr;
+}
+
+// one segment through a translated program on a fresh machine; false = it reported an error (the caller interprets)
+bool run_translated(const PcompStd& e, const U8* p, size_t n, std::vector<U8>& out) {
+  if (e.ph > 28 || e.pm > 30) return false;
+  std::vector<U32> H((size_t)1 << e.ph, 0);
+  std::vector<U8> M((size_t)1 << e.pm, 0);
+  PcompHostState st;
+  st.H = H.data();
+  st.M = M.data();
+  out.reserve(out.size() + n * 3);
+  return e.run(st, p, n, true, out) == 0;
+}
+}  // namespace
 
 PostProcessor::PostProcessor(int ph, int pm) : impl_(new Impl) { impl_->ph = ph; impl_->pm = pm; }
 PostProcessor::~PostProcessor() { delete impl_; }
@@ -161,10 +196,7 @@ void PostProcessor::segment(const U8* p, size_t n, std::vector<U8>& data) {
         break;
       case 4:
         m.prog.push_back(c);
-        if (m.prog.size() == m.want) {
-          m.vm.reset(new PcompVm(m.prog.data(), m.prog.size(), m.ph, m.pm, m.sink));
-          m.state = 5;
-        }
+        if (m.prog.size() == m.want) m.state = 5;
         break;
     }
   }
@@ -173,15 +205,39 @@ void PostProcessor::segment(const U8* p, size_t n, std::vector<U8>& data) {
     data.insert(data.end(), p + i, p + n);
     return;
   }
+  const size_t seg = m.segments++;
+  if (seg == 0) {
+    if (const PcompStd* e = translated(m.prog, m.ph, m.pm)) {
+      const size_t before = data.size();
+      if (run_translated(*e, p + i, n - i, data)) {
+        m.native_first = true;
+        m.replay.assign(p + i, p + n);
+        return;
+      }
+      data.resize(before);                     // the translated program gave up (step budget): interpret from the start
+    }
+  }
+  PcompVm& vm = m.machine();
+  if (m.native_first) {                        // a second segment: bring the interpreter's machine to where the first one left it
+    m.sink.clear();
+    for (const U8 c : m.replay) vm.run(c);
+    vm.run(0xFFFFFFFFu);
+    m.native_first = false;
+    std::vector<U8>().swap(m.replay);
+  }
   m.sink.clear();
-  for (; i < n; ++i) m.vm->run(p[i]);
-  m.vm->run(0xFFFFFFFFu);                      // EOS: ZPAQL::run(-1) (libzpaq.cpp:2236-2237)
+  for (; i < n; ++i) vm.run(p[i]);
+  vm.run(0xFFFFFFFFu);                         // EOS: ZPAQL::run(-1) (libzpaq.cpp:2236-2237)
   data.insert(data.end(), m.sink.begin(), m.sink.end());
   m.sink.clear();
 }
 
 bool PostProcessor::loaded() const { return impl_->state == 1 || impl_->state == 5; }
 const std::vector<U8>& PostProcessor::program() const { return impl_->prog; }
+
+bool pcomp_is_translated(const U8* code, size_t len, int ph, int pm) {
+  return translated(std::vector<U8>(code, code + len), ph, pm) != nullptr;
+}
 
 void post_process(const std::vector<U8>& header, const std::vector<U8>& decoded, std::vector<U8>& data) {
   data.clear();
