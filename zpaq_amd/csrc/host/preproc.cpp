@@ -156,6 +156,8 @@ class Lz77 {
             for (unsigned k = 1; k <= bucket_; ++k) {
               const unsigned at_q = q + (unsigned)(dir * (int)k);
               unsigned p;
+              // (the text behind a candidate is a random access: ask for the one six entries on now)
+              { const unsigned nq = at_q + (unsigned)(dir * 6); if (nq < n_) __builtin_prefetch(in_ + sa_[nq]); }
               if (at_q < n_ && (p = sa_[at_q] - h) < i) {
                 unsigned l, l1;
                 l = h < std::min(n_ - i, kMaxMatch) ? match_end(p, i, h, std::min(n_ - i, kMaxMatch)) : h;
