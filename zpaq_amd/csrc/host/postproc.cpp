@@ -7,6 +7,7 @@
 // to C++ at build time (tools/gen_pcomp_std.cpp, by the translator that serves the device): a block whose program is
 // byte for byte one of those runs natively -- the reference gets the same effect from its x86 JIT
 // (libzpaq.cpp:3231-3811) -- and anything else is interpreted.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -28,13 +29,17 @@ class PcompVm {
     hmask_ = (U32)H_.size() - 1;
     mmask_ = (U32)M_.size() - 1;
     memset(R_, 0, sizeof(R_));
+    // The reference puts no limit on a program's run time (a damaged BWT stream makes its inverse loop for good).  The
+    // standard programs need a few dozen steps per array element at most (inverse BWT at the end of a segment): 64 per
+    // element of H and M, and never less than 2^28, ends a hostile stream in about a second instead of a minute.
+    max_steps_ = std::max<U64>((U64)1 << 28, 64ull * ((U64)H_.size() + (U64)M_.size()));
   }
 
   void run(U32 input) {
     U32 pc = 0;
     a_ = input;
     for (U64 steps = 0;; ++steps) {
-      if (steps > (1ull << 34) || pc >= len_) bad();
+      if (steps > max_steps_ || pc >= len_) bad();
       const int op = prog_[pc++];
       const int g = op >> 3, k = op & 7;
       if (op < 64) {
@@ -127,6 +132,7 @@ class PcompVm {
   std::vector<U8> M_;
   U32 R_[256];
   U32 hmask_ = 0, mmask_ = 0;
+  U64 max_steps_ = 0;
   U32 a_ = 0, b_ = 0, c_ = 0, d_ = 0;
   bool f_ = false;
 };
