@@ -469,23 +469,41 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
       }
     }
   }
-  std::unique_ptr<PostProcessor> pp;
-  size_t pp_block = (size_t)-1;
-  for (size_t si = 0; si < segs.size(); ++si) {
-    auto& s = segs[si];
-    std::vector<U8> data;
-    if (on_device[si]) data.swap(done[si]);
-    else {
-      // one PostProcessor per block: only its first segment carries the PP header (libzpaq.cpp:2320-2330)
-      if (s->block != pp_block) { pp.reset(new PostProcessor(s->header[4], s->header[5])); pp_block = s->block; }
-      pp->segment(s->decoded.data(), s->decoded.size(), data);
-    }
-    std::vector<U8>().swap(s->decoded);
-    if (s->fs.has_sha1) {
-      Sha1 h; h.update(data.data(), data.size());
-      if (memcmp(h.result(), s->fs.sha1, 20) != 0) fail(ZPQ_E_CORRUPT, "segment checksum mismatch");
-    }
-    sink(data.data(), data.size());
+  // Host post-processing and the checksum are per block (its segments in order: one PostProcessor per block, only the
+  // first segment carries the PP header, libzpaq.cpp:2320-2330) and blocks are independent: a window of blocks at a time
+  // on the host cores, then the window's data to the sink in archive order.
+  std::vector<std::pair<size_t, size_t>> spans;                 // [first, last) segment of each block, in archive order
+  for (size_t si = 0; si < segs.size();) {
+    size_t e = si + 1;
+    while (e < segs.size() && segs[e]->block == segs[si]->block) ++e;
+    spans.push_back({si, e});
+    si = e;
+  }
+  const size_t kWindow = 64;
+  for (size_t w0 = 0; w0 < spans.size(); w0 += kWindow) {
+    const size_t w1 = std::min(spans.size(), w0 + kWindow);
+    parallel_blocks(w1 - w0, [&](size_t k) {
+      const auto span = spans[w0 + k];
+      std::unique_ptr<PostProcessor> pp;
+      for (size_t si = span.first; si < span.second; ++si) {
+        auto& s = segs[si];
+        if (!on_device[si]) {
+          if (!pp) pp.reset(new PostProcessor(s->header[4], s->header[5]));
+          done[si].clear();
+          pp->segment(s->decoded.data(), s->decoded.size(), done[si]);
+        }
+        std::vector<U8>().swap(s->decoded);
+        if (s->fs.has_sha1) {
+          Sha1 h; h.update(done[si].data(), done[si].size());
+          if (memcmp(h.result(), s->fs.sha1, 20) != 0) fail(ZPQ_E_CORRUPT, "segment checksum mismatch");
+        }
+      }
+    });
+    for (size_t b = w0; b < w1; ++b)
+      for (size_t si = spans[b].first; si < spans[b].second; ++si) {
+        sink(done[si].data(), done[si].size());
+        std::vector<U8>().swap(done[si]);
+      }
   }
 }
 
