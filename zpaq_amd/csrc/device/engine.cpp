@@ -873,11 +873,16 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     std::vector<BlockJob> jobs(cnt);
     // inputs are gathered into one buffer and sent with one copy: pageable memory by default; with
     // ZPAQ_AMD_PINNED_STAGE=1 a page-locked buffer kept by the engine, filled by several threads (experimental)
-    std::vector<uint8_t> stage_vec;
+    std::unique_ptr<uint8_t[]> stage_buf;
     uint8_t* stage = nullptr;
     const bool pinned = getenv("ZPAQ_AMD_PINNED_STAGE") != nullptr && e.pin_in.ensure(in_bytes + 64);
     if (pinned) stage = (uint8_t*)e.pin_in.p;
-    else { stage_vec.resize(in_bytes + 64); stage = stage_vec.data(); }
+    else {
+      // (not a std::vector: value-initialising a gigabyte costs a quarter of a second; the padding between blocks is
+      // never read -- every kernel goes by in_len)
+      stage_buf.reset(new uint8_t[in_bytes + 64]);
+      stage = stage_buf.get();
+    }
     std::vector<uint64_t> in_off_of(cnt);
     std::vector<uint64_t> out_off(cnt);
     // segment tables of the blocks that have several segments
