@@ -83,6 +83,69 @@ void sais(const T* s, int* sa, int n, int K) {
   induce();
 }
 
+// The top level on bytes: symbol (byte + 1, 0 for the end of the string) in the low 9 bits of a 16-bit word, the suffix
+// type in bit 15 (S-type) and bit 14 (leftmost S-type) -- the induction loops, whose text accesses are random, read one
+// word per suffix instead of a symbol and a type.
+void sais_bytes(unsigned short* s, int* sa, int n) {
+  constexpr int K = 257;
+  constexpr unsigned short kS = 0x8000u, kLms = 0x4000u, kSym = 0x01FFu;
+  if (n == 1) { sa[0] = 0; return; }
+  if (n == 2) { sa[0] = 1; sa[1] = 0; return; }
+  s[n - 1] |= kS;
+  for (int i = n - 2; i >= 0; --i) {
+    const unsigned a = s[i] & kSym, b = s[i + 1] & kSym;
+    if (a < b || (a == b && (s[i + 1] & kS))) s[i] |= kS;
+  }
+  for (int i = 1; i < n; ++i) if ((s[i] & kS) && !(s[i - 1] & kS)) s[i] |= kLms;
+  int cnt[K] = {0}, bkt[K];
+  for (int i = 0; i < n; ++i) ++cnt[s[i] & kSym];
+  auto buckets = [&](bool ends) {
+    int sum = 0;
+    for (int c = 0; c < K; ++c) { sum += cnt[c]; bkt[c] = ends ? sum : sum - cnt[c]; }
+  };
+  auto induce = [&]() {
+    buckets(false);
+    for (int i = 0; i < n; ++i) {
+      const int j = sa[i] - 1;
+      if (j >= 0) { const unsigned v = s[j]; if (!(v & kS)) sa[bkt[v & kSym]++] = j; }
+    }
+    buckets(true);
+    for (int i = n - 1; i >= 0; --i) {
+      const int j = sa[i] - 1;
+      if (j >= 0) { const unsigned v = s[j]; if (v & kS) sa[--bkt[v & kSym]] = j; }
+    }
+  };
+  std::fill(sa, sa + n, -1);
+  buckets(true);
+  for (int i = 1; i < n; ++i) if (s[i] & kLms) sa[--bkt[s[i] & kSym]] = i;
+  induce();
+  int n1 = 0;
+  for (int i = 0; i < n; ++i) if (sa[i] > 0 && (s[sa[i]] & kLms)) sa[n1++] = sa[i];
+  std::fill(sa + n1, sa + n, -1);
+  int names = 0, prev = -1;
+  for (int i = 0; i < n1; ++i) {
+    const int pos = sa[i];
+    bool diff = prev < 0;
+    for (int d = 0; !diff; ++d) {
+      // (symbol and S bit compared together; the LMS bit ends a substring)
+      if (((s[pos + d] ^ s[prev + d]) & (kSym | kS)) != 0) diff = true;
+      else if (d > 0 && ((s[pos + d] | s[prev + d]) & kLms)) break;
+    }
+    if (diff) { ++names; prev = pos; }
+    sa[n1 + pos / 2] = names - 1;
+  }
+  std::vector<int> s1((size_t)n1), sa1((size_t)n1);
+  for (int i = n1, j = 0; i < n; ++i) if (sa[i] >= 0) s1[(size_t)j++] = sa[i];
+  if (names < n1) sais(s1.data(), sa1.data(), n1, names);
+  else for (int i = 0; i < n1; ++i) sa1[(size_t)s1[(size_t)i]] = i;
+  for (int i = 1, j = 0; i < n; ++i) if (s[i] & kLms) s1[(size_t)j++] = i;
+  for (int i = 0; i < n1; ++i) sa1[(size_t)i] = s1[(size_t)sa1[(size_t)i]];
+  std::fill(sa, sa + n, -1);
+  buckets(true);
+  for (int i = n1 - 1; i >= 0; --i) { const int j = sa1[(size_t)i]; sa[--bkt[s[j] & kSym]] = j; }
+  induce();
+}
+
 }  // namespace
 
 // Suffix array of in[0..n) with the end of the string ordered before every byte.
@@ -93,7 +156,7 @@ std::vector<U32> suffix_array(const U8* in, U32 n) {
   for (U32 i = 0; i < n; ++i) s[i] = (unsigned short)(in[i] + 1u);
   s[n] = 0;
   out.resize((size_t)n + 1);                              // sorted in place (entries are < 2^31), then the sentinel's
-  sais(s.data(), (int*)out.data(), (int)n + 1, 257);      // entry at the front is dropped
+  sais_bytes(s.data(), (int*)out.data(), (int)n + 1);     // entry at the front is dropped
   out.erase(out.begin());
   return out;
 }
