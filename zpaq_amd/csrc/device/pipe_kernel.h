@@ -337,6 +337,26 @@ __device__ __forceinline__ PipeRow pipe_find(const uint4& r0, const uint4& r1, c
   return r;
 }
 
+// The same with the row picked by masks instead of nested selections (which the compiler turns into branches, four
+// exec-mask blocks per row word): used by the nibble-lane ROW unit.
+__device__ __forceinline__ PipeRow pipe_find_flat(const uint4& r0, const uint4& r1, const uint4& r2, unsigned chk, unsigned h0) {
+  const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+  const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+  const unsigned victim = (p0 <= p1 && p0 <= p2) ? 0u : (p1 < p2 ? 1u : 2u);
+  const bool hit = m0 || m1 || m2;
+  const unsigned pick = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : victim));
+  // all ones for the candidate that was found (none on a miss: the row starts empty with the new check byte)
+  const unsigned k0 = (hit && pick == 0u) ? 0xFFFFFFFFu : 0u, k1 = (hit && pick == 1u) ? 0xFFFFFFFFu : 0u,
+                 k2 = (hit && pick == 2u) ? 0xFFFFFFFFu : 0u;
+  PipeRow r;
+  r.off = h0 ^ (pick << 4);
+  r.w0 = (r0.x & k0) | (r1.x & k1) | (r2.x & k2) | (hit ? 0u : chk);
+  r.w1 = (r0.y & k0) | (r1.y & k1) | (r2.y & k2);
+  r.w2 = (r0.z & k0) | (r1.z & k1) | (r2.z & k2);
+  r.w3 = (r0.w & k0) | (r1.w & k1) | (r2.w & k2);
+  return r;
+}
+
 // the nibble's 4 bits: slots 1, 2..3, 4..7, 8..15 (hmap4 & 15) = bytes 1..3 of w0, then w1, then w2 / w3;
 // returns the 4 bit histories the predictor sees, lowest byte first
 template <class NS>
@@ -487,7 +507,7 @@ __device__ __forceinline__ void pipe_row_nibbles(PipeLane<Chain>& L, unsigned ni
           }
         }
         if (mine) {
-          PipeRow r = pipe_find(c0[sl], c1[sl], c2[sl], (cx >> sizebits) & 255u, row);
+          PipeRow r = pipe_find_flat(c0[sl], c1[sl], c2[sl], (cx >> sizebits) & 255u, row);
           const unsigned o = pipe_row_bits(r, bits4, ns);
           L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
           *(g_u32*)((g_u8*)&L.bh(ri, k) + 4u * nib) = o;
