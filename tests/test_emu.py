@@ -272,6 +272,7 @@ def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
         _pipe_check(oracle, h5, ragged + [b""], chunk=64, row_nibbles=1, row_depth=depth)
     everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
     _pipe_check(oracle, h5, ragged[:4], chunk=64, full_squash=1)            # ZPAQ_AMD_PIPE_FULL_SQUASH alone: whole squash table in LDS
+    _pipe_check(oracle, h5, ragged, chunk=64, row_flat=1)                   # ZPAQ_AMD_PIPE_ROW_FLAT: one-lane ROW unit, row picked by masks
     _pipe_check(oracle, h5, ragged, chunk=64, **everything)
     _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, row_nibbles=1, row_depth=2)
     seen = set()

@@ -424,7 +424,9 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
       nb0 = L.A128(ht + hbn); nb1 = L.A128(ht + (hbn ^ 16u)); nb2 = L.A128(ht + (hbn ^ 32u));
     }
     const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
-    PipeRow ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
+    PipeRow ra;
+    if constexpr (Chain::ROW_FLAT != 0) ra = pipe_find_flat(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
+    else ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
     uint2 o;
     o.x = pipe_row_bits(ra, byte >> 4, ns);
     const uint4 na = make_uint4(ra.w0, ra.w1, ra.w2, ra.w3);
@@ -433,7 +435,9 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     if (ra.off == hb) b0 = na;
     if (ra.off == (hb ^ 16u)) b1 = na;
     if (ra.off == (hb ^ 32u)) b2 = na;
-    PipeRow rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
+    PipeRow rb;
+    if constexpr (Chain::ROW_FLAT != 0) rb = pipe_find_flat(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
+    else rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
     o.y = pipe_row_bits(rb, byte & 15u, ns);
     L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
     L.bh(ri, k) = o;

@@ -54,6 +54,7 @@ struct PipeLayout {
   // ROW units with a lane per (block, nibble): workgroups of 2 x G lanes (ZPAQ_AMD_PIPE_ROW_NIBBLES=1, G <= 32; off by default:
   // emulator-exact, not yet measured on the MI355X)
   int row_nibbles = 0;
+  int row_flat = 0;            // one-lane ROW unit with the candidate row picked by masks instead of branches (ZPAQ_AMD_PIPE_ROW_FLAT=1)
   int row_depth = 2;           // bytes such a unit fetches its candidate rows ahead (ZPAQ_AMD_PIPE_ROW_DEPTH, 1..4)
   int light_threads() const { return light_bits ? 64 : G; }                               // workgroup size of the light kernel
   int rows_threads() const { return row_nibbles ? 2 * G : G; }                            // workgroup size of the rows kernel
