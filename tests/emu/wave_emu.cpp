@@ -1,5 +1,9 @@
 // TEST INFRASTRUCTURE -- runtime of the host-side wavefront emulator (see wave_emu.h).
 // One OS thread, one fiber per lane, hand-rolled x86-64 context switch.
+#include <cstring>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,9 +111,23 @@ void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) {
     for (int k = 0; k < 6; ++k) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
     f.sp = sp;
   }
+  // The order in which the lanes run between two cross-lane operations is the emulator's choice; the hardware runs them
+  // instruction by instruction together.  A kernel whose lanes communicate through memory inside such an interval gives
+  // different results for different orders: ZPQ_EMU_ORDER=reverse | shuffle[:seed] lets the tests try others.
+  static const char* order_env = getenv("ZPQ_EMU_ORDER");
+  static const int order_mode = !order_env ? 0 : (!strncmp(order_env, "reverse", 7) ? 1 : (!strncmp(order_env, "shuffle", 7) ? 2 : 0));
+  static unsigned long long order_rng = order_env && strchr(order_env, ':') ? strtoull(strchr(order_env, ':') + 1, nullptr, 10) * 2654435761ull + 1 : 12345;
+  std::vector<unsigned> order(threads);
+  for (unsigned t = 0; t < threads; ++t) order[t] = order_mode == 1 ? threads - 1 - t : t;
   for (;;) {
     bool ran = false;
-    for (unsigned t = 0; t < threads; ++t) {
+    if (order_mode == 2)
+      for (unsigned t = threads; t > 1; --t) {
+        order_rng = order_rng * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(order[t - 1], order[(unsigned)((order_rng >> 33) % t)]);
+      }
+    for (unsigned oi = 0; oi < threads; ++oi) {
+      const unsigned t = order[oi];
       Fiber& f = g_fibers[t];
       if (f.state != READY) continue;
       g_cur = &f;
