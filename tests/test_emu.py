@@ -293,3 +293,23 @@ def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
     for depth in (1, 3):
         _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, row_nibbles=1, row_depth=depth)
     _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, **everything)
+
+
+def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
+    """Between two cross-lane operations the emulator may run the lanes of a wavefront in any order; the hardware runs them
+    together.  The experimental units' lanes meet in memory (the positions of one block share its tables), so they must give
+    the oracle's bytes whatever the order: the default one, reversed, and two shuffles."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    stress = [b"\0" + d for d in (walk, bytes(500), bytes([7, 7, 8, 8] * 150), bytes(range(256)) * 2)]
+    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
+    for order in ("reverse", "shuffle:3", "shuffle:4"):
+        monkeypatch.setenv("ZPQ_EMU_ORDER", order)
+        _pipe_check(oracle, h5, ragged, chunk=64, **everything)
+        _pipe_check(oracle, header, stress, chunk=64, **everything)
+        _pipe_check(oracle, h5, ragged[:4], chunk=64)                   # and the product's own configuration
