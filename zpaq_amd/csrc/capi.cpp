@@ -270,7 +270,7 @@ int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t ca
   U64 total = 0;
   bool overflow = false;
   decode_archive(archive, (size_t)n, [&](const U8* p, size_t len) {
-    if (out && total + len <= cap) memcpy(out + total, p, len);
+    if (out && total + len <= cap) { if (len) memcpy(out + total, p, len); }      // (an empty segment's data pointer may be null)
     else overflow = true;
     total += len;
   });
