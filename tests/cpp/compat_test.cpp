@@ -3,6 +3,7 @@
 //                                       hdrN = expected header bytes (hex) of Compressor::startBlock(N)
 //   compat_test gpu                   : everything, including the modelled methods
 //   compat_test level N in out        : Compressor::startBlock(N) over file `in` (one segment, SHA-1) -> file `out`
+//   compat_test stream METHOD in out [name comment] : libzpaq::compress() over file `in` -> archive `out`, decompressed back
 //   compat_test segments N out in.. : one block, built-in model N, one segment per input file (named s0, s1, ..) -> `out`;
 //                                       then decodes it back both ways and checks the data
 //   compat_test threads T method      : T threads, one libzpaq::compressBlock each, like zpaq.cpp's compressThread pool
@@ -100,6 +101,21 @@ int main(int argc, char** argv) {
       fwrite(arc.c_str(), 1, arc.size(), f);
       fclose(f);
       printf("COMPAT_OK 1\n");
+      return 0;
+    }
+    if (mode == "stream") {        // libzpaq::compress(Reader, Writer, method, filename, comment) over a file, then decompress
+      const std::string data = slurp(argv[3]);
+      libzpaq::StringBuffer in, arc, back;
+      in.write(data.data(), (int)data.size());
+      libzpaq::compress(&in, &arc, argv[2], argc > 5 ? argv[5] : 0, argc > 6 ? argv[6] : 0, true);
+      FILE* f = fopen(argv[4], "wb");
+      fwrite(arc.c_str(), 1, arc.size(), f);
+      fclose(f);
+      libzpaq::StringBuffer arc2;
+      arc2.write(arc.c_str(), (int)arc.size());
+      libzpaq::decompress(&arc2, &back);
+      CHECK(back.size() == data.size() && memcmp(back.c_str(), data.data(), data.size()) == 0);
+      printf("COMPAT_OK %d\n", checks);
       return 0;
     }
     if (mode == "segments") {

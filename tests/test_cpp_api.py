@@ -25,6 +25,29 @@ def test_cpp_api_host_paths(tmp_path, zlib_, golden):
     assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
 
 
+def test_streaming_compress_of_several_blocks_host_methods(tmp_path, zlib_, ref):
+    """libzpaq::compress() cuts its input into blocks (method "N0": 2^20 - 4096 bytes each), names only the first segment and
+    batches the blocks; methods 0, 1, 2 have no model, so the whole thing runs without a GPU.  The archive must be the
+    reference's byte for byte, and decompress() must return the input."""
+    import numpy as np
+    from zpaq_amd import corpus
+    exe = _build(tmp_path)
+    data = np.concatenate([corpus.block(k, n, 60 + i) for i, (k, n) in enumerate([("text", 1500000), ("records", 900000), ("lcg", 300000)])]).tobytes()
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    for method in ("00", "10", "20", "11"):
+        out = tmp_path / f"out{method}.zpaq"
+        r = subprocess.run([exe, "stream", method, str(src), str(out), "file.bin", "a comment"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout
+        assert out.read_bytes() == ref.compress(data, method, "file.bin", "a comment"), method
+    empty = tmp_path / "empty.bin"
+    empty.write_bytes(b"")
+    out = tmp_path / "empty.zpaq"
+    r = subprocess.run([exe, "stream", "10", str(empty), str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode == 0 and out.read_bytes() == ref.compress(b"", "10"), r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_api_on_gpu(tmp_path, gpu):
     exe = _build(tmp_path)
