@@ -8,6 +8,7 @@
 #   ZPAQ_AMD_PIPE_LIGHT_BITS=m   1 CM | 2 MIX2 | 4 SSE with a lane per (block, bit position)   ZPAQ_AMD_PIPE_LIGHT_DEPTH=1..4 (3)
 #   ZPAQ_AMD_PIPE_ROW_NIBBLES=1  ROW units with a lane per (block, nibble)                  ZPAQ_AMD_PIPE_ROW_DEPTH=1..4 (2)
 #   ZPAQ_AMD_PIPE_ROW_FLAT=1     the one-lane ROW unit with the candidate row picked by masks, not branches (-17 % instructions)
+#   ZPAQ_AMD_PIPE_MAP_ILP=2|4    ICM / ISSE maps with 2 / 4 blocks per lane: independent chains interleaved in one wavefront
 #   ZPAQ_AMD_PIPE_FULL_SQUASH=1  squash from the whole table in LDS (5 instructions fewer per bit in ISSE / MIX / MIX2 / coder)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r03ab
@@ -37,11 +38,15 @@ for d in 1 2 3 4; do run mix_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPT
 for d in 1 2 3; do run rows_d$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=$d; done
 run full_squash ZPAQ_AMD_PIPE_FULL_SQUASH=1
 run row_flat ZPAQ_AMD_PIPE_ROW_FLAT=1
+run map_ilp2 ZPAQ_AMD_PIPE_MAP_ILP=2
+run map_ilp4 ZPAQ_AMD_PIPE_MAP_ILP=4
+run map_ilp2_squash ZPAQ_AMD_PIPE_MAP_ILP=2 ZPAQ_AMD_PIPE_FULL_SQUASH=1
 run light_cm ZPAQ_AMD_PIPE_LIGHT_BITS=1
 run light_mix2 ZPAQ_AMD_PIPE_LIGHT_BITS=2
 run light_sse ZPAQ_AMD_PIPE_LIGHT_BITS=4
 run light_all ZPAQ_AMD_PIPE_LIGHT_BITS=7
 run mix_rows ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
+run all_ilp2 ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_MAP_ILP=2 ZPAQ_AMD_PIPE_FULL_SQUASH=1
 for d in 2 3 4; do run all_d$d ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1; done
 # fewer, longer steps once the kernels are short (launch / event overhead per step is fixed)
 run all_d3_c1024 ZPAQ_AMD_PIPE_CHUNK=1024 ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
@@ -52,6 +57,7 @@ BENCH="python bench.py --method 3 --kind lcg --blocks 256 --block-bytes 262144 -
 run c1_default
 for d in 2 3 4; do run c1_rows_d$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=$d; done
 run c1_rows_squash ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=3 ZPAQ_AMD_PIPE_FULL_SQUASH=1
+run c1_rows_ilp2 ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=3 ZPAQ_AMD_PIPE_FULL_SQUASH=1 ZPAQ_AMD_PIPE_MAP_ILP=2
 BENCH="python bench.py --cpu-seconds 0 --api-blocks 0 --steps 1 --warmup 1"
 # per-kernel durations of the best candidate and of the default, for the timeline
 cd /tmp && export TMPDIR=/tmp

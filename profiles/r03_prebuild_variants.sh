@@ -12,6 +12,11 @@ for m in 1 2 4 7; do run ZPAQ_AMD_PIPE_LIGHT_BITS=$m; done
 run ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_ROW_NIBBLES=1
 run ZPAQ_AMD_PIPE_FULL_SQUASH=1
 run ZPAQ_AMD_PIPE_ROW_FLAT=1
+run ZPAQ_AMD_PIPE_MAP_ILP=2
+run ZPAQ_AMD_PIPE_MAP_ILP=4
+run ZPAQ_AMD_PIPE_MAP_ILP=2 ZPAQ_AMD_PIPE_FULL_SQUASH=1
+run ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_MAP_ILP=2 ZPAQ_AMD_PIPE_FULL_SQUASH=1
+run ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=3 ZPAQ_AMD_PIPE_FULL_SQUASH=1 ZPAQ_AMD_PIPE_MAP_ILP=2
 run ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=4
 run ZPAQ_AMD_PIPE_ROW_NIBBLES=1 ZPAQ_AMD_PIPE_ROW_DEPTH=3 ZPAQ_AMD_PIPE_FULL_SQUASH=1
 for d in 2 3 4; do run ZPAQ_AMD_PIPE_MIX_BITS=1 ZPAQ_AMD_PIPE_MIX_DEPTH=$d ZPAQ_AMD_PIPE_LIGHT_BITS=7 ZPAQ_AMD_PIPE_LIGHT_DEPTH=$d ZPAQ_AMD_PIPE_ROW_NIBBLES=1; done

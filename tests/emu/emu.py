@@ -95,7 +95,7 @@ def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int
 def pipe_source(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None,
                 mix_bits: int | None = None, mix_depth: int | None = None,
             light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None) -> str:
+            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None) -> str:
     import zpaq_amd as z
     L = z.lib()
     L.zpq_plan_pipe_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
@@ -106,7 +106,7 @@ def pipe_source(header: bytes, chunk: int | None = None, mix_lanes: int | None =
     with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group,
               ZPAQ_AMD_PIPE_MIX_BITS=mix_bits, ZPAQ_AMD_PIPE_MIX_DEPTH=mix_depth,
               ZPAQ_AMD_PIPE_LIGHT_BITS=light_bits, ZPAQ_AMD_PIPE_LIGHT_DEPTH=light_depth,
-              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat):
+              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat, ZPAQ_AMD_PIPE_MAP_ILP=map_ilp):
         rc = L.zpq_plan_pipe_source(plan._h, buf, len(buf), C.byref(ln), key)
     if rc != 0:
         raise RuntimeError(L.zpq_last_error().decode())
@@ -136,9 +136,9 @@ class _env:
 def pipe_build(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None,
                mix_bits: int | None = None, mix_depth: int | None = None,
             light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None) -> str:
+            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None) -> str:
     import zpaq_amd as z
-    src = pipe_source(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat)
+    src = pipe_source(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat, map_ilp)
     dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
     deps = b"".join(open(p, "rb").read() for p in (
         os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"),
@@ -166,9 +166,9 @@ def pipe_build(header: bytes, chunk: int | None = None, mix_lanes: int | None = 
 def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, mix_lanes: int | None = None,
              out_cap: int | None = None, group: int | None = None, mix_bits: int | None = None, mix_depth: int | None = None,
             light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None):
+            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None):
     """Encode every input as one block with the pipelined encoder.  Returns [(bytes, status, consumed)]."""
-    exe = pipe_build(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat)
+    exe = pipe_build(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat, map_ilp)
     cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
     with tempfile.TemporaryDirectory(dir=BUILD) as td:
         hp = os.path.join(td, "h.bin")
@@ -181,7 +181,7 @@ def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, mix
         with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group,
                   ZPAQ_AMD_PIPE_MIX_BITS=mix_bits, ZPAQ_AMD_PIPE_MIX_DEPTH=mix_depth,
               ZPAQ_AMD_PIPE_LIGHT_BITS=light_bits, ZPAQ_AMD_PIPE_LIGHT_DEPTH=light_depth,
-              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat):
+              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat, ZPAQ_AMD_PIPE_MAP_ILP=map_ilp):
             r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), *paths],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
         if r.returncode != 0:

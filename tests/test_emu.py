@@ -273,6 +273,11 @@ def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
     everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
     _pipe_check(oracle, h5, ragged[:4], chunk=64, full_squash=1)            # ZPAQ_AMD_PIPE_FULL_SQUASH alone: whole squash table in LDS
     _pipe_check(oracle, h5, ragged, chunk=64, row_flat=1)                   # ZPAQ_AMD_PIPE_ROW_FLAT: one-lane ROW unit, row picked by masks
+    # ZPAQ_AMD_PIPE_MAP_ILP: two / four blocks per lane in the ICM and ISSE maps (ragged lengths: the blocks of a lane end apart)
+    many = [b"\0" + corpus.block(kinds[i % 5], 40 + (i * 37) % 200, i).tobytes() for i in range(40)]
+    _pipe_check(oracle, h5, many, chunk=64, map_ilp=2)
+    _pipe_check(oracle, h5, ragged + [b""], chunk=64, map_ilp=4)
+    _pipe_check(oracle, h5, many[:20], chunk=64, map_ilp=2, **everything)
     _pipe_check(oracle, h5, ragged, chunk=64, **everything)
     _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, row_nibbles=1, row_depth=2)
     seen = set()

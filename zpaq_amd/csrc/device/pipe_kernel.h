@@ -1233,8 +1233,15 @@ __device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return 
 // ICM map (libzpaq.cpp:1875-1881, 1973-1977): side table cm[256] of 64 blocks in LDS as [entry][lane].
 // The entry of the NEXT bit is read before this bit's entry is written and patched when they coincide, so the
 // LDS round trip is off the lane's serial chain.
+template <class Chain> __device__ __forceinline__ void pipe_icm_ilp_body(const PipeArgs& a);
+template <class Chain> __device__ __forceinline__ void pipe_isse_ilp_body(const PipeArgs& a);
+
 template <class Chain>
 __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
+  if constexpr (Chain::MAP_ILP > 1) {
+    pipe_icm_ilp_body<Chain>(a);
+    return;
+  } else {
   constexpr unsigned G = Chain::PIPE_G;
   __shared__ unsigned tab[256 * G];
   __shared__ PipeStretch stretch;
@@ -1283,11 +1290,16 @@ __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
     for (int e = 0; e < 256; e += 4)
       L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
   });
+  }
 }
 
 // ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
 template <class Chain>
 __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
+  if constexpr (Chain::MAP_ILP > 1) {
+    pipe_isse_ilp_body<Chain>(a);
+    return;
+  } else {
   constexpr unsigned G = Chain::PIPE_G;
   __shared__ unsigned tab[512 * G];
   __shared__ typename PipeSquashFor<Chain>::type squash;
@@ -1345,6 +1357,7 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
     for (int e = 0; e < 512; e += 4)
       L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
   });
+  }
 }
 
 // =====================================================================================================
@@ -1355,6 +1368,208 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
 // weights.
 typedef uint4 __attribute__((aligned(4))) pipe_u128a4;
 typedef __attribute__((address_space(1))) pipe_u128a4 g_u128a4;
+
+// ---- ICM / ISSE maps with SEVERAL BLOCKS PER LANE (ZPAQ_AMD_PIPE_MAP_ILP=2) -------------------------------------------
+// A map's per-bit chain is serial (every bit reads the entry the bit before may have written) and a wavefront issues one
+// instruction every four cycles however few lanes are live, so a lone chain leaves most issue slots empty: alone, the ISSE
+// map needs 272 cycles per bit for 38 instructions.  With F blocks per lane (G / F live lanes, blocks lane and lane + G / F
+// ...) the F independent chains of a lane sit in one basic block and the compiler interleaves them: the same wavefront,
+// the same LDS table, F bits per pass.
+template <class Chain>
+__device__ __forceinline__ void pipe_icm_ilp_body(const PipeArgs& a) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr int F = Chain::MAP_ILP;
+  constexpr unsigned GL = G / (unsigned)F;                 // lanes that work
+  __shared__ unsigned tab[256 * G];
+  __shared__ PipeStretch stretch;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  static_for<0, Chain::NICM>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    constexpr int I = Chain::ICM_COMP[r];
+    constexpr CompK c = Chain::comp[I];
+    constexpr int ri = Chain::P_ROW[I];
+    PipeLane<Chain> L[F];
+    unsigned col[F], nbmax = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      col[f] = (unsigned)f * GL + (unsigned)lane;
+      L[f].open(a, g * G + ((unsigned)lane < GL ? col[f] : 0u), Chain::P_LEVEL[I]);
+      if ((unsigned)lane >= GL) { L[f].live = false; L[f].nb = 0; }
+      nbmax = max(nbmax, L[f].nb);
+    }
+    if (L[0].chunk < 0 || !pipe_any(nbmax > 0)) return;
+    stretch.load(a.tb, lane);
+    __syncthreads();
+    if (!nbmax) return;
+    unsigned byte[F], s[F], v[F];
+    uint2 w[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      byte[f] = 0; s[f] = 0; v[f] = 0; w[f].x = 0u; w[f].y = 0u;
+      if (L[f].nb) {
+        for (int e = 0; e < 256; e += 4) {
+          const uint4 q = L[f].A128((unsigned)c.t0 + 4u * e);
+          tab[e * G + col[f]] = q.x; tab[(e + 1) * G + col[f]] = q.y; tab[(e + 2) * G + col[f]] = q.z; tab[(e + 3) * G + col[f]] = q.w;
+        }
+        byte[f] = L[f].byte_at(0);
+        w[f] = L[f].bh(ri, 0);
+        s[f] = pipe_bh_get(w[f], 0);
+        v[f] = tab[s[f] * G + col[f]];
+      }
+    }
+    for (unsigned k = 0; k < nbmax; ++k) {
+      unsigned byten[F];
+      uint2 wn[F];
+      bool on[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        on[f] = k < L[f].nb;
+        byten[f] = byte[f]; wn[f] = w[f];
+        if (on[f]) { const unsigned kn = L[f].next(k); byten[f] = L[f].byte_at(kn); wn[f] = L[f].bh(ri, kn); }
+      }
+      PipeP8 out[F];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        unsigned sn[F], vn[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          sn[f] = B < 7 ? pipe_bh_get(w[f], B + 1) : pipe_bh_get(wn[f], 0);
+          vn[f] = tab[sn[f] * G + col[f]];
+          out[f].set(B, stretch(v[f] >> 8));
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const unsigned nv = v[f] + (unsigned)((int)((unsigned)(pipe_y(byte[f], B) * 32767) - (v[f] >> 8)) >> 2);
+          if (on[f]) tab[s[f] * G + col[f]] = nv;
+          v[f] = sn[f] == s[f] ? nv : vn[f];
+          s[f] = sn[f];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (on[f]) L[f].p(I, k) = out[f].get();
+        byte[f] = byten[f]; w[f] = wn[f];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      if (L[f].nb)
+        for (int e = 0; e < 256; e += 4)
+          L[f].A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + col[f]], tab[(e + 1) * G + col[f]], tab[(e + 2) * G + col[f]], tab[(e + 3) * G + col[f]]);
+  });
+}
+
+template <class Chain>
+__device__ __forceinline__ void pipe_isse_ilp_body(const PipeArgs& a) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr int F = Chain::MAP_ILP;
+  constexpr unsigned GL = G / (unsigned)F;
+  __shared__ unsigned tab[512 * G];
+  __shared__ typename PipeSquashFor<Chain>::type squash;
+  const int lane = threadIdx.x & 63;
+  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
+  const unsigned wg = blockIdx.x + a.wg0;
+  const unsigned role = wg / ngroups, g = wg % ngroups;
+  static_for<0, Chain::NISSE>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if (role != (unsigned)r) return;
+    constexpr int I = Chain::ISSE_COMP[r];
+    constexpr CompK c = Chain::comp[I];
+    constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
+    PipeLane<Chain> L[F];
+    unsigned col[F], nbmax = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      col[f] = (unsigned)f * GL + (unsigned)lane;
+      L[f].open(a, g * G + ((unsigned)lane < GL ? col[f] : 0u), Chain::P_LEVEL[I]);
+      if ((unsigned)lane >= GL) { L[f].live = false; L[f].nb = 0; }
+      nbmax = max(nbmax, L[f].nb);
+    }
+    if (L[0].chunk < 0 || !pipe_any(nbmax > 0)) return;
+    squash.load(a.tb, lane);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      if (L[f].nb)
+        for (int e = 0; e < 512; e += 4) {
+          const uint4 q = L[f].A128((unsigned)c.t0 + 4u * e);
+          tab[e * G + col[f]] = q.x; tab[(e + 1) * G + col[f]] = q.y; tab[(e + 2) * G + col[f]] = q.z; tab[(e + 3) * G + col[f]] = q.w;
+        }
+    __syncthreads();
+    if (!nbmax) return;
+    unsigned byte[F], s[F];
+    int w0[F], w1[F];
+    uint2 w[F];
+    uint4 vj[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      byte[f] = 0; s[f] = 0; w0[f] = 0; w1[f] = 0; w[f].x = 0u; w[f].y = 0u; vj[f] = make_uint4(0u, 0u, 0u, 0u);
+      if (L[f].nb) {
+        byte[f] = L[f].byte_at(0);
+        w[f] = L[f].bh(ri, 0);
+        vj[f] = L[f].p(J, 0);
+        s[f] = pipe_bh_get(w[f], 0);
+        w0[f] = (int)tab[(2u * s[f]) * G + col[f]];
+        w1[f] = (int)tab[(2u * s[f] + 1u) * G + col[f]];
+      }
+    }
+    for (unsigned k = 0; k < nbmax; ++k) {
+      unsigned byten[F];
+      uint2 wn[F];
+      uint4 vjn[F];
+      bool on[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        on[f] = k < L[f].nb;
+        byten[f] = byte[f]; wn[f] = w[f]; vjn[f] = vj[f];
+        if (on[f]) { const unsigned kn = L[f].next(k); byten[f] = L[f].byte_at(kn); wn[f] = L[f].bh(ri, kn); vjn[f] = L[f].p(J, kn); }
+      }
+      PipeP8 out[F];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        // every chain's table reads first, then every chain's arithmetic: one chain's LDS round trip runs under the others' work
+        unsigned sn[F];
+        int n0[F], n1[F], pj[F], sq[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          sn[f] = B < 7 ? pipe_bh_get(w[f], B + 1) : pipe_bh_get(wn[f], 0);
+          n0[f] = (int)tab[(2u * sn[f]) * G + col[f]];
+          n1[f] = (int)tab[(2u * sn[f] + 1u) * G + col[f]];
+          pj[f] = pipe_p_get(vj[f], B);
+          const int pr = sp_clamp2k((__mul24(w0[f], pj[f]) + w1[f] * 64) >> 16);          // 20-bit x 12-bit
+          out[f].set(B, pr);
+          sq[f] = squash(pr);
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const int err = pipe_y(byte[f], B) * 32767 - sq[f];
+          const int u0 = sp_clamp512k(w0[f] + ((__mul24(err, pj[f]) + (1 << 12)) >> 13));
+          const int u1 = sp_clamp512k(w1[f] + ((err + 16) >> 5));
+          if (on[f]) {
+            tab[(2u * s[f]) * G + col[f]] = (unsigned)u0;
+            tab[(2u * s[f] + 1u) * G + col[f]] = (unsigned)u1;
+          }
+          w0[f] = sn[f] == s[f] ? u0 : n0[f];
+          w1[f] = sn[f] == s[f] ? u1 : n1[f];
+          s[f] = sn[f];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (on[f]) L[f].p(I, k) = out[f].get();
+        byte[f] = byten[f]; w[f] = wn[f]; vj[f] = vjn[f];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      if (L[f].nb)
+        for (int e = 0; e < 512; e += 4)
+          L[f].A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + col[f]], tab[(e + 1) * G + col[f]], tab[(e + 2) * G + col[f]], tab[(e + 3) * G + col[f]]);
+  });
+}
 
 template <int QL>
 __device__ __forceinline__ int pipe_group_sum(int v) {

@@ -276,6 +276,7 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.mix_depth = v; }
   bool mix_bits_ok = true;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_FULL_SQUASH")) L.full_squash = atoi(e) != 0;
+  if (const char* e = getenv("ZPAQ_AMD_PIPE_MAP_ILP")) { const int v = atoi(e); if ((v == 2 || v == 4) && L.G % v == 0 && L.G / v >= 1) L.map_ilp = v; }
   if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_NIBBLES")) L.row_nibbles = atoi(e) != 0 && L.G <= 32;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_FLAT")) L.row_flat = atoi(e) != 0;
   if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.row_depth = v; }
@@ -422,7 +423,7 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   arr("LIGHT_KIND", lk.data(), (int)lk.size());
   arr("LIGHT_COMP", lc.data(), (int)lc.size());
   arr("LIGHT_SUB", L.light_sub.data(), (int)L.light_sub.size());
-  o << "  static constexpr int LIGHT_THREADS = " << L.light_threads() << ", FULL_SQUASH = " << L.full_squash << ";\n";
+  o << "  static constexpr int LIGHT_THREADS = " << L.light_threads() << ", FULL_SQUASH = " << L.full_squash << ", MAP_ILP = " << L.map_ilp << ";\n";
   o << "  static constexpr int LIGHT_DEPTH = " << L.light_depth << ", ROW_NIBBLES = " << L.row_nibbles << ", ROW_DEPTH = " << L.row_depth << ", ROW_FLAT = " << L.row_flat << ";\n";
   arr("ROW_COMP", L.rows.data(), (int)L.rows.size());
   arr("ICM_COMP", L.icm.data(), (int)L.icm.size());

@@ -48,6 +48,7 @@ struct PipeLayout {
   int mix_depth = 3;           // bytes a bit-lane MIX fetches ahead (ZPAQ_AMD_PIPE_MIX_DEPTH, 1..4)
   // CM / MIX2 / SSE with a lane per (block, bit position): workgroups of 64 lanes = 8 blocks, G / 8 of them per group and unit (ZPAQ_AMD_PIPE_LIGHT_BITS=7; off
   // by default: emulator-exact, not yet measured on the MI355X)
+  int map_ilp = 1;             // blocks per lane in the ICM / ISSE maps (ZPAQ_AMD_PIPE_MAP_ILP=2|4; experimental, off = 1)
   int full_squash = 0;         // squash from the whole 4096-entry table in LDS (ZPAQ_AMD_PIPE_FULL_SQUASH=1; experimental, off)
   int light_bits = 0;          // 1 CM | 2 MIX2 | 4 SSE
   int light_depth = 3;         // bytes such a unit fetches ahead (ZPAQ_AMD_PIPE_LIGHT_DEPTH, 1..4)
