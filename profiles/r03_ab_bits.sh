@@ -2,7 +2,8 @@
 # First GPU call of the next round: A/B of the bit-lane units built at the end of round 2 (emulator-exact, never run on
 # the MI355X; off by default).  Parity first (a wrong kernel is not worth timing), then the headline with each knob.
 #   bash profiles/r03_prebuild_variants.sh          (here, CPU: the variants' code objects, so the GPU call never waits for hipRTC)
-#   gpurun --timeout 2400 -- 'bash profiles/r03_ab_bits.sh'
+#   gpurun --timeout 2700 -- 'bash profiles/r03_ab_bits.sh'          (about 45 GPU-minutes: ~40 bench runs of ~45 s, parity, two profiles,
+#                                                                    two traces; every step has its own timeout; summary in gpurun_out/r03ab/summary.txt)
 # Knobs (host/codegen.cpp, part of the generated source and therefore of the cache key; unseen variants go through hipRTC):
 #   ZPAQ_AMD_PIPE_MIX_BITS=1     MIX with a lane per (block, bit position, weight quad)   ZPAQ_AMD_PIPE_MIX_DEPTH=1..4 (3)
 #   ZPAQ_AMD_PIPE_LIGHT_BITS=m   1 CM | 2 MIX2 | 4 SSE with a lane per (block, bit position)   ZPAQ_AMD_PIPE_LIGHT_DEPTH=1..4 (3)
