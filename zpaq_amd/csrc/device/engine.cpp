@@ -921,17 +921,13 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
       j.out_cap = hb.out_cap;
       j.res_slot = (uint32_t)k;
       in_off_of[k] = i_off;
-      if (!pinned) {
-        if (hb.prefix_len) memcpy(stage + i_off, hb.prefix, hb.prefix_len);
-        if (hb.in_len) memcpy(stage + i_off + hb.prefix_len, hb.in, hb.in_len);
-      }
       out_off[k] = o_off;
       a_off += hb.plan->hdr().arena_bytes;
       i_off += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
       o_off += ((uint64_t)hb.out_cap + 63) & ~63ull;
     }
-    if (pinned) {
-      // the gather itself is a gigabyte of memcpy for a full batch: spread it over a few threads
+    {
+      // the gather is a gigabyte of memcpy for a full batch: one thread per 16 MiB, at most 8 (small batches: this thread alone)
       const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, cnt, (size_t)(in_bytes >> 24) + 1}));
       auto gather = [&](size_t t) {
         for (size_t k = t; k < cnt; k += nt) {
