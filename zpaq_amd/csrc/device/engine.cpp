@@ -937,8 +937,12 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
         }
       };
       std::vector<std::thread> pool;
-      for (size_t t = 1; t < nt; ++t) pool.emplace_back(gather, t);
+      size_t started = 1;
+      try {
+        for (; started < nt; ++started) pool.emplace_back(gather, started);
+      } catch (...) {}                                  // no more threads to be had: this one does the rest
       gather(0);
+      for (size_t t = started; t < nt; ++t) gather(t);
       for (auto& th : pool) th.join();
     }
     HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, in_bytes, hipMemcpyHostToDevice, e.stream));
