@@ -273,6 +273,12 @@ def test_unseen_headers_compile_side_by_side(zlib_, tmp_path, monkeypatch):
     arr2 = (C.c_void_p * len(more))(*[p._h for p in more])
     assert L.zpq_precompile(arr2, len(more), 0, 1) == 2, L.zpq_last_error()
     assert len(os.listdir(tmp_path)) == 10
+    # a cache directory that cannot be written: the code objects stay in the process (the loaders look there first)
+    monkeypatch.setenv("ZPAQ_AMD_SPEC_CACHE", "/proc/zpaq_amd_no_such_dir")
+    extra = [zlib_.Plan(zlib_.method_to_header(f"x0,0ci2,1,1c0,{150 + i}m16s")[0]) for i in range(2)]
+    arr3 = (C.c_void_p * len(extra))(*[p._h for p in extra])
+    assert L.zpq_precompile(arr3, len(extra), 0, 2) == 2, L.zpq_last_error()
+    assert L.zpq_precompile(arr3, len(extra), 0, 2) == 0
 
 
 # ---------------------------------------------------------------------------------------------------------
