@@ -118,8 +118,10 @@ def cpu_baseline(blocks, method, budget_s):
         done = [i for i, v in enumerate(lens) if v >= 0]
         return {"value": len(done) * bs / 1e6 / wall, "unit": "MB/s", "cores": threads, "kind": "reference",
                 "sample": f"{len(done)} x {bs} B blocks of the same corpus, libzpaq::compressBlock(\"{method}\") "
-                          f"(reference built -O3 with its x86 JIT) from a {threads}-thread work queue "
-                          f"(nproc={os.cpu_count()}, usable={cores}); 1 thread alone: {bs / 1e6 / t1:.3f} MB/s",
+                          f"(reference built {ref.build_flags()} with its x86 JIT) from a {threads}-thread work queue "
+                          f"(nproc={os.cpu_count()}, usable={cores}: the box's CPU quota, a full host would be about "
+                          f"{os.cpu_count() / max(cores, 1):.0f}x this); 1 thread alone: {bs / 1e6 / t1:.3f} MB/s",
+                "nproc": os.cpu_count(), "usable_cores": cores,
                 "single_thread_MBps": bs / 1e6 / t1}, archives
     # fallback: our scalar C port, single thread, a slice of one block
     import zpaq_amd as z
@@ -131,6 +133,87 @@ def cpu_baseline(blocks, method, budget_s):
     wall = time.time() - t0
     return {"value": k / 1e6 / wall, "unit": "MB/s", "cores": 1, "kind": "port",
             "sample": f"first {k} B of block 0 through oracle/zpaq_oracle.c (scalar, 1 thread)"}, None
+
+
+def cpu_decode_baseline(blocks, method, budget_s):
+    """Reference libzpaq::decompress (Decompresser, libzpaq.cpp:2247-2374) on this box's host cores over a bounded sample:
+    the archives are made by THIS library (bit-identical to the reference's, which the encode leg checks), decoded by the
+    reference from a work queue (a decode error fails the leg)."""
+    from oracle.oracle_py import Ref, have_ref
+    import zpaq_amd as z
+    if not have_ref():
+        return None
+    ref = Ref()
+    cores = usable_cores()
+    nb, bs = blocks.shape
+    one = z.compress_blocks([blocks[0]], method)
+    t1 = ref.decompress_blocks_mt(one, bs, 1)
+    sample = int(max(1, min(nb, (budget_s / max(t1, 1e-3)) * cores)))
+    threads = min(cores, sample)
+    archives = z.compress_blocks([blocks[i] for i in range(sample)], method)
+    wall = ref.decompress_blocks_mt(archives, bs, threads)
+    return {"value": sample * bs / 1e6 / wall, "unit": "MB/s", "cores": threads, "kind": "reference",
+            "sample": f"{sample} x {bs} B blocks of the same corpus (archives made by this library), libzpaq::decompress "
+                      f"(reference built {ref.build_flags()} with its x86 JIT) from a {threads}-thread work queue "
+                      f"(nproc={os.cpu_count()}, usable={cores}); 1 thread alone: {bs / 1e6 / t1:.3f} MB/s",
+            "nproc": os.cpu_count(), "usable_cores": cores, "single_thread_MBps": bs / 1e6 / t1}
+
+
+def in_library_bench(a, torch, z):
+    """--in-library: N GPUs driven by ONE process through the library's own engines (zpq_init(-1): one engine and one
+    host thread per device, the batch sharded contiguously by zpq_shard_range) -- the path a multi-threaded libzpaq
+    caller gets without torch.distributed.  The boundary is host buffers, so the figure is PCIe-inclusive."""
+    from zpaq_amd import corpus, corpus_torch
+    have = torch.cuda.device_count()
+    devs = os.environ.get("ZPAQ_AMD_DEVICES")
+    if not devs:
+        if have < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} requested but only {have} GPU(s) are visible on this box")
+        devs = os.environ["ZPAQ_AMD_DEVICES"] = ",".join(str(i) for i in range(a.gpus))
+    ndev = len([x for x in devs.split(",") if x.strip() != ""])
+    z.init(-1)
+    z.set_kernel(a.kernel)
+    total_blocks = a.blocks * ndev if a.scaling == "weak" else a.blocks
+    bs = a.block_bytes
+    dev0 = torch.device("cuda", 0)
+    if a.kind == "text":
+        host = np.empty((total_blocks, bs), np.uint8)
+        for b0 in range(0, total_blocks, 1024):
+            k = min(1024, total_blocks - b0)
+            host[b0:b0 + k] = corpus_torch.text_blocks(k, bs, corpus.BASE_SEED + b0, dev0).cpu().numpy()
+        torch.cuda.empty_cache()
+    else:
+        host = make_corpus(a.kind, total_blocks, bs, first=0)
+    rows = [host[i] for i in range(total_blocks)]
+    for _ in range(a.warmup):
+        z.compress_blocks(rows, a.method)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        archives = z.compress_blocks(rows, a.method)
+    wall = time.perf_counter() - t0
+    plan = z.Plan(z.method_to_header(z.expand_method(a.method, host[0]))[0])
+    algo = plan.algo_bytes_per_byte * float(total_blocks) * (bs + 1)
+    value = float(total_blocks) * bs * a.steps / 1e6 / wall
+    back = z.decompress(archives[0], bs + 64) == host[0].tobytes()
+    line = {"metric": f"compress MB/s + bit-identical ratio, -m{a.method} over {a.blocks}x{_size_name(bs)} blocks",
+            "value": value, "unit": "MB/s", "n_gpus": ndev, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"method \"{a.method}\" x {total_blocks} blocks x {bs} B '{a.kind}' through zpq_compress_blocks on HOST "
+                                   f"buffers, one process, in-library engines on devices {devs} (PCIe-inclusive)",
+                       "blocks_total": total_blocks, "block_bytes": bs, "corpus": a.kind, "method": a.method,
+                       "parallelism": f"in-library engines x{ndev}", "devices": devs},
+            "ratio": sum(len(x) for x in archives) / (float(total_blocks) * bs), "all_status_ok": True,
+            "roundtrip_verified_blocks": int(back),
+            "roofline": {"bound": "hbm", "achieved": algo * a.steps / 1e9 / wall, "peak": HBM_PEAK_GBS * ndev, "unit": "GB/s",
+                         "frac": algo * a.steps / 1e9 / wall / (HBM_PEAK_GBS * ndev), "traffic": None,
+                         "kernel": "whole zpq_compress_blocks call (wall clock, includes staging and PCIe)"},
+            "cpu_baseline": None}
+    if a.cpu_seconds > 0:
+        base, _ = cpu_baseline(host, a.method, a.cpu_seconds)
+        line["cpu_baseline"] = base
+        line["vs_cpu"] = value / base["value"] if base["value"] else None
+    print(json.dumps(line))
 
 
 def main():
@@ -151,22 +234,50 @@ def main():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
                     help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
-    ap.add_argument("--distribute", action="store_true",
-                    help="N>1: rank 0 generates the whole corpus and scatters it over RCCL; coded blocks are gathered back "
-                         "(timed separately as dist_ms; the hot path itself has no collective)")
+    ap.add_argument("--distribute", dest="distribute", action="store_true", default=None,
+                    help="N>1 (default there): rank 0 generates the whole corpus and scatters it over RCCL; coded blocks are "
+                         "gathered back (timed separately as dist_ms; the hot path itself has no collective)")
+    ap.add_argument("--no-distribute", dest="distribute", action="store_false",
+                    help="N>1: every rank generates its own blocks (no RCCL traffic but the barrier and the timing reduction)")
+    ap.add_argument("--in-library", action="store_true",
+                    help="N>1 in ONE process: zpq_init(-1), one engine per device inside the library, the host-buffer batch "
+                         "sharded over them (no torch.distributed)")
     a = ap.parse_args()
 
     import torch
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.in_library:
+        # `python bench.py --gpus N` by itself: one rank per GPU under torch.distributed.run (RCCL over xGMI)
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} requested but only {have} GPU(s) are visible on this box")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     import zpaq_amd as z
 
+    if a.in_library:
+        return in_library_bench(a, torch, z)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch N ranks (python -m torch.distributed.run "
+                 f"--nproc-per-node N bench.py --gpus N ...) or run `python bench.py --gpus N`, which does that itself")
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} GPU(s) are visible")
+    if a.distribute is None:
+        a.distribute = world > 1
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     z.init(local)
@@ -183,14 +294,21 @@ def main():
     dist_ms = {}
     if a.distribute and world > 1:
         from zpaq_amd import dist as zd
-        full = make_corpus(a.kind, total_blocks, bs, first=0) if rank == 0 else None
+        full = None
+        if rank == 0 and a.kind == "text":        # generated on rank 0's GPU, scattered device to device
+            from zpaq_amd import corpus, corpus_torch
+            full = corpus_torch.text_blocks(total_blocks, bs, corpus.BASE_SEED, dev)
+        elif rank == 0:
+            full = make_corpus(a.kind, total_blocks, bs, first=0)
         zd.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
         mine = zd.scatter_blocks(full, total_blocks, bs)
         torch.cuda.synchronize(); zd.barrier()
         dist_ms["scatter"] = (time.perf_counter() - t0) * 1e3
+        dist_ms["scatter_bytes"] = int(total_blocks) * bs
         blocks = mine.cpu().numpy()
         nb = blocks.shape[0]
-        del full
+        del full, mine
+        torch.cuda.empty_cache()
     elif a.kind == "text":
         # same bytes as corpus.zipf_text, generated on this rank's GPU (seconds instead of minutes of host time)
         from zpaq_amd import corpus, corpus_torch
@@ -339,6 +457,8 @@ def main():
         dist_ms["gather"] = (time.perf_counter() - t0) * 1e3
         if rank == 0:
             assert len(allc) == total_blocks
+            dist_ms["gather_bytes"] = sum(len(x) for x in allc)
+        del allc
     ok = bool((status == 0).all())
     coded_total = int(out_len.sum())
 
@@ -416,7 +536,7 @@ def main():
                      "kernel": kname, "kernel_origin": origin,
                      "algo_bytes_per_launch": algo_bytes, "kernel_s_per_launch": code_s},
     }
-    if rank == 0 and world == 1:
+    if rank == 0:
         # coded payloads of the timed run, for the identity check against the reference
         ncmp = min(nb, 512)
         host_out = d_out[:ncmp].cpu().numpy()
@@ -425,7 +545,7 @@ def main():
         # ---- end-to-end through the drop-in API on host buffers (SURVEY 8(d)'s metric), outside the timed region ----
         api_archives = None
         napi = nb if a.api_blocks < 0 else min(a.api_blocks, nb)
-        if napi and a.mode == "encode":
+        if napi and a.mode == "encode" and world == 1:
             t0 = time.perf_counter()
             api_archives = z.compress_blocks([blocks[i] for i in range(napi)], a.method)
             wall = time.perf_counter() - t0
@@ -436,7 +556,11 @@ def main():
                                    "staging + H2D, Predictor init + coding kernels, D2H, archive framing",
                            "ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3],
                                   "kernel_init": ph[4], "kernel_code": ph[5], "python_wall": wall * 1e3}}
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and a.mode == "decode":
+            base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
+            line["cpu_baseline"] = base
+            line["vs_cpu"] = value / base["value"] if base and base["value"] else None
+        elif a.cpu_seconds > 0:
             base, ref_arch = cpu_baseline(blocks, a.method, a.cpu_seconds)
             line["cpu_baseline"] = base
             if ref_arch is not None:
@@ -463,12 +587,12 @@ def main():
             line["vs_cpu"] = value / base["value"] if base["value"] else None
         else:
             line["cpu_baseline"] = None
-    elif rank == 0:
-        line["cpu_baseline"] = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()            # the other ranks wait here while rank 0 times the CPU reference
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

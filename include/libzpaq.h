@@ -9,10 +9,11 @@
 // What is here:   Reader, Writer, error(), toU16, Array<T>, SHA1, StringBuffer,
 //                 compress(), compressBlock(), decompress(), Compressor,
 //                 Decompresser, plus the batched extension compressBlocks().
+//                 Every method compressBlock() accepts is served: levels 0-5,
+//                 explicit x/s methods, the LZ77 / BWT / E8E9 pre-processors and
+//                 the PCOMP post-processors they put into the archive.
 // What is not:    encryption (AES_CTR / stretchKey are declared so that zpaq.cpp
-//                 links, and call error()) and the LZ77/BWT/E8E9
-//                 pre/post-processors; methods that need the latter report
-//                 through error() instead of writing a different archive.
+//                 links, and call error()).
 //
 // Threading: like the reference, every function is re-entrant; calls from many
 // threads are serialised on the device queue.  error() must not return (it may

@@ -29,11 +29,27 @@ def _bytes_arr(b) -> np.ndarray:
     return np.frombuffer(bytes(b), dtype=np.uint8).copy() if len(b) else np.zeros(0, np.uint8)
 
 
+def _cpu_has_v3() -> bool:
+    """AVX2 + BMI2 + FMA on the CPU this runs on (the -march=x86-64-v3 build of the reference needs them)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("flags"):
+                f = set(ln.split(":", 1)[1].split())
+                return {"avx2", "bmi2", "fma", "movbe", "f16c"} <= f and ("abm" in f or "lzcnt" in f)
+    except Exception:
+        pass
+    return False
+
+
 class Ref:
     """The compiled reference (JIT build by default, nojit=True for the interpreter)."""
 
     def __init__(self, nojit: bool = False):
         name = "libzpaq_ref_nojit.so" if nojit else "libzpaq_ref.so"
+        self.flags = "-O3 -Dunix" + (" -DNOJIT" if nojit else "")
+        if not nojit and os.path.exists(os.path.join(_HERE, "_ref", "libzpaq_ref_v3.so")) and _cpu_has_v3():
+            name = "libzpaq_ref_v3.so"
+            self.flags = "-O3 -march=x86-64-v3 -Dunix"
         path = os.path.join(_HERE, "_ref", name)
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} missing: run `make -C oracle` where /root/reference exists")
@@ -69,6 +85,10 @@ class Ref:
 
     def _err(self):
         return RuntimeError(self.lib.ref_last_error().decode("latin1"))
+
+    def build_flags(self) -> str:
+        """Compiler flags of the reference build that was loaded (for the cpu_baseline line)."""
+        return self.flags
 
     @staticmethod
     def _s(x):
@@ -180,6 +200,21 @@ class Ref:
         if keep:
             return s, list(lens), [out[b, :lens[b]].tobytes() if 0 <= lens[b] <= stride else None for b in range(nb)]
         return s, list(lens)
+
+
+    def decompress_blocks_mt(self, archives, block_bytes: int, nthreads: int) -> float:
+        """libzpaq::decompress over every archive (one ZPAQ block each) from an nthreads work queue; wall seconds."""
+        n = len(archives)
+        bufs = [np.frombuffer(a, dtype=np.uint8) for a in archives]
+        PA = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        LN = (C.c_size_t * n)(*[b.size for b in bufs])
+        f = self.lib.ref_decompress_blocks_mt
+        f.restype = C.c_double
+        f.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_int]
+        s = f(PA, LN, n, int(block_bytes), int(nthreads))
+        if s < 0:
+            raise self._err()
+        return s
 
 
 def have_ref() -> bool:

@@ -756,13 +756,19 @@ void engine_caller_leave() {
   b.cv.notify_all();
 }
 
-void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results, bool announced) {
+// `announced`: the caller told the queue it was coming (engine_caller_enter) and still owns that announcement; it is
+// withdrawn here, under the queue's lock, at the moment the blocks are queued -- and stays the caller's to withdraw if
+// anything throws before that.
+void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results, bool* announced) {
   Batcher& b = batcher();
   const int d = decode ? 1 : 0;
   Ticket me{&blocks, &results};
   std::unique_lock<std::mutex> lk(b.mu);
   b.queue[d].push_back(&me);
-  if (announced && b.approaching > 0) --b.approaching;
+  if (announced && *announced) {
+    if (b.approaching > 0) --b.approaching;
+    *announced = false;
+  }
   b.cv.notify_all();
   for (;;) {
     b.cv.wait(lk, [&] { return me.done || !b.leader[d]; });
@@ -775,22 +781,24 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
     std::vector<Ticket*> batch;
     batch.swap(b.queue[d]);
     lk.unlock();
+    // Everything the leader does for the others sits inside one try block: whatever throws (the merge's allocations
+    // included), every queued ticket is marked done with the error and the leader flag is cleared below.
     std::exception_ptr err;
-    if (batch.size() == 1) {
-      try { engine_code_host_now(decode, *batch[0]->blocks, *batch[0]->results); } catch (...) { err = std::current_exception(); }
-    } else {
-      std::vector<HostBlock> all;
-      for (Ticket* t : batch) all.insert(all.end(), t->blocks->begin(), t->blocks->end());
-      std::vector<BlockResult> res;
-      try {
+    try {
+      if (batch.size() == 1) {
+        engine_code_host_now(decode, *batch[0]->blocks, *batch[0]->results);
+      } else {
+        std::vector<HostBlock> all;
+        for (Ticket* t : batch) all.insert(all.end(), t->blocks->begin(), t->blocks->end());
+        std::vector<BlockResult> res;
         engine_code_host_now(decode, all, res);
         size_t pos = 0;
         for (Ticket* t : batch) {
           t->results->assign(res.begin() + (long)pos, res.begin() + (long)(pos + t->blocks->size()));
           pos += t->blocks->size();
         }
-      } catch (...) { err = std::current_exception(); }
-    }
+      }
+    } catch (...) { err = std::current_exception(); }
     lk.lock();
     for (Ticket* t : batch) { t->err = err; t->done = true; }
     b.leader[d] = false;
@@ -1076,7 +1084,7 @@ bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<Pc
   for (int attempt = 0; attempt < 2; ++attempt) {
     uint64_t in_bytes = 0, out_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
-      if (cap[i] > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
+      if (cap[i] > 0xFFFFFFF0ull) { note = "segment output beyond the device kernel's 32-bit range"; return false; }   // the host runs it (the size hint is a comment the reference ignores)
       in_bytes += ((uint64_t)segs[i].in_len + 63) & ~63ull;
       out_bytes += (cap[i] + 63) & ~63ull;
     }
@@ -1119,7 +1127,9 @@ bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<Pc
     HIP_CHECK(hipStreamSynchronize(e.stream));
     bool again = false;
     for (size_t i = 0; i < n; ++i) {
-      if (res[2 * i + 1]) fail(ZPQ_E_VM, "ZPAQL execution error");
+      // a device status is not a verdict: the translated program has a fixed budget of backward jumps, so the host
+      // post-processor (which owns the ZPAQL-error decision, like the reference's) runs these segments again
+      if (res[2 * i + 1]) { note = "device post-processor stopped (status " + std::to_string(res[2 * i + 1]) + "): host fallback"; return false; }
       if (res[2 * i] > cap[i]) { cap[i] = res[2 * i]; again = true; }
     }
     if (again && attempt == 0) continue;

@@ -48,7 +48,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false)
 // before it submits (or gives up), so that the batch leader waits for it.
 // announced = the caller called engine_caller_enter() before: the announcement is withdrawn once its blocks are queued
 void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::vector<BlockResult>& results,
-                      bool announced = false);
+                      bool* announced = nullptr);
 void engine_caller_enter();
 void engine_caller_leave();
 

@@ -50,10 +50,16 @@ zpq_plan* plan_for(PlanCache& cache, const std::vector<U8>& header) {
   }
   if (!p) {
     p = PlanPtr(plan_from_header(header.data(), header.size()), PlanDeleter());
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (g.map.size() >= 256) g.map.clear();           // data-dependent chains: bound the cache
-    auto ins = g.map.emplace(header, p);
-    p = ins.first->second;                            // another thread may have been faster
+    // data-dependent chains: bound the cache.  The evicted plans are destroyed AFTER the lock is dropped: releasing a
+    // plan frees device memory and unloads code objects (device-synchronising calls), which must not stall every other
+    // caller of plan_for.
+    std::map<std::vector<U8>, PlanPtr> evicted;
+    {
+      std::lock_guard<std::mutex> lk(g.mu);
+      if (g.map.size() >= 256) evicted.swap(g.map);
+      auto ins = g.map.emplace(header, p);
+      p = ins.first->second;                          // another thread may have been faster
+    }
   }
   cache.emplace(header, p);
   return p.get();
@@ -82,7 +88,7 @@ struct EncJob {
   U32 nseg = 0; const U32* seg_len = nullptr; U32* seg_out_end = nullptr;
 };
 
-void encode_jobs(std::vector<EncJob>& jobs, bool announced = false) {
+void encode_jobs(std::vector<EncJob>& jobs, bool* announced = nullptr) {
   std::vector<size_t> todo(jobs.size());
   for (size_t i = 0; i < jobs.size(); ++i) todo[i] = i;
   bool worst = false;
@@ -98,7 +104,6 @@ void encode_jobs(std::vector<EncJob>& jobs, bool announced = false) {
     }
     std::vector<BlockResult> res;
     engine_code_host(false, hb, res, announced);
-    announced = false;
     std::vector<size_t> again;
     for (size_t k = 0; k < todo.size(); ++k) {
       EncJob& j = jobs[todo[k]];
@@ -200,7 +205,7 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
                             work[b].sha1_on_device ? work[b].sha1 : nullptr, 0, nullptr, nullptr});
   const double t1 = now_ms();
   if (jobs.empty()) announce.off();
-  else { announce.on = false; encode_jobs(jobs, true); }    // the queue withdraws the announcement when our blocks are in it
+  else encode_jobs(jobs, &announce.on);       // the queue withdraws the announcement when our blocks are in it
   const double t2 = now_ms();
   const Timing dev = engine_last_timing();
   // 3. stitch the archives

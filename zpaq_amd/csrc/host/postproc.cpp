@@ -31,9 +31,17 @@ class PcompVm {
     memset(R_, 0, sizeof(R_));
     // The reference puts no limit on a program's run time (a damaged BWT stream makes its inverse loop for good).  The
     // standard programs need a few dozen steps per array element at most (inverse BWT at the end of a segment): 64 per
-    // element of H and M, and never less than 2^28, ends a hostile stream in about a second instead of a minute.
-    max_steps_ = std::max<U64>((U64)1 << 28, 64ull * ((U64)H_.size() + (U64)M_.size()));
+    // element of H and M, and never less than 2^28, ends a hostile stream in about a second instead of a minute.  That
+    // bound is only safe for programs whose cost is known, so it applies to the standard ones (set_standard(true)); a
+    // custom program keeps 2^34 steps per call (about a minute), or ZPAQ_AMD_PCOMP_MAX_STEPS if the caller sets it --
+    // the one deviation from the reference here, which would never give up.
+    max_steps_ = (U64)1 << 34;
+    if (const char* e = getenv("ZPAQ_AMD_PCOMP_MAX_STEPS")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) max_steps_ = v; }
+    tight_steps_ = std::max<U64>((U64)1 << 28, 64ull * ((U64)H_.size() + (U64)M_.size()));
   }
+
+  // a program whose cost per input is known (one of the standard LZ77 / BWT / E8E9 inverses): the tight bound applies
+  void set_standard(bool yes) { if (yes) max_steps_ = std::min(max_steps_, tight_steps_); }
 
   void run(U32 input) {
     U32 pc = 0;
@@ -132,7 +140,7 @@ class PcompVm {
   std::vector<U8> M_;
   U32 R_[256];
   U32 hmask_ = 0, mmask_ = 0;
-  U64 max_steps_ = 0;
+  U64 max_steps_ = 0, tight_steps_ = 0;
   U32 a_ = 0, b_ = 0, c_ = 0, d_ = 0;
   bool f_ = false;
 };
@@ -153,18 +161,18 @@ struct PostProcessor::Impl {
   size_t segments = 0;
   bool native_first = false;
   std::vector<U8> replay;
-  PcompVm& machine() {
-    if (!vm) vm.reset(new PcompVm(prog.data(), prog.size(), ph, pm, sink));
-    return *vm;
-  }
+  PcompVm& machine();
 };
 
 namespace {
-const PcompStd* translated(const std::vector<U8>& prog, int ph, int pm) {
-  if (getenv("ZPAQ_AMD_PCOMP_INTERPRET")) return nullptr;
+const PcompStd* standard_program(const std::vector<U8>& prog, int ph, int pm) {
   for (const PcompStd* e = kPcompStd; e->code; ++e)
     if (e->len == prog.size() && e->ph == ph && e->pm == pm && memcmp(e->code, prog.data(), prog.size()) == 0) return e;
   return nullptr;
+}
+const PcompStd* translated(const std::vector<U8>& prog, int ph, int pm) {
+  if (getenv("ZPAQ_AMD_PCOMP_INTERPRET")) return nullptr;
+  return standard_program(prog, ph, pm);
 }
 
 // one segment through a translated program on a fresh machine; false = it reported an error (the caller interprets)
@@ -179,6 +187,14 @@ bool run_translated(const PcompStd& e, const U8* p, size_t n, std::vector<U8>& o
   return e.run(st, p, n, true, out) == 0;
 }
 }  // namespace
+
+PcompVm& PostProcessor::Impl::machine() {
+  if (!vm) {
+    vm.reset(new PcompVm(prog.data(), prog.size(), ph, pm, sink));
+    vm->set_standard(standard_program(prog, ph, pm) != nullptr);
+  }
+  return *vm;
+}
 
 PostProcessor::PostProcessor(int ph, int pm) : impl_(new Impl) { impl_->ph = ph; impl_->pm = pm; }
 PostProcessor::~PostProcessor() { delete impl_; }

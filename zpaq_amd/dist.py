@@ -29,20 +29,21 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def scatter_blocks(blocks: Optional[np.ndarray], nblocks: int, block_bytes: int, root: int = 0) -> torch.Tensor:
-    """Root passes the whole corpus [nblocks, block_bytes] (uint8); every rank receives its slice.
+def scatter_blocks(blocks, nblocks: int, block_bytes: int, root: int = 0) -> torch.Tensor:
+    """Root passes the whole corpus [nblocks, block_bytes] (uint8: a numpy array, or a torch tensor that may already be
+    on the device); every rank receives its slice.
 
     Grouped point-to-point sends (ncclSend/ncclRecv under RCCL): per-rank slices differ in size
     when nblocks is not a multiple of the world size, which scatter() cannot express.
     """
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return torch.from_numpy(np.ascontiguousarray(blocks))
+        return blocks if isinstance(blocks, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blocks))
     rank, world = dist.get_rank(), dist.get_world_size()
     b, e = shard_range(nblocks, rank, world)
     dev = _dev()
     mine = torch.empty((e - b, block_bytes), dtype=torch.uint8, device=dev)
     if rank == root:
-        full = torch.from_numpy(np.ascontiguousarray(blocks)).to(dev)
+        full = (blocks if isinstance(blocks, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blocks))).to(dev)
         ops = []
         for r in range(world):
             rb, re = shard_range(nblocks, r, world)
