@@ -40,6 +40,10 @@ import time
 
 import numpy as np
 
+# the encoder's seven streams want a hardware queue each (zpaq_amd/csrc/device/engine.cpp); read when HIP initialises,
+# which torch does before the library is loaded
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -493,7 +497,7 @@ def main():
     # which kernel coded the blocks (4 pipelined encoder, 3 per-header wavefront kernel, 2 generic wave, 1 generic one-lane)
     note = C.create_string_buffer(512)
     dec = 1 if a.mode == "decode" else 0
-    kinds = sorted({int(L.zpq_plan_kernel_kind2(pl._h, dec, note, 512)) for pl, _ in groups})
+    kinds = sorted({int(L.zpq_plan_kernel_kind3(pl._h, dec, len(idx), note, 512)) for pl, idx in groups})
     kname = {4: "zpq_pipe_{hcomp,rows,light,icm,isse,mix}: one launch of each per step, concurrent",
              3: "zpq_spec_" + ("decode" if dec else "encode"), 2: "code_wave_kernel", 1: "code_serial_kernel"}.get(kinds[-1], "?")
     origin = note.value.decode(errors="replace")

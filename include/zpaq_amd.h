@@ -94,9 +94,15 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * [3] units in the light kernel, [4] ICM maps, [5] ISSE maps, [6] MIX wavefronts per group, [7] blocks per HCOMP
  * workgroup, [8] highest dataflow level (a batch of L-byte blocks takes ceil(L / chunk) + out[8] steps),
  * [9] blocks per group (= threads per workgroup of every kernel but hcomp, which has 64), [10] ROW units,
- * [11] threads per workgroup of the mix kernel, [12] of the rows kernel, [13] of the light kernel. */
+ * [11] threads per workgroup of the mix kernel, [12] of the rows kernel, [13] of the light kernel.
+ * The encoder has two shapes per chain: mode 0 "throughput" (a lane per block; batches that fill the GPU) and mode 1
+ * "latency" (MIX / CM / MIX2 with a lane per bit position as well; the engine uses it for chains with at most 384 blocks
+ * in the batch).  The plain calls give mode 0; the _opts calls take the mode and, for tests, the chunk (bytes per step,
+ * 0 = 512) and the group (blocks per wavefront, 0 = 32). */
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
+int zpq_plan_pipe_source_opts(const zpq_plan*, int mode, int chunk, int group, char* src, size_t cap, size_t* len, char key41[41]);
+int zpq_plan_pipe_layout_opts(const zpq_plan*, int mode, int chunk, int group, uint64_t out[16]);
 /* The same for a block's PCOMP post-processing program (device/pcomp_kernel.h: LZ77 / BWT / E8E9 inverses run one
  * lane per segment on the device when a batch has enough of them): code = the PCOMP bytes without their 2-byte
  * length, ph / pm = header bytes 4 and 5. */
@@ -123,6 +129,8 @@ const uint8_t* zpq_plan_blob(const zpq_plan*, size_t* len);
  * specialised kernel came from ("cache:<key>" / "hiprtc") or why it is not used. */
 int zpq_plan_kernel_kind(zpq_plan*, char* note, size_t cap);            /* compression */
 int zpq_plan_kernel_kind2(zpq_plan*, int decode, char* note, size_t cap);
+/* ... for a batch that holds nblocks blocks of this plan (the encoder's mode and the decoder's workgroup shape depend on it) */
+int zpq_plan_kernel_kind3(zpq_plan*, int decode, uint32_t nblocks, char* note, size_t cap);
 /* Directories used by the specialisation cache / hipRTC include path. */
 const char* zpq_spec_cache_dir(void);
 const char* zpq_spec_include_dir(void);
@@ -218,6 +226,8 @@ int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t ca
 /* ---- host-side pieces of the boundary, exposed for reuse and for tests ---- */
 /* SHA1 (libzpaq.h:934-954). */
 void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]);
+/* tests: 1 = hash with the portable compression function instead of the x86 SHA extensions (0 = back to automatic) */
+void zpq_sha1_force_portable(int yes);
 /* compressBlock's level->method expansion (libzpaq.cpp:7579-7691), including
  * level-5 period detection on the data.  Writes a NUL-terminated "x..." /
  * "0..." string. */

@@ -53,7 +53,7 @@ def prebuild(cfg):
     for name, env in cfg["variants"]:
         knob_env(env)
         for h in headers:
-            src, key = pb.pipe_source_and_key(h)
+            src, key = pb.pipe_source_and_key(h, 1 if env.get("ZPAQ_AMD_PIPE_MODE") == "latency" else 0)
             if src is None:
                 print(f"{name}: no pipelined encoder ({key})")
                 continue
@@ -147,7 +147,7 @@ def main():
             res = d_res.cpu().numpy()
             ok = bool((res[:, 2] == 0).all())
             note = C.create_string_buffer(512)
-            kd = int(L.zpq_plan_kernel_kind2(next(iter(plans.values()))._h, 0, note, 512))
+            kd = int(L.zpq_plan_kernel_kind3(next(iter(plans.values()))._h, 0, nb, note, 512))
             if ref_out is None:
                 ref_out, ref_len = d_out.clone(), res[:, 0].copy()
                 same = True

@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")    # as the library sets it when it is loaded before HIP starts (engine.cpp)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

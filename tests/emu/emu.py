@@ -92,22 +92,17 @@ def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int
 
 
 # ---- the pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h) ----
-def pipe_source(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None,
-                mix_bits: int | None = None, mix_depth: int | None = None,
-            light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None) -> str:
+def pipe_source(header: bytes, chunk: int | None = None, group: int | None = None, mode: int = 0) -> str:
+    """Generated source of the pipelined encoder: mode 0 = throughput (lane per block, SSE per bit position),
+    1 = latency (MIX / CM / MIX2 per bit position as well); chunk / group: bytes per step / blocks per wavefront."""
     import zpaq_amd as z
     L = z.lib()
-    L.zpq_plan_pipe_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    L.zpq_plan_pipe_source_opts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
     plan = z.Plan(header)
     buf = C.create_string_buffer(4 << 20)
     ln = C.c_size_t(0)
     key = C.create_string_buffer(41)
-    with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group,
-              ZPAQ_AMD_PIPE_MIX_BITS=mix_bits, ZPAQ_AMD_PIPE_MIX_DEPTH=mix_depth,
-              ZPAQ_AMD_PIPE_LIGHT_BITS=light_bits, ZPAQ_AMD_PIPE_LIGHT_DEPTH=light_depth,
-              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat, ZPAQ_AMD_PIPE_MAP_ILP=map_ilp):
-        rc = L.zpq_plan_pipe_source(plan._h, buf, len(buf), C.byref(ln), key)
+    rc = L.zpq_plan_pipe_source_opts(plan._h, int(mode), int(chunk or 0), int(group or 0), buf, len(buf), C.byref(ln), key)
     if rc != 0:
         raise RuntimeError(L.zpq_last_error().decode())
     return buf.value.decode()
@@ -133,12 +128,9 @@ class _env:
                 os.environ[k] = v
 
 
-def pipe_build(header: bytes, chunk: int | None = None, mix_lanes: int | None = None, group: int | None = None,
-               mix_bits: int | None = None, mix_depth: int | None = None,
-            light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None) -> str:
+def pipe_build(header: bytes, chunk: int | None = None, group: int | None = None, mode: int = 0) -> str:
     import zpaq_amd as z
-    src = pipe_source(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat, map_ilp)
+    src = pipe_source(header, chunk, group, mode)
     dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
     deps = b"".join(open(p, "rb").read() for p in (
         os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"),
@@ -163,12 +155,10 @@ def pipe_build(header: bytes, chunk: int | None = None, mix_lanes: int | None = 
     return exe
 
 
-def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, mix_lanes: int | None = None,
-             out_cap: int | None = None, group: int | None = None, mix_bits: int | None = None, mix_depth: int | None = None,
-            light_bits: int | None = None, light_depth: int | None = None,
-            row_nibbles: int | None = None, row_depth: int | None = None, full_squash: int | None = None, row_flat: int | None = None, map_ilp: int | None = None):
+def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, out_cap: int | None = None,
+             group: int | None = None, mode: int = 0):
     """Encode every input as one block with the pipelined encoder.  Returns [(bytes, status, consumed)]."""
-    exe = pipe_build(header, chunk, mix_lanes, group, mix_bits, mix_depth, light_bits, light_depth, row_nibbles, row_depth, full_squash, row_flat, map_ilp)
+    exe = pipe_build(header, chunk, group, mode)
     cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
     with tempfile.TemporaryDirectory(dir=BUILD) as td:
         hp = os.path.join(td, "h.bin")
@@ -178,12 +168,8 @@ def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, mix
             p = os.path.join(td, f"in{i}")
             open(p, "wb").write(bytes(d))
             paths.append(p)
-        with _env(ZPAQ_AMD_PIPE_CHUNK=chunk, ZPAQ_AMD_PIPE_MIX_LANES=mix_lanes, ZPAQ_AMD_PIPE_GROUP=group,
-                  ZPAQ_AMD_PIPE_MIX_BITS=mix_bits, ZPAQ_AMD_PIPE_MIX_DEPTH=mix_depth,
-              ZPAQ_AMD_PIPE_LIGHT_BITS=light_bits, ZPAQ_AMD_PIPE_LIGHT_DEPTH=light_depth,
-              ZPAQ_AMD_PIPE_ROW_NIBBLES=row_nibbles, ZPAQ_AMD_PIPE_ROW_DEPTH=row_depth, ZPAQ_AMD_PIPE_FULL_SQUASH=full_squash, ZPAQ_AMD_PIPE_ROW_FLAT=row_flat, ZPAQ_AMD_PIPE_MAP_ILP=map_ilp):
-            r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), *paths],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+        r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), str(int(mode)), str(int(chunk or 0)), str(int(group or 0)), *paths],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
         if r.returncode != 0:
             raise RuntimeError(f"pipe emulator failed ({r.returncode}): {r.stderr[-2000:]}")
         res = []

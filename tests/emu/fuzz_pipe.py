@@ -59,9 +59,7 @@ for case in range(ncase):
     except Exception as e:
         continue
     inputs = [b"\0" + make_data(r, case * 10 + i) for i in range(r.choice([1, 3, 5]))] + ([b""] if r.random() < 0.3 else [])
-    kw = dict(chunk=64, mix_bits=r.choice([0, 1, 1]), mix_depth=r.choice([1, 2, 3]), light_bits=r.choice([0, 7, 7, 5]), light_depth=r.choice([1, 2, 3]),
-              row_nibbles=r.choice([0, 1, 1]), row_depth=r.choice([1, 2, 3]), full_squash=r.choice([0, 1]), row_flat=r.choice([0, 1]),
-              map_ilp=r.choice([1, 2, 4]))
+    kw = dict(chunk=64, mode=r.choice([0, 1]))
     if len(sys.argv) > 3 and sys.argv[3] == "wavefront":
         # the per-header wavefront kernel (spec_kernel.h) in both directions instead: encode == oracle, decode(oracle) == input
         waves = r.choice([4, 8])
@@ -75,7 +73,6 @@ for case in range(ncase):
         if not ok: print("CASE", seed0, case, "MISMATCH (wavefront kernel)"); print(cfg)
         bad += not ok; done += 1
         continue
-    if len(sys.argv) > 3 and sys.argv[3] == "default": kw = dict(chunk=64)          # the product's own configuration
     if r.random() < 0.2: kw["group"] = r.choice([8, 16])
     try:
         res = emu.pipe_run(header, inputs, **kw)

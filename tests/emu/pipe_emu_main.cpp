@@ -70,10 +70,12 @@ void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 5) { fprintf(stderr, "usage: pipe_emu_run <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
+  if (argc < 8) { fprintf(stderr, "usage: pipe_emu_run <header.bin> <out_cap> <out_prefix> <mode> <chunk> <group> <input>...\n"); return 2; }
   const std::vector<uint8_t> header = slurp(argv[1]);
   const uint32_t out_cap = (uint32_t)strtoul(argv[2], nullptr, 10);
   const std::string prefix = argv[3];
+  const int mode = atoi(argv[4]), chunk = atoi(argv[5]), group = atoi(argv[6]);
+  argv += 3; argc -= 3;                    // the inputs follow
   const unsigned nb = (unsigned)(argc - 4);
 
   zpq_plan* plan = nullptr;
@@ -82,7 +84,7 @@ int main(int argc, char** argv) {
   const uint8_t* blob = zpq_plan_blob(plan, &blob_len);
   const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
   uint64_t lay[16];
-  if (zpq_plan_pipe_layout(plan, lay) != 0) { fprintf(stderr, "layout: %s\n", zpq_last_error()); return 2; }
+  if (zpq_plan_pipe_layout_opts(plan, mode, chunk, group, lay) != 0) { fprintf(stderr, "layout: %s\n", zpq_last_error()); return 2; }
   const uint64_t group_bytes = lay[0];
   const unsigned C = (unsigned)lay[2], nlight = (unsigned)lay[3], nicm = (unsigned)lay[4], nisse = (unsigned)lay[5],
                  mixw = (unsigned)lay[6], hl = (unsigned)lay[7], maxlevel = (unsigned)lay[8], G = (unsigned)lay[9], nrows = (unsigned)lay[10],

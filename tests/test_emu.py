@@ -118,15 +118,21 @@ def _pipe_check(oracle, header, inputs, **kw):
 
 def test_pipe_encoder_standard_chains(zlib_, oracle):
     """-m4 / -m5 chains, ragged blocks incl. empty and one-byte inputs, several chunks per block, more blocks than
-    one group, and every workgroup width the generator supports."""
+    one group, every workgroup width the generator supports -- in both shapes of the encoder (mode 0: a lane per block,
+    what a batch that fills the GPU runs; mode 1: MIX / CM / MIX2 with a lane per bit position, what small batches run)."""
     blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
     h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
     h4, _, _ = zlib_.method_to_header(zlib_.expand_method("4", blk))
     kinds = ["text", "lcg", "zeros", "records", "pattern"]
     ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
-    _pipe_check(oracle, h5, ragged + [b""], chunk=64)
-    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64)
-    _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16)
+    src0, src1 = emu.pipe_source(h5, 64, mode=0), emu.pipe_source(h5, 64, mode=1)
+    assert "PIPE_MODE = 0, MIX_BITS = 0" in src0 and "NLIGHT = 9" in src0          # CM, MATCH, MIX2, 4 x SSE, MIX2, coder
+    assert "PIPE_MODE = 1, MIX_BITS = 1" in src1 and "NLIGHT = 15" in src1         # CM, MIX2 (20) and SSE as 4 workgroups of 64 lanes each
+    for mode in (0, 1):
+        _pipe_check(oracle, h5, ragged + [b""], chunk=64, mode=mode)
+        _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, mode=mode)
+        _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, mode=mode)
+        _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16, mode=mode)
 
 
 def test_pipe_encoder_every_component_type_and_legacy_models(oracle, golden):
@@ -139,7 +145,8 @@ def test_pipe_encoder_every_component_type_and_legacy_models(oracle, golden):
         d = gen_input(e).tobytes()
         if len(d) < 64:
             d = corpus.block("records", 600, 3).tobytes()
-        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64)
+        for mode in (0, 1):        # (legacy models: MIX lane groups of 2 and 4, several blocks per bit-lane wavefront)
+            _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, mode=mode)
     assert len(seen) >= 6
 
 
@@ -171,138 +178,26 @@ end
 
 
 def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
-    """The units fetch the next byte's table words before they store this byte's.  Tiny tables and contexts that
-    move by little from byte to byte take every aliasing path: same context (forwarding by bit position), contexts
-    closer than the address range of a byte (fetch after the stores), hash rows sharing a 64-byte line."""
+    """The units fetch the next bytes' table words before they store this byte's.  Tiny tables and contexts that
+    move by little from byte to byte take every aliasing path: same context (forwarding by bit position / from the lane's
+    own history), contexts closer than the address range of a byte (fetch after the stores: the bit-lane units' lanes meet
+    in memory there), hash rows sharing a 64-byte line.  Both shapes of the encoder."""
     header, _ = zlib_.assemble(PIPE_STRESS_CFG)
     r = np.random.default_rng(1)
     walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
     datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
              corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
-    _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64)
     # MATCH: long matches, a history buffer (1 KiB here) that wraps, candidates overlapping the byte being written
     rep = bytes(np.random.default_rng(5).integers(0, 256, 97, dtype=np.uint8)) * 40
     more = [rep, corpus.block("text", 1500, 3).tobytes() * 3, bytes(3000), b"abcabcabd" * 400, corpus.block("records", 4000, 8).tobytes()]
-    _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256)
-
-
-def test_pipe_encoder_mix_bit_lanes(zlib_, oracle, golden):
-    """ZPAQ_AMD_PIPE_MIX_BITS=1: the MIX unit with a lane per (block, bit position, weight quad) and rows fetched
-    MIX_DEPTH bytes ahead (pipe_kernel.h::pipe_mix_bits_body).  Same bytes as the oracle for the -m5 chain at every
-    depth, for the legacy models (lane groups of 2 and 4: several blocks per wavefront), for other group widths, and
-    for the stress chain whose 256-row MIX makes every pair of different contexts collide (the fetch-again path) while
-    equal contexts exercise the lane's own history."""
-    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
-    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
-    kinds = ["text", "lcg", "zeros", "records", "pattern"]
-    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
-    for depth in (1, 4):
-        assert "MIX_BITS = 1, MIX_DEPTH = %d" % depth in emu.pipe_source(h5, 64, None, None, 1, depth)
-        _pipe_check(oracle, h5, ragged + [b""], chunk=64, mix_bits=1, mix_depth=depth)
-    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, mix_bits=1)
-    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, mix_bits=1, mix_depth=2)
-    # legacy mid / max models and the nine-type config
-    seen = set()
-    for e in [golden["config_cases"][0]] + golden["level_cases"]:
-        header = bytes.fromhex(e["header"])
-        if header in seen or not header[6] or header[6] > 64:
-            continue
-        seen.add(header)
-        if "MIX_BITS = 1" not in emu.pipe_source(header, 64, None, None, 1, 3):
-            continue                            # no MIX, or one that does not keep the whole partial byte in its row index
-        d = gen_input(e).tobytes()
-        if len(d) < 64:
-            d = corpus.block("records", 600, 3).tobytes()
-        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, mix_bits=1)
-    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
-    r = np.random.default_rng(1)
-    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
-    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
-             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
-    for depth in (2, 4):
-        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mix_bits=1, mix_depth=depth)
-
-
-def test_pipe_encoder_light_bit_lanes(zlib_, oracle, golden):
-    """ZPAQ_AMD_PIPE_LIGHT_BITS=7 (1 CM | 2 MIX2 | 4 SSE): CM, MIX2 and SSE with a lane per (block, bit position), workgroups of 8 blocks x 8 positions,
-    unit, table words fetched LIGHT_DEPTH bytes ahead (pipe_kernel.h::pipe_cm_bits / pipe_mix2_bits / pipe_sse_bits) --
-    alone and together with the bit-lane MIX, on the -m5 chain, the legacy models and the stress chain whose tiny tables
-    make words of different contexts collide."""
-    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
-    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
-    kinds = ["text", "lcg", "zeros", "records", "pattern"]
-    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
-    src = emu.pipe_source(h5, 64, None, None, None, None, 7, 2)
-    assert "NLIGHT = 15" in src and "LIGHT_DEPTH = 2" in src           # CM, MIX2 (20) and SSE as 4 workgroups of 64 lanes each
-    for depth in (1, 4):
-        _pipe_check(oracle, h5, ragged + [b""], chunk=64, light_bits=7, light_depth=depth)
-    _pipe_check(oracle, h5, ragged, chunk=64, light_bits=7, light_depth=3, mix_bits=1, mix_depth=3)
-    _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, light_bits=7, mix_bits=1)
-    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, light_bits=7, light_depth=2)
-    seen = set()
-    for e in [golden["config_cases"][0]] + golden["level_cases"]:
-        header = bytes.fromhex(e["header"])
-        if header in seen or not header[6] or header[6] > 64:
-            continue
-        seen.add(header)
-        d = gen_input(e).tobytes()
-        if len(d) < 64:
-            d = corpus.block("records", 600, 3).tobytes()
-        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, light_bits=7, mix_bits=1)
-    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
-    r = np.random.default_rng(1)
-    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
-    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
-             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
-    for depth in (2, 4):
-        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, light_bits=7, light_depth=depth, mix_bits=1, mix_depth=depth)
-
-
-def test_pipe_encoder_row_nibble_lanes(zlib_, oracle, golden):
-    """ZPAQ_AMD_PIPE_ROW_NIBBLES=1: the ROW units with a lane per (block, nibble), candidate rows fetched ROW_DEPTH bytes
-    ahead (pipe_kernel.h::pipe_row_nibbles) -- alone and with every other experimental unit on.  The stress chain's hash
-    tables of 2 and 4 lines make the two nibbles of a byte share a line (second pass) and nearly every fetch stale; zeros
-    and the repeated patterns keep the context constant (fetch-again path on every byte)."""
-    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
-    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
-    kinds = ["text", "lcg", "zeros", "records", "pattern"]
-    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
-    assert "ROW_NIBBLES = 1, ROW_DEPTH = 3" in emu.pipe_source(h5, 64, row_nibbles=1, row_depth=3)
-    for depth in (1, 4):
-        _pipe_check(oracle, h5, ragged + [b""], chunk=64, row_nibbles=1, row_depth=depth)
-    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
-    _pipe_check(oracle, h5, ragged[:4], chunk=64, full_squash=1)            # ZPAQ_AMD_PIPE_FULL_SQUASH alone: whole squash table in LDS
-    _pipe_check(oracle, h5, ragged, chunk=64, row_flat=1)                   # ZPAQ_AMD_PIPE_ROW_FLAT: one-lane ROW unit, row picked by masks
-    # ZPAQ_AMD_PIPE_MAP_ILP: two / four blocks per lane in the ICM and ISSE maps (ragged lengths: the blocks of a lane end apart)
-    many = [b"\0" + corpus.block(kinds[i % 5], 40 + (i * 37) % 200, i).tobytes() for i in range(40)]
-    _pipe_check(oracle, h5, many, chunk=64, map_ilp=2)
-    _pipe_check(oracle, h5, ragged + [b""], chunk=64, map_ilp=4)
-    _pipe_check(oracle, h5, many[:20], chunk=64, map_ilp=2, **everything)
-    _pipe_check(oracle, h5, ragged, chunk=64, **everything)
-    _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, row_nibbles=1, row_depth=2)
-    seen = set()
-    for e in [golden["config_cases"][0]] + golden["level_cases"]:
-        header = bytes.fromhex(e["header"])
-        if header in seen or not header[6] or header[6] > 64:
-            continue
-        seen.add(header)
-        d = gen_input(e).tobytes()
-        if len(d) < 64:
-            d = corpus.block("records", 600, 3).tobytes()
-        _pipe_check(oracle, header, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, **everything)
-    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
-    r = np.random.default_rng(1)
-    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
-    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150),
-             corpus.block("lcg", 300, 9).tobytes(), bytes(range(256)) * 2]
-    for depth in (1, 3):
-        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, row_nibbles=1, row_depth=depth)
-    _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, **everything)
+    for mode in (0, 1):
+        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mode=mode)
+        _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256, mode=mode)
 
 
 def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
     """Between two cross-lane operations the emulator may run the lanes of a wavefront in any order; the hardware runs them
-    together.  The experimental units' lanes meet in memory (the positions of one block share its tables), so they must give
+    together.  The bit-lane units' lanes meet in memory (the positions of one block share its tables), so they must give
     the oracle's bytes whatever the order: the default one, reversed, and two shuffles."""
     blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
     h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
@@ -312,9 +207,8 @@ def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
     r = np.random.default_rng(1)
     walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
     stress = [b"\0" + d for d in (walk, bytes(500), bytes([7, 7, 8, 8] * 150), bytes(range(256)) * 2)]
-    everything = dict(row_nibbles=1, mix_bits=1, light_bits=7, full_squash=1)
     for order in ("reverse", "shuffle:3", "shuffle:4"):
         monkeypatch.setenv("ZPQ_EMU_ORDER", order)
-        _pipe_check(oracle, h5, ragged, chunk=64, **everything)
-        _pipe_check(oracle, header, stress, chunk=64, **everything)
-        _pipe_check(oracle, h5, ragged[:4], chunk=64)                   # and the product's own configuration
+        for mode in (0, 1):
+            _pipe_check(oracle, h5, ragged, chunk=64, mode=mode)
+            _pipe_check(oracle, header, stress, chunk=64, mode=mode)

@@ -393,6 +393,27 @@ def test_mixed_corpus_batch_against_the_reference(gpu, ref):
     assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)
 
 
+@pytest.mark.parametrize("shape", ["latency", "throughput"])
+def test_both_shapes_of_the_pipelined_encoder(gpu, oracle, golden, ref, monkeypatch, shape):
+    """The encoder has two shapes per chain (pipe_kernel.h: a lane per block / MIX, CM, MIX2 with a lane per bit position)
+    and the engine picks one from the batch size.  Here each is FORCED (ZPAQ_AMD_PIPE_MODE) and the tests that cover the
+    golden vectors, all nine component types, a batch that fills the GPU, several chains in one batch and a chain only
+    hipRTC knows run again: whichever shape the engine picks in production has coded every one of these cases on the
+    MI355X, bit-identical to the oracle / the reference."""
+    monkeypatch.setenv("ZPAQ_AMD_PIPE_MODE", shape)
+    test_encode_matches_oracle_and_golden(gpu, oracle, golden, 4)
+    test_all_nine_component_types(gpu, oracle, golden, 4)
+    for idx in (0, 1, 2):
+        test_legacy_min_mid_max_models(gpu, golden, 4, idx)
+    test_mixed_plans_in_one_batch_and_ragged_sizes(gpu, oracle)
+    test_large_batch_picks_its_own_kernels(gpu, oracle)
+    test_mixed_corpus_batch_against_the_reference(gpu, ref)
+    test_one_mib_records_block_with_detected_periods(gpu, ref)
+    note = __import__("ctypes").create_string_buffer(256)
+    e = golden["config_cases"][0]
+    assert gpu.lib().zpq_plan_kernel_kind3(gpu.Plan(bytes.fromhex(e["header"]))._h, 0, 4, note, 256) == 4
+
+
 def _lcg_block(n, seed):
     """BASELINE.md's generator: x = x * 1664525 + 1013904223, byte = x >> 24, first byte after one step."""
     x, out = seed, bytearray(n)

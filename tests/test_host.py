@@ -51,18 +51,16 @@ def test_sha1(zlib_):
         assert zlib_.sha1(d) == hashlib.sha1(d.tobytes()).digest()
 
 
-def test_sha1_portable_path():
+def test_sha1_portable_path(zlib_):
     """sha1.cpp picks the x86 SHA-extension compression function at run time; the portable one must agree."""
-    import subprocess
-    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
-            "import zpaq_amd as z\n"
-            "from zpaq_amd import corpus\n"
-            "assert all(z.sha1(corpus.lcg_bytes(n, 9)) == hashlib.sha1(corpus.lcg_bytes(n, 9).tobytes()).digest()\n"
-            "           for n in (0, 1, 55, 56, 63, 64, 65, 127, 128, 1000, 70001))\n"
-            "print('same')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, ZPAQ_AMD_NO_SHANI="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
-    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-1500:]
+    import hashlib
+    lens = (0, 1, 55, 56, 63, 64, 65, 127, 128, 1000, 70001)
+    try:
+        for portable in (1, 0):
+            zlib_.lib().zpq_sha1_force_portable(portable)
+            assert all(zlib_.sha1(corpus.lcg_bytes(n, 9)) == hashlib.sha1(corpus.lcg_bytes(n, 9).tobytes()).digest() for n in lens)
+    finally:
+        zlib_.lib().zpq_sha1_force_portable(0)
 
 
 def test_tables_match_oracle_and_checksums(zlib_, oracle):
@@ -406,7 +404,7 @@ def test_host_batches_shard_contiguously_over_devices(zlib_):
 
 # ---------------------------------------------------------------------------------------------------------
 # Host post-processing: the standard PCOMP programs run as C++ translated at build time (tools/gen_pcomp_std.cpp);
-# ZPAQ_AMD_PCOMP_INTERPRET=1 forces the interpreter.  Both must produce the same bytes, for valid and for damaged streams.
+# ZPAQ_AMD_PCOMP=interpret forces the interpreter.  Both must produce the same bytes, for valid and for damaged streams.
 
 def _stored_block(header, segments):
     """A block without a model (n = 0) by hand: `segments` are the payloads (the first one starts with the PP header)."""
@@ -433,16 +431,16 @@ def test_translated_pcomp_programs_equal_the_interpreter(zlib_, ref, monkeypatch
         return out[:ln.value].tobytes()
 
     def both(archive, cap):
-        monkeypatch.delenv("ZPAQ_AMD_PCOMP_INTERPRET", raising=False)
+        monkeypatch.delenv("ZPAQ_AMD_PCOMP", raising=False)
         res = []
         for interp in (False, True):
             if interp:
-                monkeypatch.setenv("ZPAQ_AMD_PCOMP_INTERPRET", "1")
+                monkeypatch.setenv("ZPAQ_AMD_PCOMP", "interpret")
             try:
                 res.append(zlib_.decompress(archive, cap))
             except zlib_.ZpaqError as e:
                 res.append(("error", e.code))
-        monkeypatch.delenv("ZPAQ_AMD_PCOMP_INTERPRET", raising=False)
+        monkeypatch.delenv("ZPAQ_AMD_PCOMP", raising=False)
         return res
 
     rng = np.random.default_rng(11)

@@ -67,10 +67,12 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
 
 int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) { return zpq_plan_kernel_kind2(p, 0, note, cap); }
 
-int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) {
+int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) { return zpq_plan_kernel_kind3(p, decode, 0, note, cap); }
+
+int zpq_plan_kernel_kind3(zpq_plan* p, int decode, uint32_t nblocks, char* note, size_t cap) {
   try {
     std::string n;
-    const int k = engine_plan_kernel_kind(p, n, decode != 0);
+    const int k = engine_plan_kernel_kind(p, n, decode != 0, nblocks);
     if (note && cap) { strncpy(note, n.c_str(), cap - 1); note[cap - 1] = 0; }
     return k;
   } catch (const Failure& f) { set_last_error(f.what()); return -f.code; }
@@ -113,10 +115,21 @@ const uint8_t* zpq_plan_blob(const zpq_plan* p, size_t* len) {
 }
 
 int zpq_plan_pipe_source(const zpq_plan* p, char* src, size_t cap, size_t* len, char key41[41]) {
+  return zpq_plan_pipe_source_opts(p, 0, 0, 0, src, cap, len, key41);
+}
+
+static PipeOptions opts_of(int mode, int chunk, int group) {
+  PipeOptions o = pipe_options(mode);
+  if (chunk) o.chunk = chunk;
+  o.group = group;
+  return o;
+}
+
+int zpq_plan_pipe_source_opts(const zpq_plan* p, int mode, int chunk, int group, char* src, size_t cap, size_t* len, char key41[41]) {
   ZPQ_TRY
   if (!p) fail(ZPQ_E_ARG, "null plan");
   std::string source, key, why;
-  if (!pipe_source_and_key(*p, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (!pipe_source_and_key(*p, opts_of(mode, chunk, group), source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
   if (len) *len = source.size();
   if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
   if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
@@ -137,17 +150,19 @@ int zpq_pcomp_source(const uint8_t* code, size_t codelen, int ph, int pm, char* 
   ZPQ_CATCH
 }
 
-int zpq_plan_pipe_layout(const zpq_plan* p, uint64_t out[16]) {
+int zpq_plan_pipe_layout(const zpq_plan* p, uint64_t out[16]) { return zpq_plan_pipe_layout_opts(p, 0, 0, 0, out); }
+
+int zpq_plan_pipe_layout_opts(const zpq_plan* p, int mode, int chunk, int group, uint64_t out[16]) {
   ZPQ_TRY
   if (!p || !out) fail(ZPQ_E_ARG, "null argument");
   PipeLayout L;
   std::string why;
-  if (!pipe_layout(*p, L, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (!pipe_layout(*p, opts_of(mode, chunk, group), L, why)) fail(ZPQ_E_UNSUPPORTED, why);
   memset(out, 0, 16 * sizeof(uint64_t));
   out[0] = L.group_bytes; out[1] = (uint64_t)L.S; out[2] = (uint64_t)L.C; out[3] = L.light.size();
   out[4] = L.icm.size(); out[5] = L.isse.size(); out[6] = (uint64_t)L.mix_waves_per_group();
   out[7] = (uint64_t)L.hcomp_lanes; out[8] = (uint64_t)L.coder_level; out[9] = (uint64_t)L.G; out[10] = L.rows.size();
-  out[11] = (uint64_t)L.mix_threads(); out[12] = (uint64_t)L.rows_threads(); out[13] = (uint64_t)L.light_threads();
+  out[11] = (uint64_t)L.mix_threads(); out[12] = (uint64_t)L.G; out[13] = (uint64_t)L.light_threads();
   return ZPQ_OK;
   ZPQ_CATCH
 }
@@ -284,6 +299,7 @@ int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t ca
 void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]) {
   Sha1 s; s.update(in, (size_t)n); memcpy(out20, s.result(), 20);
 }
+void zpq_sha1_force_portable(int yes) { sha1_force_portable(yes != 0); }
 
 int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char* out, size_t cap) {
   ZPQ_TRY

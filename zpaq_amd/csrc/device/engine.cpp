@@ -21,6 +21,15 @@
 #include "kernels.h"
 #include "spec_loader.hpp"
 
+// The pipelined encoder keeps seven HIP streams busy (one per kernel plus the caller's).  The runtime maps streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its packets in order, so with the default two of the six
+// kernels of a step wait for each other although nothing orders them: measured on the MI355X, -m3 on 256 blocks 766 ->
+// 493 ms, -m5 on 64 blocks 3.0 -> 2.1 s with 8 queues, no change for batches that fill the machine (profiles/r03).  The
+// variable is read when the HIP runtime initialises, so it is set when this library is loaded -- before the process's
+// first HIP call in a C++ host such as zpaq; a host that initialised HIP earlier (python with torch) sets it itself
+// (bench.py, tests/conftest.py do).  A value the user exported is left alone.
+__attribute__((constructor)) static void zpq_more_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace zpq {
 
 #define HIP_CHECK(expr)                                                                       \
@@ -143,7 +152,6 @@ int jit_budget() {
   return 64;
 }
 int jit_threads() {
-  if (const char* v = getenv("ZPAQ_AMD_JIT_THREADS")) return std::max(1, atoi(v));
   unsigned hw = std::thread::hardware_concurrency();
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw ? hw : 1, (unsigned)CPU_COUNT(&set));
@@ -285,7 +293,7 @@ void engine_plan_release(zpq_plan* p) {
   (void)hipGetDevice(&before);
   for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
     zpq_plan::OnDevice& od = p->dev[id];
-    if (!od.d_blob && !od.pipe && !od.spec[0] && !od.spec[1]) continue;
+    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.spec[0] && !od.spec[1]) continue;
     if (hipSetDevice(id) != hipSuccess) continue;
     set_plan_device_index(id);
     if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
@@ -300,9 +308,23 @@ void engine_plan_release(zpq_plan* p) {
 // `dense` = the launch holds more blocks than one wavefront per SIMD can take (4 x CUs): then the
 // 8-blocks-per-workgroup shape (two wavefronts per SIMD, half the side tables in LDS) has the higher
 // throughput; below that the 4-block shape (everything in LDS, one workgroup per CU) is faster.
-struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe = nullptr; };
+struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe = nullptr; int mode = 0; };
 
-static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode) {
+// The pipelined encoder has two shapes per chain (host/codegen.hpp PipeOptions): a chain with few blocks in the batch is
+// latency bound -- a step costs one wavefront's serial chain however empty the machine is -- and runs the units with a
+// lane per bit position; a chain that fills the machine is bound by HBM transactions and runs the lane-per-block units,
+// which issue fewer requests.  Measured crossover on the MI355X, -m5 / 1 MiB blocks: between 256 and 512 blocks
+// (profiles/r03/call4_summary.txt, call5_summary.txt).  ZPAQ_AMD_PIPE_MODE=latency|throughput forces one (A/B, tests).
+static const uint32_t kLatencyModeBlocks = 384;
+static int pipe_mode_for(uint32_t blocks_of_plan) {
+  if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
+    if (!strcmp(m, "latency")) return 1;
+    if (!strcmp(m, "throughput")) return 0;
+  }
+  return blocks_of_plan <= kLatencyModeBlocks ? 1 : 0;
+}
+
+static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
   KernelPick r;
   const int want = e.kernel_choice;
@@ -318,9 +340,9 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   // generic wave kernel this time and are picked up by later calls.
   if (!decode && (want == 0 || want == 4)) {
     bool did = false;
-    PipeKernel* k = pipe_kernel_for(p, want == 4 || e.jit_left > 0, &did);
+    PipeKernel* k = pipe_kernel_for(p, mode, want == 4 || e.jit_left > 0, &did);
     if (did && e.jit_left > 0) --e.jit_left;
-    if (k) { r.kind = 4; r.pipe = k; return r; }
+    if (k) { r.kind = 4; r.pipe = k; r.mode = mode; return r; }
     if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->cur().pipe_note);
   }
   const int forced = spec_variant_forced();
@@ -339,13 +361,13 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   return r;
 }
 
-int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode) {
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_t nblocks) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   bind_device(e.device);
   e.jit_left = jit_budget();
-  const KernelPick k = kernel_kind(e, p, false, decode);
+  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu));
   note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
@@ -366,10 +388,10 @@ static bool same_group(const LaunchGroup& g, const KernelPick& k, const zpq_plan
 }
 
 // bytes of stream buffer the pipelined encoder needs for `count` blocks of `plan`
-static uint64_t pipe_bytes(const zpq_plan* plan, uint32_t count) {
+static uint64_t pipe_bytes(const zpq_plan* plan, uint32_t count, int mode) {
   PipeLayout L;
   std::string why;
-  if (!pipe_layout(*plan, L, why)) return 0;
+  if (!pipe_layout(*plan, pipe_options(mode), L, why)) return 0;
   return (uint64_t)((count + (uint32_t)L.G - 1) / (uint32_t)L.G) * L.group_bytes;
 }
 
@@ -390,7 +412,6 @@ struct PipeRun {
   uint32_t ngroups;
   uint32_t threads;          // lanes per workgroup of every kernel but hcomp and mix (= blocks per group)
   uint32_t mix_threads;      // ... of the mix kernel (= threads unless its lanes are per bit position)
-  uint32_t rows_threads;     // ... of the rows kernel (= threads unless its lanes are per nibble)
   uint32_t light_threads;    // ... of the light kernel (= threads unless some of its units have a lane per bit position)
   bool consumes[6][6];
   int slack;
@@ -414,7 +435,7 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
           HIP_CHECK(hipEventCreate(&rec.a));
           HIP_CHECK(hipEventCreate(&rec.b));
           HIP_CHECK(hipEventRecord(rec.a, st));
-          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads))), 1, 1, 0, st, args, nullptr));
+          HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(per, r.grid[k] - w0), 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 2 ? r.light_threads : r.threads)), 1, 1, 0, st, args, nullptr));
           HIP_CHECK(hipEventRecord(rec.b, st));
           recs.push_back(rec);
         }
@@ -437,34 +458,8 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
             kv.second.first / kv.second.second, kv.second.second);
 }
 
-// profiling aid (ZPAQ_AMD_PIPE_SPLIT): extra streams so that per-unit launches of one kernel still overlap
-static std::vector<hipStream_t> g_split_streams;
-static std::vector<std::pair<hipStream_t, hipStream_t>> g_split_used;      // (unit stream, the kernel stream it joins)
-static hipStream_t split_stream(Engine&, size_t idx, hipStream_t parent) {
-  while (g_split_streams.size() <= idx) {
-    hipStream_t s2;
-    HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    g_split_streams.push_back(s2);
-  }
-  hipStream_t su = g_split_streams[idx];
-  Event fork;
-  HIP_CHECK(hipEventRecord(fork, parent));
-  HIP_CHECK(hipStreamWaitEvent(su, fork, 0));
-  g_split_used.push_back({su, parent});
-  return su;
-}
-static void split_join(Engine&) {
-  for (auto& pr : g_split_used) {
-    Event done;
-    HIP_CHECK(hipEventRecord(done, pr.first));
-    HIP_CHECK(hipStreamWaitEvent(pr.second, done, 0));
-  }
-  g_split_used.clear();
-}
-
 static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
   if (runs.empty()) return;
-  const bool split = getenv("ZPAQ_AMD_PIPE_SPLIT") != nullptr;
   if (getenv("ZPAQ_AMD_PIPE_PROFILE")) { launch_pipe_profiled(e, runs, st); return; }
   for (auto& ps : e.pstream)
     if (!ps) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
@@ -525,21 +520,8 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
           r.args.trace_base = (uint32_t)(trace_run_base[(size_t)(&r - &runs[0])] + per_step * step + before);
         }
         void* args[1] = {(void*)&r.args};
-        if (split && k != 0) {
-          // ZPAQ_AMD_PIPE_SPLIT=1 (profiling aid): one launch per unit type, on streams of their own, so that a kernel
-          // trace shows which unit of a kernel is the slow one
-          for (uint32_t w0 = 0, ui = 0; w0 < r.grid[k]; w0 += r.ngroups, ++ui) {
-            PipeArgs a2 = r.args;
-            a2.wg0 = w0;
-            void* args2[1] = {(void*)&a2};
-            hipStream_t su = split_stream(e, (size_t)k * 64 + ui, e.pstream[k]);
-            HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], std::min(r.ngroups, r.grid[k] - w0), 1, 1, k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads)), 1, 1, 0, su, args2, nullptr));
-          }
-          continue;
-        }
-        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 1 ? r.rows_threads : (k == 2 ? r.light_threads : r.threads))), 1, 1, 0, e.pstream[k], args, nullptr));
+        HIP_CHECK(hipModuleLaunchKernel(r.k->fn[k], r.grid[k], 1, 1, k == 0 ? 64u : (k == 5 ? r.mix_threads : (k == 2 ? r.light_threads : r.threads)), 1, 1, 0, e.pstream[k], args, nullptr));
       }
-      if (split) split_join(e);
       HIP_CHECK(hipEventRecord(*ev[k][step % R], e.pstream[k]));
     }
   }
@@ -577,14 +559,14 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
   std::vector<PipeRun> runs;
   uint64_t pipe_need = 0;
   for (const LaunchGroup& g : groups)
-    if (g.pick.kind == 4) pipe_need += pipe_bytes(g.plan, g.count);
+    if (g.pick.kind == 4) pipe_need += pipe_bytes(g.plan, g.count, g.pick.mode);
   if (pipe_need) e.pipe.ensure(pipe_need);
   uint64_t pipe_off = 0;
   for (const LaunchGroup& g : groups) {
     if (g.pick.kind != 4) continue;
     PipeLayout L;
     std::string why;
-    if (!pipe_layout(*g.plan, L, why)) fail(ZPQ_E_DEVICE, "pipe layout vanished: " + why);
+    if (!pipe_layout(*g.plan, pipe_options(g.pick.mode), L, why)) fail(ZPQ_E_DEVICE, "pipe layout vanished: " + why);
     PipeRun r;
     r.k = g.pick.pipe;
     r.args = PipeArgs{d_jobs + g.first, d_res, g.count, e.d_tables, (uint8_t*)e.pipe.p + pipe_off, 0, 0u};
@@ -592,7 +574,6 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.ngroups = ng;
     r.threads = (uint32_t)L.G;
     r.mix_threads = (uint32_t)L.mix_threads();
-    r.rows_threads = (uint32_t)L.rows_threads();
     r.light_threads = (uint32_t)L.light_threads();
     memcpy(r.consumes, L.consumes, sizeof(r.consumes));
     r.slack = L.slack;
@@ -672,14 +653,26 @@ static int kind_of_sorted(const std::vector<LaunchGroup>& groups, size_t k) {
 // kernels are compiled side by side on the host cores before the kernels are picked, so that such a batch pays about one
 // compilation time, not one per header.  The code objects land in the cache directory / the loader's in-process store;
 // kernel_kind() then finds them there.
+// blocks of the batch per plan -> the mode its pipelined encoder runs in
 template <class PlanOf>
-static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vector<uint32_t>& order, PlanOf plan_of) {
+static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& order, PlanOf plan_of) {
+  std::map<const zpq_plan*, uint32_t> cnt;
+  for (uint32_t b : order) ++cnt[plan_of(b)];
+  std::map<const zpq_plan*, int> mode;
+  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second);
+  return mode;
+}
+
+template <class PlanOf>
+static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vector<uint32_t>& order, PlanOf plan_of,
+                              const std::map<const zpq_plan*, int>& mode_of) {
   const int want = e.kernel_choice;
   if (want == 1 || want == 2 || e.jit_left <= 1) return;
   const bool pipe = !decode && (want == 0 || want == 4);
   const int forced = spec_variant_forced();
   const int variant = forced >= 0 ? forced : (dense ? 1 : 0);
   std::vector<const zpq_plan*> unseen;
+  std::vector<int> modes;
   const zpq_plan* last = nullptr;
   for (uint32_t b : order) {
     const zpq_plan* p = plan_of(b);
@@ -687,11 +680,12 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
     last = p;
     if (!p->hdr().wave_ok) continue;
     const auto& d = p->cur();
-    if (pipe ? d.pipe_state != 0 : d.spec_state[variant] != 0) continue;        // loaded, or known not to work
-    if (std::find(unseen.begin(), unseen.end(), p) == unseen.end()) unseen.push_back(p);
+    const int mode = mode_of.at(p);
+    if (pipe ? d.pipe_state[mode] != 0 : d.spec_state[variant] != 0) continue;        // loaded, or known not to work
+    if (std::find(unseen.begin(), unseen.end(), p) == unseen.end()) { unseen.push_back(p); modes.push_back(mode); }
   }
   if (unseen.size() < 2) return;            // a single header is compiled where it is loaded
-  e.jit_left -= spec_precompile(unseen, pipe, variant, e.jit_left, jit_threads());
+  e.jit_left -= spec_precompile(unseen, pipe, variant, e.jit_left, jit_threads(), nullptr, &modes);
   if (e.jit_left < 1) e.jit_left = 1;       // (what was compiled is found in the cache; the budget only counts compilations)
 }
 
@@ -699,9 +693,10 @@ template <class PlanOf, class LenOf>
 static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
   const size_t cnt = order.size();
   const bool dense = cnt > (size_t)4 * e.cus;
-  precompile_unseen(e, decode, dense, order, plan_of);
+  const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of);
+  precompile_unseen(e, decode, dense, order, plan_of, mode_of);
   std::vector<KernelPick> pick(cnt);
-  for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode);
+  for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode, mode_of.at(plan_of(order[k])));
   std::vector<uint32_t> idx(cnt);
   for (size_t k = 0; k < cnt; ++k) idx[k] = (uint32_t)k;
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
@@ -856,7 +851,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     while (end < nb) {
       const HostBlock& hb = blocks[end];
       uint64_t a = hb.plan->hdr().arena_bytes;
-      if (!decode && e.kernel_choice != 1 && e.kernel_choice != 2 && e.kernel_choice != 3) a += pipe_bytes(hb.plan, 64) / 64;   // share of a full group
+      if (!decode && e.kernel_choice != 1 && e.kernel_choice != 2 && e.kernel_choice != 3) a += pipe_bytes(hb.plan, 64, 0) / 64;   // share of a full group
       if (end > pos && need + a > e.budget) break;
       need += a;
       max_arena = std::max(max_arena, hb.plan->hdr().arena_bytes);
@@ -1040,7 +1035,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   std::vector<LaunchGroup> groups = make_groups(e, decode, order, plan_of, [&](uint32_t b) { return in_len[b]; });
   uint64_t pipe_need = 0;
   for (const LaunchGroup& gr : groups)
-    if (gr.pick.kind == 4) pipe_need += pipe_bytes(gr.plan, gr.count);
+    if (gr.pick.kind == 4) pipe_need += pipe_bytes(gr.plan, gr.count, gr.pick.mode);
   if (need + pipe_need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: batch state exceeds the device budget (split the batch)");
   e.arena.ensure(need);
   e.jobs.ensure((size_t)nblocks * sizeof(BlockJob));

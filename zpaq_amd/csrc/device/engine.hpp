@@ -40,7 +40,7 @@ void engine_set_kernel(int which);
 Timing engine_last_timing();
 void engine_plan_release(zpq_plan* p);
 // 4 pipelined encoder (compression only) / 3 specialised / 2 generic wave / 1 generic one-lane; note = origin of the specialised kernel or why not
-int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false);
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false, uint32_t nblocks = 0);   // nblocks = 0: a batch that fills the GPU
 
 // Host-buffer batch: copies in, runs (possibly in several residency waves), copies out.  Concurrent callers are
 // coalesced into one device batch (see the submission queue in engine.cpp); a caller that will submit shortly
@@ -65,6 +65,6 @@ struct PcompSeg { const U8* in; U32 in_len; U64 hint; std::vector<U8>* out; };
 bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<PcompSeg>& segs, std::string& note);
 void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out);
 int engine_selftest(int32_t out[8]);
-int engine_jit_threads();      // host threads spec_precompile() uses by default (ZPAQ_AMD_JIT_THREADS)
+int engine_jit_threads();      // host threads spec_precompile() uses by default (the host cores the process may use, at most 16)
 
 }  // namespace zpq

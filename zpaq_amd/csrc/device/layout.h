@@ -50,11 +50,21 @@ struct CompDesc {         // 64 bytes
   uint32_t limit;         // CM/SSE: cp[]*4 count limit
   uint32_t mask0;         // t0 index mask (elements): CM 2^s-1, MATCH 2^a1-1, MIX/MIX2 2^s-1, SSE 32*2^s-1
   uint32_t mask1;         // t1 mask (bytes): ICM/ISSE ht_n-1, MATCH 2^a2-1
-  uint32_t pad0;
+  uint32_t stride;        // MIX: words from one weight row to the next (>= m; see mix_row_stride), 0 otherwise
   uint64_t t0;            // arena offset of cm / a16
   uint64_t t1;            // arena offset of ht
   uint64_t pad1;
 };
+
+// MIX weight rows in HBM: row r of an m-input mixer starts at word r * stride.  The reference packs rows (stride = m); a
+// row is then 4 m bytes at a 4-byte-aligned address and straddles 128-byte memory lines (m = 19: 76-byte rows, 1.6 lines
+// per row on average).  The coder touches one row per bit and component at a random place of a table far larger than any
+// cache, and the MI355X's memory system moves 128-byte lines whatever is asked of them (profiles/r03/gups.hip: 49 G
+// random line reads per second, 24 G read-modify-writes), so rows are padded to the next power of two up to 32 words:
+// one line per row, and 16-byte-aligned for the lane groups that load a row as 16-byte quads.
+static inline constexpr uint32_t mix_row_stride(uint32_t m) {
+  return m <= 1 ? 1u : (m <= 2 ? 2u : (m <= 4 ? 4u : (m <= 8 ? 8u : (m <= 16 ? 16u : ((m + 31u) & ~31u)))));
+}
 
 struct PlanHeader {       // followed in the same buffer by CompDesc[n], Segment[nseg], prog[prog_len]
   uint32_t n;             // components

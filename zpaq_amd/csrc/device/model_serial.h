@@ -201,7 +201,7 @@ __device__ inline int serial_predict(SerialCtx& s) {
       }
       case C_MIX: {
         const int m = (int)c.a3;
-        r.cxt = ((s.h[i] + (uint32_t)(c8 & (int)c.a5)) & c.mask0) * (uint32_t)m;
+        r.cxt = ((s.h[i] + (uint32_t)(c8 & (int)c.a5)) & c.mask0) * c.stride;
         const int32_t* wt = (const int32_t*)(s.arena + c.t0) + r.cxt;
         int sum = 0;
         for (int j = 0; j < m; ++j) sum += (wt[j] >> 8) * p[c.a2 + j];

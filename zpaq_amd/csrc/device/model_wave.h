@@ -170,7 +170,7 @@ __device__ inline int wvm_run(WaveVm& s, uint32_t input) {
 
 // Per-lane component state (registers).
 struct Lane {
-  uint32_t type, a1, a2, a3, a4, a5, limit, mask0, mask1;
+  uint32_t type, a1, a2, a3, a4, a5, limit, mask0, mask1, stride;
   uint8_t* t0;
   uint8_t* t1;
   uint32_t cxt, ra, rb, rc, rlimit;   // Component::cxt, a, b, c, limit
@@ -228,7 +228,7 @@ __device__ inline void wave_predict_phase1(const WaveModel& m, Lane& s) {
       break;
     }
     case C_MIX: {
-      s.cxt = ((s.h + (uint32_t)(c8 & (int)s.a5)) & s.mask0) * s.a3;
+      s.cxt = ((s.h + (uint32_t)(c8 & (int)s.a5)) & s.mask0) * s.stride;
       break;
     }
     default: break;   // CONS fixed; AVG, SSE entirely in phase 2
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void code_wave_kernel(const Bl
   {
     CompDesc c;
     if (lane < m.n) c = comp[lane];
-    else { c.type = C_NONE; c.a1 = c.a2 = c.a3 = c.a4 = c.a5 = 0; c.limit = c.mask0 = c.mask1 = 0; c.t0 = c.t1 = 0; }
-    s.type = c.type; s.a1 = c.a1; s.a2 = c.a2; s.a3 = c.a3; s.a4 = c.a4; s.a5 = c.a5;
+    else { c.type = C_NONE; c.a1 = c.a2 = c.a3 = c.a4 = c.a5 = 0; c.limit = c.mask0 = c.mask1 = 0; c.stride = 0; c.t0 = c.t1 = 0; }
+    s.type = c.type; s.a1 = c.a1; s.a2 = c.a2; s.a3 = c.a3; s.a4 = c.a4; s.a5 = c.a5; s.stride = c.stride;
     s.limit = c.limit; s.mask0 = c.mask0; s.mask1 = c.mask1;
     s.t0 = job.arena + c.t0;
     s.t1 = job.arena + c.t1;

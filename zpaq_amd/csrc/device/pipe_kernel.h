@@ -47,6 +47,16 @@
 // (b) finds them in L2.  The ROW unit loads the candidate rows of both nibbles up front and forwards the row the
 // first nibble rewrote; the ISSE/ICM maps read the next bit's LDS entry early and forward the entry just trained.
 //
+// Two shapes of one unit.  With all bits known, the 8 bits of a byte are independent for every unit whose table index
+// contains the bit position and whose training touches only the indexed entry (CM, SSE, MIX2 / MIX with a full c0 mask):
+// such a unit also exists with a lane per (block, bit position) -- an 8 x shorter chain per byte, 8 x the wavefronts and
+// more memory requests.  What the MI355X says (profiles/r03): a batch that fills the machine is bound by HBM
+// TRANSACTIONS -- every random 16-byte row costs a 128-byte line each way, 24 G read-modify-writes per second for the whole
+// GPU (profiles/r03/gups.hip) -- and there the lane-per-block units win (fewer requests; only SSE is faster per bit
+// position everywhere); a chain with few blocks in the batch is bound by the length of one wavefront's chain, and there
+// the bit-position units win (-m5, 64 blocks: 1.6 x).  The generator emits one or the other (PIPE_MODE, PipeOptions in
+// host/codegen.hpp) and the engine picks per chain from the number of its blocks in the batch.
+//
 // Integer arithmetic is the reference's, statement for statement; the parity tests compare the
 // coded bytes with the oracle and with the reference.  The same source runs in tests/emu on the host.
 #pragma once
@@ -234,20 +244,6 @@ struct PipeSquash {
   }
 };
 
-// ... or through all 4096 entries (ZPAQ_AMD_PIPE_FULL_SQUASH=1: 8 KB of LDS instead of 2.7, one add and one read
-// instead of two clamps, the read and two selects on every unit's per-bit chain; arguments are clamped to -2047..2047)
-struct PipeSquashFull {
-  unsigned short all[4096];
-  __device__ __forceinline__ void load(const DeviceTables* tb, int lane) {
-    for (int i = lane; i < 4096; i += (int)blockDim.x) all[i] = tb->squash[i];
-  }
-  __device__ __forceinline__ int operator()(int p) const { return all[(unsigned)(p + 2048) & 4095u]; }
-};
-template <class Chain, bool Full = (Chain::FULL_SQUASH != 0)>
-struct PipeSquashFor { typedef PipeSquash type; };
-template <class Chain>
-struct PipeSquashFor<Chain, true> { typedef PipeSquashFull type; };
-
 // Predictor::train (libzpaq.h:1151-1157)
 __device__ __forceinline__ unsigned pipe_train(unsigned v, int y, unsigned dtv, unsigned limit) {
   const unsigned count = v & 0x3ffu;
@@ -337,26 +333,6 @@ __device__ __forceinline__ PipeRow pipe_find(const uint4& r0, const uint4& r1, c
   return r;
 }
 
-// The same with the row picked by masks instead of nested selections (which the compiler turns into branches, four
-// exec-mask blocks per row word): used by the nibble-lane ROW unit.
-__device__ __forceinline__ PipeRow pipe_find_flat(const uint4& r0, const uint4& r1, const uint4& r2, unsigned chk, unsigned h0) {
-  const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
-  const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
-  const unsigned victim = (p0 <= p1 && p0 <= p2) ? 0u : (p1 < p2 ? 1u : 2u);
-  const bool hit = m0 || m1 || m2;
-  const unsigned pick = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : victim));
-  // all ones for the candidate that was found (none on a miss: the row starts empty with the new check byte)
-  const unsigned k0 = (hit && pick == 0u) ? 0xFFFFFFFFu : 0u, k1 = (hit && pick == 1u) ? 0xFFFFFFFFu : 0u,
-                 k2 = (hit && pick == 2u) ? 0xFFFFFFFFu : 0u;
-  PipeRow r;
-  r.off = h0 ^ (pick << 4);
-  r.w0 = (r0.x & k0) | (r1.x & k1) | (r2.x & k2) | (hit ? 0u : chk);
-  r.w1 = (r0.y & k0) | (r1.y & k1) | (r2.y & k2);
-  r.w2 = (r0.z & k0) | (r1.z & k1) | (r2.z & k2);
-  r.w3 = (r0.w & k0) | (r1.w & k1) | (r2.w & k2);
-  return r;
-}
-
 // the nibble's 4 bits: slots 1, 2..3, 4..7, 8..15 (hmap4 & 15) = bytes 1..3 of w0, then w1, then w2 / w3;
 // returns the 4 bit histories the predictor sees, lowest byte first
 template <class NS>
@@ -424,9 +400,7 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
       nb0 = L.A128(ht + hbn); nb1 = L.A128(ht + (hbn ^ 16u)); nb2 = L.A128(ht + (hbn ^ 32u));
     }
     const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
-    PipeRow ra;
-    if constexpr (Chain::ROW_FLAT != 0) ra = pipe_find_flat(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
-    else ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
+    PipeRow ra = pipe_find(a0, a1, a2, (cxa >> sizebits) & 255u, ha);
     uint2 o;
     o.x = pipe_row_bits(ra, byte >> 4, ns);
     const uint4 na = make_uint4(ra.w0, ra.w1, ra.w2, ra.w3);
@@ -435,9 +409,7 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     if (ra.off == hb) b0 = na;
     if (ra.off == (hb ^ 16u)) b1 = na;
     if (ra.off == (hb ^ 32u)) b2 = na;
-    PipeRow rb;
-    if constexpr (Chain::ROW_FLAT != 0) rb = pipe_find_flat(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
-    else rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
+    PipeRow rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
     o.y = pipe_row_bits(rb, byte & 15u, ns);
     L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
     L.bh(ri, k) = o;
@@ -448,85 +420,6 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
     ha = han; hb = hbn;
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
-  }
-}
-
-// ROW unit with a lane per (block, NIBBLE) (ZPAQ_AMD_PIPE_ROW_NIBBLES).  Both rows of a byte are known when the byte
-// starts -- the second one's context is the first's plus the high nibble, which the encoder has -- so two lanes do the two
-// finds and the 2 x 4 bit-history steps side by side: a wavefront of 64 lanes serves 32 blocks with ~100 instructions per
-// byte where the one-lane unit needs ~600 for the same 32 blocks.  Candidates are fetched ROW_DEPTH bytes ahead; a lane
-// knows every line its block wrote since (it can compute the partner's addresses itself), and fetches its three
-// candidates again when one of them is its own line.  The rare second nibble that shares a line with its byte's first
-// nibble (tiny tables) runs in a second pass, after the first nibble's store.
-template <class Chain, int I, class NS>
-__device__ __forceinline__ void pipe_row_nibbles(PipeLane<Chain>& L, unsigned nib, const NS& ns) {
-  constexpr CompK c = Chain::comp[I];
-  constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
-  constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I], D = Chain::ROW_DEPTH;
-  if (!L.nb) return;
-  const unsigned last = L.nb - 1u;
-  // context of a nibble's row: c8 = 1 for the first, 16 + the high nibble for the second
-  auto cx_of = [&](unsigned hh, unsigned bytev, unsigned which) __attribute__((always_inline)) -> unsigned {
-    return hh + (which ? 16u * (16u + (bytev >> 4)) : 16u);
-  };
-  auto row_of = [&](unsigned cx) __attribute__((always_inline)) -> unsigned { return (cx * 16u) & (rmask - 15u); };
-  // ring of W = 2 D slots (slot = byte index mod W, fixed registers): context and byte fetched W bytes ahead, the three
-  // candidate rows D bytes ahead
-  constexpr int W = 2 * D;
-  unsigned hx[W], bx[W], rq[W];                // context, input byte, own first candidate
-  uint4 c0[W], c1[W], c2[W];                   // the three candidates as fetched
-  unsigned hl0[D], hl1[D];                     // lines the block wrote for the last D bytes (first / second nibble)
-  auto near = [&](int sl) __attribute__((always_inline)) {
-    rq[sl] = row_of(cx_of(hx[sl], bx[sl], nib));
-    c0[sl] = L.A128(ht + rq[sl]); c1[sl] = L.A128(ht + (rq[sl] ^ 16u)); c2[sl] = L.A128(ht + (rq[sl] ^ 32u));
-  };
-#pragma unroll
-  for (int sl = 0; sl < W; ++sl) { const unsigned kk = min((unsigned)sl, last); hx[sl] = L.ctx(ci, kk); bx[sl] = L.byte_at(kk); }
-#pragma unroll
-  for (int sl = 0; sl < D; ++sl) near(sl);
-#pragma unroll
-  for (int i = 0; i < D; ++i) { hl0[i] = 0xFFFFFFFFu; hl1[i] = 0xFFFFFFFFu; }
-  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
-#pragma unroll
-    for (int sl = 0; sl < W; ++sl) {
-      const unsigned k = kb + (unsigned)sl;
-      const bool on = k < L.nb;
-      const unsigned hcur = hx[sl], bcur = bx[sl], row = rq[sl];
-      const unsigned cx = cx_of(hcur, bcur, nib);
-      const unsigned line = row & ~63u, pline = row_of(cx_of(hcur, bcur, 1u - nib)) & ~63u;
-      const unsigned bits4 = nib ? (bcur & 15u) : (bcur >> 4);
-      bool stale = false;
-#pragma unroll
-      for (int i = 0; i < D; ++i) stale = stale || line == hl0[i] || line == hl1[i];
-      const bool defer = nib != 0u && line == pline;              // this byte's first nibble rewrites the line first
-#pragma unroll 1
-      for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !pipe_any(on && defer)) break;
-        const bool mine = on && (defer == (pass == 1));
-        const bool again = mine && (stale || pass == 1);
-        if (pipe_any(again)) {
-          pipe_stores_done();
-          if (again) {
-            c0[sl] = pipe_settle(L.A128(ht + row)); c1[sl] = pipe_settle(L.A128(ht + (row ^ 16u))); c2[sl] = pipe_settle(L.A128(ht + (row ^ 32u)));
-          }
-        }
-        if (mine) {
-          PipeRow r = pipe_find_flat(c0[sl], c1[sl], c2[sl], (cx >> sizebits) & 255u, row);
-          const unsigned o = pipe_row_bits(r, bits4, ns);
-          L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
-          *(g_u32*)((g_u8*)&L.bh(ri, k) + 4u * nib) = o;
-        }
-      }
-#pragma unroll
-      for (int i = D - 1; i > 0; --i) { hl0[i] = hl0[i - 1]; hl1[i] = hl1[i - 1]; }
-      hl0[0] = nib ? pline : line;
-      hl1[0] = nib ? line : pline;
-      {
-        const unsigned kw = min(k + (unsigned)W, last);
-        hx[sl] = L.ctx(ci, kw); bx[sl] = L.byte_at(kw);
-        near((sl + D) % W);
-      }
-    }
   }
 }
 
@@ -842,7 +735,9 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
   }
 }
 
-// ---- CM / MIX2 / SSE with a lane per (block, BIT POSITION) (ZPAQ_AMD_PIPE_LIGHT_BITS) ------------------------------
+// ---- CM / MIX2 / SSE with a lane per (block, BIT POSITION) ----------------------------------------------------------
+// (SSE in both shapes of the encoder -- it is the longest chain of the light kernel and wins at every batch size measured;
+//  CM and MIX2 in latency mode only: PipeOptions in host/codegen.hpp)
 // Same idea as pipe_mix_bits_body: the table word a bit uses is indexed by the bit's position in the byte (hmap4 / c8
 // are part of the index) and training touches that word only, so with all bits known the 8 bits of a byte are
 // independent.  8 lanes per block, the 8 positions of a block in ONE wavefront (a workgroup = PIPE_G lanes = PIPE_G / 8
@@ -1134,13 +1029,6 @@ __device__ __forceinline__ void pipe_rows_body(const PipeArgs& a) {
     constexpr int r = decltype(rc)::value;
     if (role != (unsigned)r) return;
     PipeLane<Chain> L;
-    if constexpr (Chain::ROW_NIBBLES != 0) {
-      // workgroup = 2 x PIPE_G lanes: lane = (block, nibble)
-      L.open(a, g * Chain::PIPE_G + ((unsigned)lane >> 1), 1);
-      if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-      pipe_row_nibbles<Chain, Chain::ROW_COMP[r]>(L, (unsigned)lane & 1u, ns);
-      return;
-    }
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, 1);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     pipe_row<Chain, Chain::ROW_COMP[r]>(L, ns);
@@ -1153,7 +1041,7 @@ template <class Chain>
 __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
   __shared__ int dt[1024];
   __shared__ unsigned short dt2k[256];
-  __shared__ typename PipeSquashFor<Chain>::type squash;
+  __shared__ PipeSquash squash;
   __shared__ PipeStretch stretch;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
@@ -1233,15 +1121,8 @@ __device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return 
 // ICM map (libzpaq.cpp:1875-1881, 1973-1977): side table cm[256] of 64 blocks in LDS as [entry][lane].
 // The entry of the NEXT bit is read before this bit's entry is written and patched when they coincide, so the
 // LDS round trip is off the lane's serial chain.
-template <class Chain> __device__ __forceinline__ void pipe_icm_ilp_body(const PipeArgs& a);
-template <class Chain> __device__ __forceinline__ void pipe_isse_ilp_body(const PipeArgs& a);
-
 template <class Chain>
 __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
-  if constexpr (Chain::MAP_ILP > 1) {
-    pipe_icm_ilp_body<Chain>(a);
-    return;
-  } else {
   constexpr unsigned G = Chain::PIPE_G;
   __shared__ unsigned tab[256 * G];
   __shared__ PipeStretch stretch;
@@ -1290,19 +1171,14 @@ __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
     for (int e = 0; e < 256; e += 4)
       L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
   });
-  }
 }
 
 // ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
 template <class Chain>
 __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
-  if constexpr (Chain::MAP_ILP > 1) {
-    pipe_isse_ilp_body<Chain>(a);
-    return;
-  } else {
   constexpr unsigned G = Chain::PIPE_G;
   __shared__ unsigned tab[512 * G];
-  __shared__ typename PipeSquashFor<Chain>::type squash;
+  __shared__ PipeSquash squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
@@ -1357,7 +1233,6 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
     for (int e = 0; e < 512; e += 4)
       L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
   });
-  }
 }
 
 // =====================================================================================================
@@ -1369,208 +1244,6 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
 typedef uint4 __attribute__((aligned(4))) pipe_u128a4;
 typedef __attribute__((address_space(1))) pipe_u128a4 g_u128a4;
 
-// ---- ICM / ISSE maps with SEVERAL BLOCKS PER LANE (ZPAQ_AMD_PIPE_MAP_ILP=2) -------------------------------------------
-// A map's per-bit chain is serial (every bit reads the entry the bit before may have written) and a wavefront issues one
-// instruction every four cycles however few lanes are live, so a lone chain leaves most issue slots empty: alone, the ISSE
-// map needs 272 cycles per bit for 38 instructions.  With F blocks per lane (G / F live lanes, blocks lane and lane + G / F
-// ...) the F independent chains of a lane sit in one basic block and the compiler interleaves them: the same wavefront,
-// the same LDS table, F bits per pass.
-template <class Chain>
-__device__ __forceinline__ void pipe_icm_ilp_body(const PipeArgs& a) {
-  constexpr unsigned G = Chain::PIPE_G;
-  constexpr int F = Chain::MAP_ILP;
-  constexpr unsigned GL = G / (unsigned)F;                 // lanes that work
-  __shared__ unsigned tab[256 * G];
-  __shared__ PipeStretch stretch;
-  const int lane = threadIdx.x & 63;
-  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
-  const unsigned wg = blockIdx.x + a.wg0;
-  const unsigned role = wg / ngroups, g = wg % ngroups;
-  static_for<0, Chain::NICM>([&](auto rc) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
-    if (role != (unsigned)r) return;
-    constexpr int I = Chain::ICM_COMP[r];
-    constexpr CompK c = Chain::comp[I];
-    constexpr int ri = Chain::P_ROW[I];
-    PipeLane<Chain> L[F];
-    unsigned col[F], nbmax = 0;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      col[f] = (unsigned)f * GL + (unsigned)lane;
-      L[f].open(a, g * G + ((unsigned)lane < GL ? col[f] : 0u), Chain::P_LEVEL[I]);
-      if ((unsigned)lane >= GL) { L[f].live = false; L[f].nb = 0; }
-      nbmax = max(nbmax, L[f].nb);
-    }
-    if (L[0].chunk < 0 || !pipe_any(nbmax > 0)) return;
-    stretch.load(a.tb, lane);
-    __syncthreads();
-    if (!nbmax) return;
-    unsigned byte[F], s[F], v[F];
-    uint2 w[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      byte[f] = 0; s[f] = 0; v[f] = 0; w[f].x = 0u; w[f].y = 0u;
-      if (L[f].nb) {
-        for (int e = 0; e < 256; e += 4) {
-          const uint4 q = L[f].A128((unsigned)c.t0 + 4u * e);
-          tab[e * G + col[f]] = q.x; tab[(e + 1) * G + col[f]] = q.y; tab[(e + 2) * G + col[f]] = q.z; tab[(e + 3) * G + col[f]] = q.w;
-        }
-        byte[f] = L[f].byte_at(0);
-        w[f] = L[f].bh(ri, 0);
-        s[f] = pipe_bh_get(w[f], 0);
-        v[f] = tab[s[f] * G + col[f]];
-      }
-    }
-    for (unsigned k = 0; k < nbmax; ++k) {
-      unsigned byten[F];
-      uint2 wn[F];
-      bool on[F];
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        on[f] = k < L[f].nb;
-        byten[f] = byte[f]; wn[f] = w[f];
-        if (on[f]) { const unsigned kn = L[f].next(k); byten[f] = L[f].byte_at(kn); wn[f] = L[f].bh(ri, kn); }
-      }
-      PipeP8 out[F];
-#pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        unsigned sn[F], vn[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          sn[f] = B < 7 ? pipe_bh_get(w[f], B + 1) : pipe_bh_get(wn[f], 0);
-          vn[f] = tab[sn[f] * G + col[f]];
-          out[f].set(B, stretch(v[f] >> 8));
-        }
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const unsigned nv = v[f] + (unsigned)((int)((unsigned)(pipe_y(byte[f], B) * 32767) - (v[f] >> 8)) >> 2);
-          if (on[f]) tab[s[f] * G + col[f]] = nv;
-          v[f] = sn[f] == s[f] ? nv : vn[f];
-          s[f] = sn[f];
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        if (on[f]) L[f].p(I, k) = out[f].get();
-        byte[f] = byten[f]; w[f] = wn[f];
-      }
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      if (L[f].nb)
-        for (int e = 0; e < 256; e += 4)
-          L[f].A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + col[f]], tab[(e + 1) * G + col[f]], tab[(e + 2) * G + col[f]], tab[(e + 3) * G + col[f]]);
-  });
-}
-
-template <class Chain>
-__device__ __forceinline__ void pipe_isse_ilp_body(const PipeArgs& a) {
-  constexpr unsigned G = Chain::PIPE_G;
-  constexpr int F = Chain::MAP_ILP;
-  constexpr unsigned GL = G / (unsigned)F;
-  __shared__ unsigned tab[512 * G];
-  __shared__ typename PipeSquashFor<Chain>::type squash;
-  const int lane = threadIdx.x & 63;
-  const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
-  const unsigned wg = blockIdx.x + a.wg0;
-  const unsigned role = wg / ngroups, g = wg % ngroups;
-  static_for<0, Chain::NISSE>([&](auto rc) __attribute__((always_inline)) {
-    constexpr int r = decltype(rc)::value;
-    if (role != (unsigned)r) return;
-    constexpr int I = Chain::ISSE_COMP[r];
-    constexpr CompK c = Chain::comp[I];
-    constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
-    PipeLane<Chain> L[F];
-    unsigned col[F], nbmax = 0;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      col[f] = (unsigned)f * GL + (unsigned)lane;
-      L[f].open(a, g * G + ((unsigned)lane < GL ? col[f] : 0u), Chain::P_LEVEL[I]);
-      if ((unsigned)lane >= GL) { L[f].live = false; L[f].nb = 0; }
-      nbmax = max(nbmax, L[f].nb);
-    }
-    if (L[0].chunk < 0 || !pipe_any(nbmax > 0)) return;
-    squash.load(a.tb, lane);
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      if (L[f].nb)
-        for (int e = 0; e < 512; e += 4) {
-          const uint4 q = L[f].A128((unsigned)c.t0 + 4u * e);
-          tab[e * G + col[f]] = q.x; tab[(e + 1) * G + col[f]] = q.y; tab[(e + 2) * G + col[f]] = q.z; tab[(e + 3) * G + col[f]] = q.w;
-        }
-    __syncthreads();
-    if (!nbmax) return;
-    unsigned byte[F], s[F];
-    int w0[F], w1[F];
-    uint2 w[F];
-    uint4 vj[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      byte[f] = 0; s[f] = 0; w0[f] = 0; w1[f] = 0; w[f].x = 0u; w[f].y = 0u; vj[f] = make_uint4(0u, 0u, 0u, 0u);
-      if (L[f].nb) {
-        byte[f] = L[f].byte_at(0);
-        w[f] = L[f].bh(ri, 0);
-        vj[f] = L[f].p(J, 0);
-        s[f] = pipe_bh_get(w[f], 0);
-        w0[f] = (int)tab[(2u * s[f]) * G + col[f]];
-        w1[f] = (int)tab[(2u * s[f] + 1u) * G + col[f]];
-      }
-    }
-    for (unsigned k = 0; k < nbmax; ++k) {
-      unsigned byten[F];
-      uint2 wn[F];
-      uint4 vjn[F];
-      bool on[F];
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        on[f] = k < L[f].nb;
-        byten[f] = byte[f]; wn[f] = w[f]; vjn[f] = vj[f];
-        if (on[f]) { const unsigned kn = L[f].next(k); byten[f] = L[f].byte_at(kn); wn[f] = L[f].bh(ri, kn); vjn[f] = L[f].p(J, kn); }
-      }
-      PipeP8 out[F];
-#pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        // every chain's table reads first, then every chain's arithmetic: one chain's LDS round trip runs under the others' work
-        unsigned sn[F];
-        int n0[F], n1[F], pj[F], sq[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          sn[f] = B < 7 ? pipe_bh_get(w[f], B + 1) : pipe_bh_get(wn[f], 0);
-          n0[f] = (int)tab[(2u * sn[f]) * G + col[f]];
-          n1[f] = (int)tab[(2u * sn[f] + 1u) * G + col[f]];
-          pj[f] = pipe_p_get(vj[f], B);
-          const int pr = sp_clamp2k((__mul24(w0[f], pj[f]) + w1[f] * 64) >> 16);          // 20-bit x 12-bit
-          out[f].set(B, pr);
-          sq[f] = squash(pr);
-        }
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const int err = pipe_y(byte[f], B) * 32767 - sq[f];
-          const int u0 = sp_clamp512k(w0[f] + ((__mul24(err, pj[f]) + (1 << 12)) >> 13));
-          const int u1 = sp_clamp512k(w1[f] + ((err + 16) >> 5));
-          if (on[f]) {
-            tab[(2u * s[f]) * G + col[f]] = (unsigned)u0;
-            tab[(2u * s[f] + 1u) * G + col[f]] = (unsigned)u1;
-          }
-          w0[f] = sn[f] == s[f] ? u0 : n0[f];
-          w1[f] = sn[f] == s[f] ? u1 : n1[f];
-          s[f] = sn[f];
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        if (on[f]) L[f].p(I, k) = out[f].get();
-        byte[f] = byten[f]; w[f] = wn[f]; vj[f] = vjn[f];
-      }
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      if (L[f].nb)
-        for (int e = 0; e < 512; e += 4)
-          L[f].A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + col[f]], tab[(e + 1) * G + col[f]], tab[(e + 2) * G + col[f]], tab[(e + 3) * G + col[f]]);
-  });
-}
-
 template <int QL>
 __device__ __forceinline__ int pipe_group_sum(int v) {
   if constexpr (QL >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -1580,7 +1253,8 @@ __device__ __forceinline__ int pipe_group_sum(int v) {
   return v;
 }
 
-// MIX with a lane per (block, BIT POSITION, weight quad).  A MIX whose context mask keeps the whole partial byte
+// MIX with a lane per (block, BIT POSITION, weight quad) -- latency mode (chains with few blocks in the batch: the MI355X
+// measurements in profiles/r03 put the crossover between 256 and 512 blocks).  A MIX whose context mask keeps the whole partial byte
 // (c.a5 == 255, at least 256 rows) selects a different weight row for each of a byte's 8 bits -- c8 is part of the row
 // index -- and training touches the selected row only, so with all bits known the 8 bits of a byte are independent:
 // 8 x QL lanes work on one byte at a time, the per-byte chain is one bit's ~70 instructions instead of eight bits' ~1000,
@@ -1591,7 +1265,7 @@ __device__ __forceinline__ int pipe_group_sum(int v) {
 // row range apart: any lane may have written it).
 template <class Chain>
 __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
-  __shared__ typename PipeSquashFor<Chain>::type squash;
+  __shared__ PipeSquash squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
@@ -1628,7 +1302,7 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
     }
     auto row_of = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
       const unsigned c8 = (1u << B) | (bytev >> (8u - B));           // pipe_c8 for a lane's own position
-      return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)m) + qoff;
+      return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)c.stride) + qoff;
     };
     auto input = [&](int x, unsigned kk) __attribute__((always_inline)) -> int {      // this position's half-word of the stream element
       return (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
@@ -1725,7 +1399,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     pipe_mix_bits_body<Chain>(a);
     return;
   } else {
-  __shared__ typename PipeSquashFor<Chain>::type squash;
+  __shared__ PipeSquash squash;
   const int lane = threadIdx.x & 63;
   const unsigned ngroups = (a.nblocks + Chain::PIPE_G - 1u) / Chain::PIPE_G;
   const unsigned wg = blockIdx.x + a.wg0;
@@ -1734,15 +1408,14 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
   static_for<0, Chain::NMIXR>([&](auto rc) __attribute__((always_inline)) {
     constexpr int r = decltype(rc)::value;
     constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r], first = Chain::MIX_FIRST[r];   // first = sum of QL of earlier roles
-    constexpr int SPLIT = Chain::MIX_SPLIT;        // wavefronts are 1 / SPLIT full: fewer lanes, more wavefronts
-    const unsigned per_group = (unsigned)(QL * SPLIT);                                        // wavefronts per group
-    if (wg < (unsigned)(first * SPLIT) * ngroups || wg >= (unsigned)((first + QL) * SPLIT) * ngroups) return;
+    const unsigned per_group = (unsigned)QL;                                                  // wavefronts per group
+    if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + QL) * ngroups) return;
     constexpr CompK c = Chain::comp[I];
     constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL / SPLIT, TAIL = m % 4;
+    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL, TAIL = m % 4;
     static_assert(BPW >= 1 && NQ <= QL, "MIX lane group");
     constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
-    const unsigned wi = wg - (unsigned)(first * SPLIT) * ngroups;
+    const unsigned wi = wg - (unsigned)first * ngroups;
     const unsigned g = wi / per_group, sub = wi % per_group;
     const unsigned bl = (unsigned)lane / QL, q = (unsigned)lane % QL;
     PipeLane<Chain> L;
@@ -1762,7 +1435,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
       tin[x] = J + (have[x] ? t : 0);
     }
     auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
-      return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)m) + qoff;   // s <= 24
+      return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)c.stride) + qoff;   // s <= 24
     };
     unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
     const unsigned k1 = L.next(0);

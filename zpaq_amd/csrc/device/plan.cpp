@@ -104,7 +104,8 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "MIX j >= i");
         if (cp[3] < 1 || cp[3] > i - cp[2]) fail(ZPQ_E_HEADER, "MIX m not in 1..i-j");
         c.mask0 = (1u << cp[1]) - 1;
-        c.t0 = seg(align_up((4ull * cp[3]) << cp[1], 16), F_U32, (uint32_t)(65536 / cp[3]));
+        c.stride = mix_row_stride(cp[3]);              // padded rows: one 128-byte line per row (layout.h)
+        c.t0 = seg(align_up((4ull * c.stride) << cp[1], 16), F_U32, (uint32_t)(65536 / cp[3]));
         mem += 4 * size * cp[3]; algo += 64.0 * cp[3];
         dep_mask |= 1ull << (i & 63);
         mix_mask |= 1ull << (i & 63);

@@ -61,6 +61,7 @@ struct CompK {
   unsigned long long t0, t1;   // arena byte offsets
   int lds;                     // byte offset of the side table in the wave's LDS region, or -1
   int slot;                    // ordinal among MIX (resp. SSE) components, else -1
+  unsigned stride = 0;         // MIX: words between weight rows (layout.h mix_row_stride)
 };
 
 struct SpecTables {                            // shared by the waves of a workgroup
@@ -597,7 +598,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
         constexpr int i = decltype(ic)::value;
         constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) {
-          const unsigned r = ((hmix[c.slot] + (unsigned)(c8 & 255)) & c.mask0) * c.a3;
+          const unsigned r = ((hmix[c.slot] + (unsigned)(c8 & 255)) & c.mask0) * c.stride;
           mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * r);
         }
         if constexpr (c.type == C_SSE && sse_pf(c)) {
@@ -611,10 +612,10 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         const unsigned hi = hmix[c.slot];
-        mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.a3;
+        mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.stride;
         if constexpr (mix_pf(c)) {
-          mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.a3));
-          mixc1[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.a3));
+          mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.stride));
+          mixc1[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.stride));
         } else {
           mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
         }
@@ -767,7 +768,7 @@ __device__ __forceinline__ void spec_kernel_body(const BlockJob* jobs, BlockResu
       constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         hmix_n[c.slot] = sp_rlu(h_next, i);
-        const unsigned r = ((hmix_n[c.slot] + (1u & c.a5)) & c.mask0) * c.a3;
+        const unsigned r = ((hmix_n[c.slot] + (1u & c.a5)) & c.mask0) * c.stride;
         ka2 ^= G32(mixbase[c.slot] + 4u * r);
       } else if constexpr (c.type == C_SSE) {
         hsse_n[c.slot] = sp_rlu(h_next, i);

@@ -114,8 +114,8 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
   return true;
 }
 
-bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not) {
-  if (!generate_pipe_source(plan, source, why_not)) return false;
+bool pipe_source_and_key(const zpq_plan& plan, const PipeOptions& opt, std::string& source, std::string& key, std::string& why_not) {
+  if (!generate_pipe_source(plan, opt, source, why_not)) return false;
   std::string h1, h2, h3;
   const std::string inc = spec_include_dir();
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) || !read_file(inc + "/pipe_kernel.h", h3)) {
@@ -264,18 +264,18 @@ static int precompile_in_processes(const std::vector<JitItem>& todo, int procs, 
 }
 
 int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int variant, int max_compiles, int threads,
-                    std::string* log) {
+                    std::string* log, const std::vector<int>* modes) {
   std::vector<JitItem> todo;
   std::vector<std::string> seen;
-  const bool no_pipe = getenv("ZPAQ_AMD_NO_PIPE") != nullptr, no_spec = getenv("ZPAQ_AMD_NO_SPEC") != nullptr;
-  for (const zpq_plan* p : plans) {
+  for (size_t pi = 0; pi < plans.size(); ++pi) {
+    const zpq_plan* p = plans[pi];
     if ((int)todo.size() >= max_compiles) break;
     if (!p || !p->hdr().wave_ok) continue;
     JitItem it;
     std::string why;
     bool have = false;
-    if (pipe && !no_pipe) have = pipe_source_and_key(*p, it.source, it.key, why);
-    if (!have && !no_spec) have = spec_source_and_key(*p, variant, it.source, it.key, why);
+    if (pipe) have = pipe_source_and_key(*p, pipe_options(modes && pi < modes->size() ? (*modes)[pi] : 0), it.source, it.key, why);
+    if (!have) have = spec_source_and_key(*p, variant, it.source, it.key, why);
     if (!have) continue;
     bool dup = false;
     for (const std::string& k : seen) dup = dup || k == it.key;
@@ -324,7 +324,6 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   if (plan->cur().spec_state[variant] > 0) return (SpecKernel*)plan->cur().spec[variant];
   if (plan->cur().spec_state[variant] < 0) return nullptr;
   plan->cur().spec_state[variant] = -1;
-  if (getenv("ZPAQ_AMD_NO_SPEC")) { plan->cur().spec_note = "disabled by ZPAQ_AMD_NO_SPEC"; return nullptr; }
   std::string source, key, why;
   if (!spec_source_and_key(*plan, variant, source, key, why)) { plan->cur().spec_note = why; return nullptr; }
   std::vector<char> code;
@@ -377,13 +376,13 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
   return k;
 }
 
-PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
-  if (plan->cur().pipe_state > 0) return (PipeKernel*)plan->cur().pipe;
-  if (plan->cur().pipe_state < 0) return nullptr;
-  plan->cur().pipe_state = -1;
-  if (getenv("ZPAQ_AMD_NO_PIPE")) { plan->cur().pipe_note = "disabled by ZPAQ_AMD_NO_PIPE"; return nullptr; }
+PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit, bool* did_jit) {
+  mode = mode ? 1 : 0;
+  if (plan->cur().pipe_state[mode] > 0) return (PipeKernel*)plan->cur().pipe[mode];
+  if (plan->cur().pipe_state[mode] < 0) return nullptr;
+  plan->cur().pipe_state[mode] = -1;
   std::string source, key, why;
-  if (!pipe_source_and_key(*plan, source, key, why)) { plan->cur().pipe_note = why; return nullptr; }
+  if (!pipe_source_and_key(*plan, pipe_options(mode), source, key, why)) { plan->cur().pipe_note = why; return nullptr; }
   std::vector<char> code;
   std::string origin, blob;
   const std::string path = spec_cache_dir() + "/" + key + ".hsaco";
@@ -394,7 +393,7 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
     origin = "cache:" + key;
   } else {
     if (!allow_jit) {
-      plan->cur().pipe_state = 0;
+      plan->cur().pipe_state[mode] = 0;
       plan->cur().pipe_note = "hipRTC compile deferred (JIT budget of this batch spent)";
       return nullptr;
     }
@@ -424,8 +423,8 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit, bool* did_jit) {
     return nullptr;
   }
   k->origin = origin;
-  plan->cur().pipe = k;
-  plan->cur().pipe_state = 1;
+  plan->cur().pipe[mode] = k;
+  plan->cur().pipe_state[mode] = 1;
   plan->cur().pipe_note = origin;
   return k;
 }
@@ -494,12 +493,13 @@ PcompKernel* pcomp_kernel_for(const U8* code, size_t len, int ph, int pm, std::s
 }
 
 void spec_kernel_release(zpq_plan* plan) {
-  if (plan && plan->cur().pipe) {
-    PipeKernel* k = (PipeKernel*)plan->cur().pipe;
+  for (int m = 0; plan && m < 2; ++m) {
+    if (!plan->cur().pipe[m]) continue;
+    PipeKernel* k = (PipeKernel*)plan->cur().pipe[m];
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
-    plan->cur().pipe = nullptr;
-    plan->cur().pipe_state = 0;
+    plan->cur().pipe[m] = nullptr;
+    plan->cur().pipe_state[m] = 0;
   }
   for (int v = 0; plan && v < 2; ++v) {
     if (!plan->cur().spec[v]) continue;

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "plan.hpp"
+#include "../host/codegen.hpp"
 
 namespace zpq {
 
@@ -36,8 +37,9 @@ struct PipeKernel {
   hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hcomp, rows, light, icm, isse, mix
   std::string origin;
 };
-PipeKernel* pipe_kernel_for(zpq_plan* plan, bool allow_jit = true, bool* did_jit = nullptr);
-bool pipe_source_and_key(const zpq_plan& plan, std::string& source, std::string& key, std::string& why_not);
+// mode: 0 throughput, 1 latency (host/codegen.hpp PipeOptions); one code object per (header, mode)
+PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit = true, bool* did_jit = nullptr);
+bool pipe_source_and_key(const zpq_plan& plan, const PipeOptions& opt, std::string& source, std::string& key, std::string& why_not);
 
 // A block's PCOMP post-processor translated for the device (device/pcomp_kernel.h), per (program, ph, pm) and device;
 // loaded kernels live until the process ends.  nullptr + note when the program cannot be translated or compiled.
@@ -54,11 +56,12 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
 // hipRTC compile only (no device needed, nothing loaded or cached): returns the code object size or 0, log filled.
 size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log);
 // Compiles (hipRTC, no device needed) the code objects the listed plans would need -- the pipelined encoder when
-// `pipe` (and the chain has one), the wavefront kernel of `variant` otherwise -- that are neither in the cache directory nor compiled
+// `pipe` (and the chain has one; modes[i] = the mode plan i will run in, throughput when `modes` is null), the wavefront
+// kernel of `variant` otherwise -- that are neither in the cache directory nor compiled
 // earlier in this process, on up to `threads` host threads at once, at most `max_compiles` of them.  Results go to the
 // cache directory (when writable) and to an in-process store the loaders look into first.  Returns the number compiled.
 int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int variant, int max_compiles, int threads,
-                    std::string* log = nullptr);
+                    std::string* log = nullptr, const std::vector<int>* modes = nullptr);
 std::string spec_include_dir();
 std::string spec_cache_dir();
 

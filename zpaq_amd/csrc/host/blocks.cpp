@@ -178,7 +178,7 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     const Assembled as = assemble(cfg.c_str(), args);
     // The segment trailer carries the SHA-1 of the ORIGINAL block.  A modelled block that is coded as it is goes to the
     // device unchanged, so it is hashed there (sha1_blocks_kernel, beside the coder); everything else here.
-    w.sha1_on_device = dosha1 && args[1] == 0 && as.hcomp[6] != 0 && !getenv("ZPAQ_AMD_HOST_SHA1");
+    w.sha1_on_device = dosha1 && args[1] == 0 && as.hcomp[6] != 0;
     if (dosha1 && !w.sha1_on_device) { Sha1 s; s.update(in[b].data, n); memcpy(w.sha1, s.result(), 20); }
     if ((U64)n + 4096 > (0x100000ull << args[0])) fail(ZPQ_E_ARG, "block larger than the method's block size");
     // LZ77 / BWT / E8E9 (libzpaq.cpp:7709-7716); E8E9 rewrites the caller's buffer in place, as the reference does
@@ -434,14 +434,14 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
   // DEVICE when there is enough of them to fill lanes: one lane per segment, the program translated like HCOMP
   // (device/pcomp_kernel.h).  Blocks of several segments share one machine across segments and small jobs are not
   // worth a launch: those run through the host interpreter (host/postproc.cpp), like stored blocks on a box without
-  // a GPU.  ZPAQ_AMD_PCOMP=device|host forces one.
+  // a GPU.  ZPAQ_AMD_PCOMP=device|host forces one (interpret: host, and the interpreter instead of the translated programs).
   std::vector<size_t> per_block(nblocks, 0);
   for (auto& s : segs) ++per_block[s->block];
   std::vector<std::vector<U8>> done(segs.size());
   std::vector<char> on_device(segs.size(), 0);
   {
     const char* mode = getenv("ZPAQ_AMD_PCOMP");
-    const bool force_dev = mode && !strcmp(mode, "device"), force_host = mode && !strcmp(mode, "host");
+    const bool force_dev = mode && !strcmp(mode, "device"), force_host = mode && (!strcmp(mode, "host") || !strcmp(mode, "interpret"));
     std::map<std::vector<U8>, std::vector<size_t>> by_prog;     // key: ph pm code
     U64 prog_bytes = 0;
     for (size_t i = 0; i < segs.size() && !force_host; ++i) {

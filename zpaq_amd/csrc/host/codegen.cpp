@@ -220,7 +220,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
     if (c.type == C_MIX && (c.a3 > 64 || c.a2 + c.a3 > 64)) { why_not = "MIX wider than a wavefront"; return false; }
     comps << "    {" << c.type << "u," << c.a1 << "u," << c.a2 << "u," << c.a3 << "u," << c.a4 << "u," << c.a5 << "u, "
           << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, " << lds << ","
-          << slot << "},\n";
+          << slot << "," << c.stride << "u},\n";
   }
   o << "  static constexpr int N = " << n << ", NMIX = " << nmix << ", NSSE = " << nsse << ", WAVES = " << waves << ";\n"
     << "  static constexpr unsigned HMASK = " << ph.hmask << "u, MMASK = " << ph.mmask << "u;\n"
@@ -248,7 +248,13 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
 
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined encoder: dataflow levels + buffer layout (see device/pipe_kernel.h for the design)
-bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
+PipeOptions pipe_options(int mode) {
+  PipeOptions o;
+  o.mode = mode ? 1 : 0;
+  return o;
+}
+
+bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, std::string& why_not) {
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
@@ -256,34 +262,14 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   const CompDesc* comp = plan.comps();
   L = PipeLayout();
   L.n = n;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_CHUNK")) {
-    const int c = atoi(e);
-    if (c >= 64 && c <= 8192 && (c & (c - 1)) == 0) L.C = c;
-  }
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_GROUP")) {
-    const int g = atoi(e);
-    if (g == 8 || g == 16 || g == 32 || g == 64) L.G = g;
-  }
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_SPLIT")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) L.mix_split = v;
-  }
+  L.mode = opt.mode ? 1 : 0;
+  if (opt.chunk >= 64 && opt.chunk <= 8192 && (opt.chunk & (opt.chunk - 1)) == 0) L.C = opt.chunk;
+  if (opt.group == 8 || opt.group == 16 || opt.group == 32 || opt.group == 64) L.G = opt.group;
   enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind
-  int qforce = 0;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_LANES")) qforce = atoi(e);
-  bool want_mix_bits = false;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_BITS")) want_mix_bits = atoi(e) != 0;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_MIX_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.mix_depth = v; }
   bool mix_bits_ok = true;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_FULL_SQUASH")) L.full_squash = atoi(e) != 0;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_MAP_ILP")) { const int v = atoi(e); if ((v == 2 || v == 4) && L.G % v == 0 && L.G / v >= 1) L.map_ilp = v; }
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_NIBBLES")) L.row_nibbles = atoi(e) != 0 && L.G <= 32;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_FLAT")) L.row_flat = atoi(e) != 0;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_ROW_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.row_depth = v; }
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_LIGHT_BITS")) L.light_bits = L.G % 8 == 0 ? atoi(e) & 7 : 0;     // 1 CM | 2 MIX2 | 4 SSE
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_LIGHT_DEPTH")) { const int v = atoi(e); if (v >= 1 && v <= 4) L.light_depth = v; }
+  L.light_bits = L.mode ? 7 : 4;           // 1 CM | 2 MIX2 | 4 SSE
   enum { K_CM_BITS = 9, K_MIX2_BITS, K_SSE_BITS };
-  // a light unit: one workgroup per group, or -- a lane per bit position -- eight
+  // a light unit: one workgroup per group, or -- a lane per bit position -- G / 8 of them (64 lanes = 8 blocks x 8 positions)
   auto light_unit = [&](int kind, int bits_kind, bool bits_ok, int i) {
     if (bits_ok && (L.light_bits >> (bits_kind - K_CM_BITS) & 1)) { for (int sub = 0; sub < L.G * 8 / L.light_threads(); ++sub) { L.light.push_back({bits_kind, i}); L.light_sub.push_back(sub); } }
     else { L.light.push_back({kind, i}); L.light_sub.push_back(0); }
@@ -309,9 +295,7 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
         const int m = (int)c.a3, nq = (m + 3) / 4;     // lanes that hold weights: 4 per lane, one 16-byte access
         int ql = 1;
         while (ql < nq) ql *= 2;
-        if (qforce > ql && (qforce == 2 || qforce == 4 || qforce == 8 || qforce == 16)) ql = qforce;
         if (ql > L.G) { why_not = "MIX lane group wider than the block group"; return false; }
-        while (L.mix_split > 1 && ql * L.mix_split > L.G) L.mix_split /= 2;
         L.mix.push_back(i);
         L.mix_ql.push_back(ql);
         // a lane per bit position: the 8 rows of a byte must be distinct and a block's 8 x ql lanes fit one wavefront
@@ -322,12 +306,11 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
     }
     L.level[i] = lv;
   }
-  if (want_mix_bits && mix_bits_ok && !L.mix.empty()) { L.mix_bits = 1; L.mix_split = 1; }
+  if (L.mode && mix_bits_ok && !L.mix.empty()) L.mix_bits = 1;
   // ROW units (level 1) have a kernel of their own; the light kernel: the components in COMP order, then the coder
   for (int i = 0; i < n; ++i) if (L.row[i] >= 0) L.rows.push_back(i);
   light_unit(K_CODER, K_CM_BITS, false, n - 1);
   L.coder_level = L.level[n - 1] + 1;
-  if (const char* e = getenv("ZPAQ_AMD_PIPE_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 16) L.slack = v; }
   L.S = L.coder_level + 1 + L.slack;
   {
     // which kernel produces the p stream of component i, and who reads what
@@ -363,13 +346,13 @@ bool pipe_layout(const zpq_plan& plan, PipeLayout& L, std::string& why_not) {
   L.off_p = off;     off += S * (uint64_t)n * C * G * 16;
   L.off_state = off; off += (uint64_t)L.nstate * G * 4;
   L.group_bytes = (off + 4095) & ~4095ull;
-  if (L.group_bytes >= (1ull << 32)) { why_not = "stream buffer of a block group exceeds 4 GiB (lower ZPAQ_AMD_PIPE_CHUNK)"; return false; }
+  if (L.group_bytes >= (1ull << 32)) { why_not = "stream buffer of a block group exceeds 4 GiB"; return false; }
   return true;
 }
 
-bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string& why_not) {
+bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::string& source, std::string& why_not) {
   PipeLayout L;
-  if (!pipe_layout(plan, L, why_not)) return false;
+  if (!pipe_layout(plan, opt, L, why_not)) return false;
   const PlanHeader& ph = plan.hdr();
   const int n = L.n;
   const CompDesc* comp = plan.comps();
@@ -386,7 +369,7 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
     if (c.type == C_MIX) slot = nmix++;
     if (c.type == C_SSE) slot = nsse++;
     comps << "    {" << c.type << "u," << c.a1 << "u," << c.a2 << "u," << c.a3 << "u," << c.a4 << "u," << c.a5 << "u, "
-          << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, -1," << slot << "},\n";
+          << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, -1," << slot << "," << c.stride << "u},\n";
   }
   auto arr = [&](const char* name, const int* v, int cnt) {
     o << "  static constexpr int " << name << "[" << std::max(cnt, 1) << "] = {";
@@ -416,15 +399,14 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
   for (auto& r : L.light) { lk.push_back(r.first); lc.push_back(r.second); }
   int first = 0;
   // MIX_FIRST: lane groups of earlier MIX roles (x MIX_SPLIT = wavefronts per group); with bit lanes: their wavefronts per group
-  for (int q : L.mix_ql) { mf.push_back(first); first += L.mix_bits ? L.mix_waves_of(q) : q; }
-  o << "  static constexpr int MIX_SPLIT = " << L.mix_split << ", MIX_BITS = " << L.mix_bits << ", MIX_DEPTH = " << L.mix_depth << ";\n";
+  for (int q : L.mix_ql) { mf.push_back(first); first += L.mix_waves_of(q); }
+  o << "  static constexpr int PIPE_MODE = " << L.mode << ", MIX_BITS = " << L.mix_bits << ", MIX_DEPTH = " << L.depth << ";\n";
   o << "  static constexpr int NROWU = " << L.rows.size() << ", NLIGHT = " << L.light.size() << ", NICM = " << L.icm.size() << ", NISSE = " << L.isse.size()
     << ", NMIXR = " << L.mix.size() << ";\n";
   arr("LIGHT_KIND", lk.data(), (int)lk.size());
   arr("LIGHT_COMP", lc.data(), (int)lc.size());
   arr("LIGHT_SUB", L.light_sub.data(), (int)L.light_sub.size());
-  o << "  static constexpr int LIGHT_THREADS = " << L.light_threads() << ", FULL_SQUASH = " << L.full_squash << ", MAP_ILP = " << L.map_ilp << ";\n";
-  o << "  static constexpr int LIGHT_DEPTH = " << L.light_depth << ", ROW_NIBBLES = " << L.row_nibbles << ", ROW_DEPTH = " << L.row_depth << ", ROW_FLAT = " << L.row_flat << ";\n";
+  o << "  static constexpr int LIGHT_THREADS = " << L.light_threads() << ", LIGHT_DEPTH = " << L.depth << ";\n";
   arr("ROW_COMP", L.rows.data(), (int)L.rows.size());
   arr("ICM_COMP", L.icm.data(), (int)L.icm.size());
   arr("ISSE_COMP", L.isse.data(), (int)L.isse.size());
@@ -437,7 +419,7 @@ bool generate_pipe_source(const zpq_plan& plan, std::string& source, std::string
        "}  // namespace zpq_gen\n";
   const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
   for (int k = 0; k < 6; ++k)
-    o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << names[k] << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp: 64)
+    o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << names[k] << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp, light, bit-lane mix: 64)
          "  ZPQ_PIPE_TRACE(a, " << k << ");\n"
          "  zpq::pipe_" << names[k] << "_body<zpq_gen::Chain>(a);\n}\n";
   source = o.str();

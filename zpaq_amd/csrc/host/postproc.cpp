@@ -33,10 +33,9 @@ class PcompVm {
     // standard programs need a few dozen steps per array element at most (inverse BWT at the end of a segment): 64 per
     // element of H and M, and never less than 2^28, ends a hostile stream in about a second instead of a minute.  That
     // bound is only safe for programs whose cost is known, so it applies to the standard ones (set_standard(true)); a
-    // custom program keeps 2^34 steps per call (about a minute), or ZPAQ_AMD_PCOMP_MAX_STEPS if the caller sets it --
-    // the one deviation from the reference here, which would never give up.
+    // custom program keeps 2^34 steps per call (about a minute) -- the one deviation from the reference here, which
+    // would never give up.
     max_steps_ = (U64)1 << 34;
-    if (const char* e = getenv("ZPAQ_AMD_PCOMP_MAX_STEPS")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v) max_steps_ = v; }
     tight_steps_ = std::max<U64>((U64)1 << 28, 64ull * ((U64)H_.size() + (U64)M_.size()));
   }
 
@@ -171,7 +170,7 @@ const PcompStd* standard_program(const std::vector<U8>& prog, int ph, int pm) {
   return nullptr;
 }
 const PcompStd* translated(const std::vector<U8>& prog, int ph, int pm) {
-  if (getenv("ZPAQ_AMD_PCOMP_INTERPRET")) return nullptr;
+  if (const char* m = getenv("ZPAQ_AMD_PCOMP")) { if (!strcmp(m, "interpret")) return nullptr; }     // tests: the interpreter instead of the translated program
   return standard_program(prog, ph, pm);
 }
 

@@ -77,10 +77,13 @@ static bool cpu_has_sha() {
 }
 #endif
 
+static bool g_sha1_portable = false;          // tests: zpq_sha1_force_portable()
+void sha1_force_portable(bool yes) { g_sha1_portable = yes; }
+
 void sha1_compress(U32 h_[5], const U8* p) {
 #if defined(__x86_64__)
-  static const bool shani = cpu_has_sha() && !getenv("ZPAQ_AMD_NO_SHANI");   // the variable exists for the tests
-  if (shani) { sha1_compress_shani(h_, p); return; }
+  static const bool shani = cpu_has_sha();
+  if (shani && !g_sha1_portable) { sha1_compress_shani(h_, p); return; }
 #endif
   sha1_compress_scalar(h_, p);
 }

@@ -70,16 +70,17 @@ def source_and_key(header):
     return buf.value.decode(), key.value.decode()
 
 
-def pipe_source_and_key(header):
-    """The pipelined encoder of this header (device/pipe_kernel.h): source + cache key, or (None, reason)."""
+def pipe_source_and_key(header, mode=0):
+    """The pipelined encoder of this header (device/pipe_kernel.h) in one of its two shapes (mode 0 throughput, 1 latency):
+    source + cache key, or (None, reason)."""
     import zpaq_amd as z
     L = z.lib()
-    L.zpq_plan_pipe_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    L.zpq_plan_pipe_source_opts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
     p = z.Plan(header)
     buf = C.create_string_buffer(4 << 20)
     ln = C.c_size_t(0)
     key = C.create_string_buffer(41)
-    rc = L.zpq_plan_pipe_source(p._h, buf, len(buf), C.byref(ln), key)
+    rc = L.zpq_plan_pipe_source_opts(p._h, mode, 0, 0, buf, len(buf), C.byref(ln), key)
     if rc != 0:
         return None, L.zpq_last_error().decode()
     return buf.value.decode(), key.value.decode()
@@ -139,7 +140,7 @@ def compile_one(args):
     return key, "built"
 
 
-def main(verbose=True):
+def main(verbose=True, clean=True):
     import zpaq_amd as z
     L = z.lib()
     L.zpq_spec_cache_dir.restype = C.c_char_p
@@ -153,10 +154,11 @@ def main(verbose=True):
     # workgroup for batches of up to 4 x CUs blocks, 8 per workgroup (two wavefronts per SIMD) beyond that
     forced = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
     for h, why in standard_headers().items():
-        src, key = pipe_source_and_key(h)
-        if src is not None and key not in seen:
-            seen.add(key)
-            jobs.append((src, key, cache, inc))
+        for mode in (0, 1):
+            src, key = pipe_source_and_key(h, mode)
+            if src is not None and key not in seen:
+                seen.add(key)
+                jobs.append((src, key, cache, inc))
         for waves in ("4", "8"):
             os.environ["ZPAQ_AMD_SPEC_WAVES"] = waves
             src, key = source_and_key(h)
@@ -178,7 +180,7 @@ def main(verbose=True):
         os.environ["ZPAQ_AMD_SPEC_WAVES"] = forced
     # drop stale code objects of older template versions
     for fn in os.listdir(cache):
-        if fn.endswith(".hsaco") and fn[:-6] not in seen and not os.environ.get("ZPAQ_AMD_KEEP_CACHE"):
+        if clean and fn.endswith(".hsaco") and fn[:-6] not in seen:       # (--keep: experiments keep their variants)
             os.remove(os.path.join(cache, fn))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         res = list(ex.map(compile_one, jobs))
@@ -189,4 +191,4 @@ def main(verbose=True):
 
 
 if __name__ == "__main__":
-    main()
+    main(clean="--keep" not in sys.argv)
