@@ -225,7 +225,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=1024, help="blocks per GPU (weak scaling) or in total (--scaling strong)")
+    ap.add_argument("--blocks", type=int, default=None,
+                    help="blocks per GPU (weak scaling) or in total (--scaling strong); default 1024 (BASELINE configs[2]), and "
+                         "2048 with --mode decode: configs[4] decodes the 8192-block archive of the 8-GPU run on ONE GPU, "
+                         "which holds 2048 blocks of model state at a time -- one such residency wave is a step")
     ap.add_argument("--block-bytes", type=int, default=1 << 20)
     ap.add_argument("--kind", default="text", help="text | lcg | zeros | records | pattern | mixed (configs[3])")
     ap.add_argument("--method", default="5")
@@ -247,6 +250,8 @@ def main():
                     help="N>1 in ONE process: zpq_init(-1), one engine per device inside the library, the host-buffer batch "
                          "sharded over them (no torch.distributed)")
     a = ap.parse_args()
+    if a.blocks is None:
+        a.blocks = 2048 if a.mode == "decode" else 1024
 
     import torch
 
@@ -550,16 +555,23 @@ def main():
         api_archives = None
         napi = nb if a.api_blocks < 0 else min(a.api_blocks, nb)
         if napi and a.mode == "encode" and world == 1:
-            t0 = time.perf_counter()
-            api_archives = z.compress_blocks([blocks[i] for i in range(napi)], a.method)
-            wall = time.perf_counter() - t0
-            ph = (C.c_double * 8)()
-            L.zpq_last_api_timing(ph)
+            # twice: the first call of a process also allocates the engine's staging / IO buffers (page-locked host memory,
+            # device buffers); a service calls again and again -- the second call is the one reported, the first one beside it
+            first_ms = None
+            for _ in range(2 if a.warmup > 0 else 1):
+                t0 = time.perf_counter()
+                api_archives = z.compress_blocks([blocks[i] for i in range(napi)], a.method)
+                wall = time.perf_counter() - t0
+                ph = (C.c_double * 8)()
+                L.zpq_last_api_timing(ph)
+                if first_ms is None:
+                    first_ms = ph[0]
             line["api"] = {"value": napi * bs / 1e6 / (ph[0] / 1e3) if ph[0] else None, "unit": "MB/s", "blocks": napi,
                            "what": "zpq_compress_blocks on host buffers: SHA-1 + method expansion + header assembly, "
                                    "staging + H2D, Predictor init + coding kernels, D2H, archive framing",
                            "ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3],
-                                  "kernel_init": ph[4], "kernel_code": ph[5], "python_wall": wall * 1e3}}
+                                  "kernel_init": ph[4], "kernel_code": ph[5], "python_wall": wall * 1e3,
+                                  "library_total_first_call": first_ms}}
         if a.cpu_seconds > 0 and a.mode == "decode":
             base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
             line["cpu_baseline"] = base

@@ -96,7 +96,7 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * [9] blocks per group (= threads per workgroup of every kernel but hcomp, which has 64), [10] ROW units,
  * [11] threads per workgroup of the mix kernel, [12] of the rows kernel, [13] of the light kernel.
  * The encoder has two shapes per chain: mode 0 "throughput" (a lane per block; batches that fill the GPU) and mode 1
- * "latency" (MIX / CM / MIX2 with a lane per bit position as well; the engine uses it for chains with at most 384 blocks
+ * "latency" (MIX / CM / MIX2 with a lane per bit position as well; the engine uses it for chains with at most 640 blocks
  * in the batch).  The plain calls give mode 0; the _opts calls take the mode and, for tests, the chunk (bytes per step,
  * 0 = 512) and the group (blocks per wavefront, 0 = 32). */
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -72,7 +73,18 @@ double run(unsigned char* base, unsigned long long region_bytes, unsigned nregio
   return accesses / (ms * 1e-3) / 1e9;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--calib")) {
+    // two launches with known transaction counts, for calibrating the PMC counters (FETCH_SIZE / WRITE_SIZE per random row):
+    // 2048 x 64 lanes x 256 iterations x 4 = 134 217 728 random 16-byte loads, then as many load + store pairs, over 32 GiB
+    unsigned char* b = nullptr; unsigned* sk = nullptr;
+    CK(hipMalloc((void**)&b, (32ull << 20) * 1024)); CK(hipMemset(b, 0, (32ull << 20) * 1024)); CK(hipMalloc((void**)&sk, 64));
+    hipLaunchKernelGGL((gups<0, 4>), dim3(2048), dim3(64), 0, 0, b, 32ull << 20, 1024u, 64u, 256, sk);
+    hipLaunchKernelGGL((gups<1, 4>), dim3(2048), dim3(64), 0, 0, b, 32ull << 20, 1024u, 64u, 256, sk);
+    CK(hipDeviceSynchronize());
+    printf("calib: 134217728 loads, then 134217728 load+store pairs\n");
+    return 0;
+  }
   size_t free_b = 0, total_b = 0;
   CK(hipMemGetInfo(&free_b, &total_b));
   const unsigned nregions = 1024;

@@ -89,6 +89,12 @@ void block_barrier() {
   to_scheduler();
 }
 
+// a lane polling memory another wavefront of the workgroup writes: let everybody else run, then look again
+void spin_yield() {
+  g_cur->state = READY;
+  to_scheduler();
+}
+
 unsigned long cross_lane_ops() { return g_ops; }
 
 void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) {

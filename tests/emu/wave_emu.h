@@ -54,6 +54,7 @@ extern Dim3 g_threadIdx, g_blockIdx, g_blockDim;   // of the fiber that is runni
 // block until all 64 lanes of this fiber's wavefront are here (returns the lane's exchange row)
 int* wave_exchange(int value);          // publish `value`, wait, return pointer to the 64 published values
 void block_barrier();                   // __syncthreads
+void spin_yield();                      // inside a poll loop on LDS / memory another wavefront writes
 int lane_id();
 
 typedef void (*KernelFn)(void* args);

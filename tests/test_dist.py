@@ -95,3 +95,20 @@ def test_torch_corpus_generator_on_cpu():
     o = corpus_torch.text_blocks(3, 50000, 777, torch.device("cpu"), chunk=2).numpy()
     for b in range(3):
         assert (o[b] == corpus.zipf_text(50000, 777 + b)).all()
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` starts its own N ranks (torch.distributed.run, RCCL); with fewer than N GPUs visible it
+    must say so instead of running everything on one device and printing n_gpus: 1 (here: no GPU at all)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 2 requested but only" in (r.stderr + r.stdout), (r.stdout + r.stderr)[-800:]
+    # ... and under a launcher whose world size disagrees with --gpus
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

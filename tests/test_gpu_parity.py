@@ -481,3 +481,46 @@ def test_pcomp_post_processing_on_the_device(gpu, ref, monkeypatch, mode):
         parts.append(exe.tobytes())
         stream += ref.compress_block(exe.copy(), m)
     assert gpu.decompress(stream) == b"".join(parts)
+
+
+def test_state_budget_forces_residency_waves_and_out_of_memory_recovers(gpu, oracle):
+    """zpq_set_state_budget: a batch whose model state exceeds the budget is coded in several residency waves
+    (engine.cpp, engine_code_host_on) -- same bytes as in one wave; a budget below ONE block's state fails with NOMEM
+    ("Out of memory", the reference's message for it) and the next call, with the budget restored, works."""
+    blocks = [corpus.block(["text", "records", "lcg"][i % 3], 20000 + 13 * i, 900 + i) for i in range(11)]
+    whole = gpu.compress_blocks(blocks, "5")
+    h = parse_block(whole[0])["header"]
+    state = gpu.Plan(h).state_bytes
+    try:
+        gpu.set_state_budget(3 * state + (state >> 1))            # 3 blocks per wave -> 4 waves
+        assert gpu.compress_blocks(blocks, "5") == whole
+        assert gpu.decompress(b"".join(whole)) == b"".join(b.tobytes() for b in blocks)      # the decoder's waves as well
+        gpu.set_state_budget(state // 2)
+        with pytest.raises(gpu.ZpaqError) as ei:
+            gpu.compress_blocks(blocks[:2], "5")
+        assert ei.value.code == 1 and "ut of memory" in str(ei.value)
+    finally:
+        gpu.set_state_budget(0)
+    assert gpu.compress_blocks(blocks, "5") == whole
+
+
+def test_two_engines_shard_one_batch(gpu):
+    """zpq_init(-1) with ZPAQ_AMD_DEVICES=0,0: two engines (two slots: own streams, arenas, loaded code objects) on the one
+    GPU this box has -- the in-library sharding path of an N-GPU node (engine_code_host_now: contiguous block ranges,
+    one host thread per engine).  Archives must come back in block order and equal the single-engine result."""
+    import subprocess
+    blocks = [corpus.block(["text", "lcg", "records", "zeros"][i % 4], 30000 + 7 * i, 300 + i) for i in range(37)]
+    alone = gpu.compress_blocks(blocks, "5")
+    code = ("import os, sys, hashlib\n"
+            "os.environ['ZPAQ_AMD_DEVICES'] = '0,0'\n"
+            "sys.path.insert(0, %r)\n"
+            "import zpaq_amd as z\n"
+            "from zpaq_amd import corpus\n"
+            "z.init(-1)\n"
+            "blocks = [corpus.block(['text', 'lcg', 'records', 'zeros'][i %% 4], 30000 + 7 * i, 300 + i) for i in range(37)]\n"
+            "arch = z.compress_blocks(blocks, '5')\n"
+            "assert z.decompress(b''.join(arch)) == b''.join(b.tobytes() for b in blocks)\n"
+            "print('DIGEST', hashlib.sha1(b''.join(arch)).hexdigest(), len(arch))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "DIGEST %s 37" % hashlib.sha1(b"".join(alone)).hexdigest() in r.stdout

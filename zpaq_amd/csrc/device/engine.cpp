@@ -86,7 +86,8 @@ struct Event {
 struct Engine {
   std::mutex mu;
   bool ready = false;
-  int device = -1;
+  int device = -1;                     // HIP device this engine drives
+  int slot = 0;                        // its index in g_engines = the slot of every plan's per-engine state (zpq_plan::dev[])
   hipStream_t stream = nullptr;
   DeviceTables* d_tables = nullptr;
   uint64_t budget = 0;
@@ -105,14 +106,19 @@ struct Engine {
   hipEvent_t busy = nullptr;           // recorded after the last launch of a call that returned with work in flight
 };
 
-// One engine per GPU.  `primary` serves the device-resident entry points and every batch when only one device is
-// configured; host-buffer batches are sharded over `ids` (contiguous block ranges, one thread and one engine per
-// device, no collective: blocks are independent, libzpaq.h:57-59).  Default: the one device LOCAL_RANK names (one
-// process per GPU under torch.distributed / zpaq_amd.dist); zpq_init(-1) or ZPAQ_AMD_DEVICES=all|0,1,.. selects more.
+// One engine per configured GPU, each in its own SLOT of g_engines.  `primary` serves the device-resident entry points
+// and every batch when only one engine is configured; host-buffer batches are sharded over `ids` (the slots in use:
+// contiguous block ranges, one thread and one engine each, no collective: blocks are independent, libzpaq.h:57-59).
+// Default: one engine for the device LOCAL_RANK names (one process per GPU under torch.distributed / zpaq_amd.dist), in
+// the slot of that number; zpq_init(-1) or ZPAQ_AMD_DEVICES=all|0,1,.. configures more -- slot i drives the i-th device
+// named, and a device may be named twice (two engines, two streams sets, two arenas on one GPU: how the sharding path is
+// exercised on a one-GPU box).
 struct DeviceSet {
   std::mutex mu;
-  std::vector<int> ids;
+  std::vector<int> ids;                // slots in use
+  int dev_of[zpq_plan::kMaxDevices];   // slot -> HIP device (-1: the slot's own number)
   int primary = -1;
+  DeviceSet() { for (int& d : dev_of) d = -1; }
   uint64_t budget_override = 0;
   int kernel_choice = 0;
 };
@@ -134,16 +140,23 @@ int primary_device() {
   return d.primary;
 }
 
-Engine& eng(int dev = -1) {
-  if (dev < 0) dev = primary_device();
-  return g_engines[dev];
+Engine& eng(int slot = -1) {
+  if (slot < 0) slot = primary_device();
+  return g_engines[slot];
 }
 
-// binds the calling thread to a device: HIP's current device and the plan slot the loaders address
-void bind_device(int dev) {
-  HIP_CHECK(hipSetDevice(dev));
-  set_plan_device_index(dev);
+int device_of_slot(int slot) {
+  DeviceSet& d = devset();
+  std::lock_guard<std::mutex> g(d.mu);
+  return d.dev_of[slot] >= 0 ? d.dev_of[slot] : slot;
 }
+
+// binds the calling thread to an engine: HIP's current device and the plan slot the loaders address
+void bind_slot(int device, int slot) {
+  HIP_CHECK(hipSetDevice(device));
+  set_plan_device_index(slot);
+}
+void bind_device(Engine& e) { bind_slot(e.device, e.slot); }
 
 // hipRTC compilations one call may spend on headers nobody compiled before (the rest of that call's unseen headers
 // run on the generic kernel and are picked up by later calls), and the host threads that compile side by side
@@ -158,22 +171,23 @@ int jit_threads() {
   return (int)std::max(1u, std::min(hw, 16u));
 }
 
-void engine_init_device(Engine& e, int device);
-void require_ready(Engine& e, int dev = -1) {
-  if (!e.ready) engine_init_device(e, dev < 0 ? primary_device() : dev);   // lazy default init
+void engine_init_device(Engine& e, int slot, int device);
+void require_ready(Engine& e, int slot = -1) {
+  if (slot < 0) slot = primary_device();
+  if (!e.ready) engine_init_device(e, slot, device_of_slot(slot));          // lazy default init
 }
 
 }  // namespace
 
 namespace {
-void engine_init_device(Engine& e, int device) {
-  if (e.ready && e.device == device) return;
+void engine_init_device(Engine& e, int slot, int device) {
+  if (e.ready && e.device == device && e.slot == slot) return;
   int count = 0;
   hipError_t err = hipGetDeviceCount(&count);
   if (err != hipSuccess || count <= 0)
     fail(ZPQ_E_DEVICE, "no HIP device available (the modelled path has no CPU fallback)");
   if (device < 0 || device >= count) fail(ZPQ_E_DEVICE, "no such HIP device: " + std::to_string(device));
-  bind_device(device);
+  bind_slot(device, slot);
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
@@ -200,6 +214,7 @@ void engine_init_device(Engine& e, int device) {
   { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); e.budget = d.budget_override; e.kernel_choice = d.kernel_choice; }
   if (!e.budget) e.budget = (uint64_t)(free_b * 0.85);
   e.device = device;
+  e.slot = slot;
   e.ready = true;
 }
 }  // namespace
@@ -215,14 +230,18 @@ void engine_init(int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     fail(ZPQ_E_DEVICE, "no HIP device available (the modelled path has no CPU fallback)");
-  std::vector<int> ids;
+  std::vector<int> ids, devs;            // slots and the device each drives
   const char* env = getenv("ZPAQ_AMD_DEVICES");
-  if (device >= 0 && !(env && env[0])) ids.push_back(device % count);
-  else if (!env || !env[0] || !strcmp(env, "all")) { for (int i = 0; i < count && i < zpq_plan::kMaxDevices; ++i) ids.push_back(i); }
+  if (device >= 0 && !(env && env[0])) { ids.push_back(device % count); devs.push_back(device % count); }
+  else if (!env || !env[0] || !strcmp(env, "all")) { for (int i = 0; i < count && i < zpq_plan::kMaxDevices; ++i) { ids.push_back(i); devs.push_back(i); } }
   else {
+    // an explicit list: slot i drives the i-th device named (a device may be named more than once)
     for (const char* p = env; *p;) {
-      if (*p >= '0' && *p <= '9') { const int v = atoi(p); if (v < count && v < zpq_plan::kMaxDevices) ids.push_back(v); while (*p >= '0' && *p <= '9') ++p; }
-      else ++p;
+      if (*p >= '0' && *p <= '9') {
+        const int v = atoi(p);
+        if (v < count && (int)ids.size() < zpq_plan::kMaxDevices) { ids.push_back((int)ids.size()); devs.push_back(v); }
+        while (*p >= '0' && *p <= '9') ++p;
+      } else ++p;
     }
     if (ids.empty()) fail(ZPQ_E_ARG, "ZPAQ_AMD_DEVICES names no usable device");
   }
@@ -230,14 +249,19 @@ void engine_init(int device) {
     DeviceSet& d = devset();
     std::lock_guard<std::mutex> g(d.mu);
     d.ids = ids;
-    d.primary = (device >= 0 && std::find(ids.begin(), ids.end(), device % count) != ids.end()) ? device % count : ids[0];
+    for (int& x : d.dev_of) x = -1;
+    for (size_t i = 0; i < ids.size(); ++i) d.dev_of[ids[i]] = devs[i];
+    d.primary = ids[0];
+    for (size_t i = 0; i < ids.size(); ++i)
+      if (device >= 0 && devs[i] == device % count) { d.primary = ids[i]; break; }
   }
-  for (int id : ids) {
-    Engine& e = g_engines[id];
+  for (size_t i = 0; i < ids.size(); ++i) {
+    Engine& e = g_engines[ids[i]];
     std::lock_guard<std::mutex> g(e.mu);
-    engine_init_device(e, id);
+    if (e.ready && (e.device != devs[i] || e.slot != ids[i])) fail(ZPQ_E_ARG, "zpq_init: the engine of this slot already drives another device (zpq_shutdown first)");
+    engine_init_device(e, ids[i], devs[i]);
   }
-  bind_device(primary_device());
+  { Engine& e = eng(); bind_device(e); }
 }
 
 int engine_device_count() {
@@ -266,9 +290,17 @@ void engine_shutdown() {
   }
 }
 
+// bytes of model state (+ stream buffers) one residency wave may hold; 0 = back to the default (85 % of what is free now)
 void engine_set_budget(uint64_t bytes) {
   { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); d.budget_override = bytes; }
-  for (Engine& e : g_engines) { std::lock_guard<std::mutex> g(e.mu); if (e.ready) e.budget = bytes; }
+  for (Engine& e : g_engines) {
+    std::lock_guard<std::mutex> g(e.mu);
+    if (!e.ready) continue;
+    if (bytes) { e.budget = bytes; continue; }
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(e.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      e.budget = (uint64_t)((free_b + e.arena.cap + e.pipe.cap + e.io_in.cap + e.io_out.cap) * 0.85);     // (what the engine holds itself counts as free)
+  }
 }
 void engine_set_kernel(int which) {
   { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); d.kernel_choice = which; }
@@ -278,7 +310,7 @@ Timing engine_last_timing() { Engine& e = eng(); std::lock_guard<std::mutex> g(e
 
 static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
-  zpq_plan::OnDevice& od = p->dev[e.device];
+  zpq_plan::OnDevice& od = p->dev[e.slot];
   if (od.d_blob) return (const uint8_t*)od.d_blob;
   void* d = nullptr;
   HIP_CHECK(hipMalloc(&d, p->blob.size()));
@@ -294,12 +326,13 @@ void engine_plan_release(zpq_plan* p) {
   for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
     zpq_plan::OnDevice& od = p->dev[id];
     if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.spec[0] && !od.spec[1]) continue;
-    if (hipSetDevice(id) != hipSuccess) continue;
+    if (hipSetDevice(g_engines[id].device >= 0 ? g_engines[id].device : id) != hipSuccess) continue;
     set_plan_device_index(id);
     if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
     spec_kernel_release(p);
   }
-  if (before >= 0) { (void)hipSetDevice(before); set_plan_device_index(before); }
+  if (before >= 0) (void)hipSetDevice(before);
+  set_plan_device_index(primary_device());
 }
 
 // Which kernel codes a plan: 4 = pipelined encoder (compression only, device/pipe_kernel.h), 3 = per-header
@@ -313,9 +346,10 @@ struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe =
 // The pipelined encoder has two shapes per chain (host/codegen.hpp PipeOptions): a chain with few blocks in the batch is
 // latency bound -- a step costs one wavefront's serial chain however empty the machine is -- and runs the units with a
 // lane per bit position; a chain that fills the machine is bound by HBM transactions and runs the lane-per-block units,
-// which issue fewer requests.  Measured crossover on the MI355X, -m5 / 1 MiB blocks: between 256 and 512 blocks
-// (profiles/r03/call4_summary.txt, call5_summary.txt).  ZPAQ_AMD_PIPE_MODE=latency|throughput forces one (A/B, tests).
-static const uint32_t kLatencyModeBlocks = 384;
+// which issue fewer requests.  Measured crossover on the MI355X, -m5 / 1 MiB blocks, 8 hardware queues: latency mode is
+// 1.40 x faster at 64 blocks, 1.07 x at 512, 0.95 x at 768, 0.86 x at 1024 (profiles/r03/call6_summary.txt).
+// ZPAQ_AMD_PIPE_MODE=latency|throughput forces one (A/B, tests).
+static const uint32_t kLatencyModeBlocks = 640;
 static int pipe_mode_for(uint32_t blocks_of_plan) {
   if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
     if (!strcmp(m, "latency")) return 1;
@@ -365,7 +399,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  bind_device(e.device);
+  bind_device(e);
   e.jit_left = jit_budget();
   const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu));
   note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
@@ -837,7 +871,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
   Engine& e = eng(dev);
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e, dev);
-  bind_device(e.device);
+  bind_device(e);
   wait_in_flight(e);
   const size_t nb = blocks.size();
   e.jit_left = jit_budget();
@@ -878,7 +912,8 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     // ZPAQ_AMD_PINNED_STAGE=1 a page-locked buffer kept by the engine, filled by several threads (experimental)
     std::unique_ptr<uint8_t[]> stage_buf;
     uint8_t* stage = nullptr;
-    const bool pinned = getenv("ZPAQ_AMD_PINNED_STAGE") != nullptr && e.pin_in.ensure(in_bytes + 64);
+    const char* pin_env = getenv("ZPAQ_AMD_PINNED_STAGE");          // (A/B of round 3: "0" = pageable staging)
+    const bool pinned = !(pin_env && pin_env[0] == '0') && in_bytes >= (1u << 20) && e.pin_in.ensure(in_bytes + 64);
     if (pinned) stage = (uint8_t*)e.pin_in.p;
     else {
       // (not a std::vector: value-initialising a gigabyte costs a quarter of a second; the padding between blocks is
@@ -1018,7 +1053,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  bind_device(e.device);
+  bind_device(e);
   wait_in_flight(e);
   hipStream_t st = stream ? (hipStream_t)stream : e.stream;
   e.jit_left = jit_budget();
@@ -1068,7 +1103,7 @@ bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<Pc
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  bind_device(e.device);
+  bind_device(e);
   wait_in_flight(e);
   PcompKernel* k = pcomp_kernel_for(code, codelen, ph, pm, note);
   if (!k) return false;
@@ -1144,7 +1179,7 @@ void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n,
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  bind_device(e.device);
+  bind_device(e);
   wait_in_flight(e);
   uint64_t bytes = 0;
   for (uint32_t i = 0; i < n; ++i) bytes += ((uint64_t)len[i] + 63) & ~63ull;
@@ -1172,7 +1207,7 @@ int engine_selftest(int32_t out[8]) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
-  bind_device(e.device);
+  bind_device(e);
   int32_t* d = nullptr;
   HIP_CHECK(hipMalloc((void**)&d, 8 * sizeof(int32_t)));
   HIP_CHECK(hipMemsetAsync(d, 0, 8 * sizeof(int32_t), e.stream));
