@@ -228,6 +228,13 @@ int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t ca
 void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]);
 /* tests: 1 = hash with the portable compression function instead of the x86 SHA extensions (0 = back to automatic) */
 void zpq_sha1_force_portable(int yes);
+/* Suffix arrays (the sort inside the byte-aligned LZ77 and BWT pre-processors of methods 2-4; reference: divsufsort,
+ * libzpaq.cpp:4658-6434, called from LZBuffer 6463-6883 and compressBlock 7709-7716) of n host buffers in ONE device
+ * call: out[i] receives len[i] positions, the end of the string ordered before every byte.  zpq_compress_blocks uses
+ * this by itself for batches with 4 or more such blocks; ZPQ_E_UNSUPPORTED when the device declines (a buffer of 16 MiB
+ * or more, more than 65 535 buffers, not enough memory) -- the library then sorts on the host. */
+int zpq_suffix_arrays_device(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint32_t* const* out);
+int zpq_suffix_array_host(const uint8_t* in, uint32_t n, uint32_t* out);      /* the host's sorter (SA-IS), one buffer */
 /* compressBlock's level->method expansion (libzpaq.cpp:7579-7691), including
  * level-5 period detection on the data.  Writes a NUL-terminated "x..." /
  * "0..." string. */

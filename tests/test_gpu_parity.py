@@ -371,6 +371,17 @@ def test_4_mib_zeros_known_answer(gpu):
     assert gpu.decompress(a) == bytes(4 << 20)
 
 
+def test_16_mib_zeros_known_answer(gpu):
+    """BASELINE.md section 2, the top of the north-star range: 16 MiB zeros, method 5 -> 688 B (463 MiB of model state for
+    the one block; one lane per unit of the encoder in latency mode, 32 784 steps).  The first 64 KiB decode back
+    (Decompresser::decompress(n): a whole-block decode of one wavefront would take minutes)."""
+    a, = gpu.compress_blocks([np.zeros(16 << 20, np.uint8)], "5")
+    assert len(a) == 688 and hashlib.sha1(a).hexdigest() == "aecc5f154175bc56a6af2d0015f1e01acef55655"
+    f = parse_block(a)
+    (dec, used), = gpu.decode_batch([gpu.Plan(f["header"])], [a[f["payload_start"]:]], [65537])
+    assert dec == bytes(65537) and used == 0          # PP byte + 64 KiB of zeros, stopped before the end of the stream
+
+
 def test_one_mib_records_block_with_detected_periods(gpu, ref):
     """1 MiB of 16-byte records: level-5 period detection adds components (n = 31), a chain no build step knows
     (hipRTC for both the pipelined encoder and the wavefront decoder).  Archive must equal the reference's."""
@@ -524,3 +535,39 @@ def test_two_engines_shard_one_batch(gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "DIGEST %s 37" % hashlib.sha1(b"".join(alone)).hexdigest() in r.stdout
+
+
+def test_suffix_arrays_on_the_device(gpu, ref):
+    """The sort inside the byte-aligned LZ77 and BWT pre-processors (reference: divsufsort, libzpaq.cpp:4658-6434), for a
+    whole batch in one device call (device/sa_kernels.hip: prefix doubling, one radix sort per round over every block).
+    A suffix array is canonical: the device's must equal the host sorter's, entry for entry -- text, random bytes, a block
+    of zeros (log2(n) rounds), periodic records, ragged and tiny buffers -- and the archives of methods that sort (3: LZ77
+    through a suffix array; 3 with the text hint: BWT; 2: bit-packed LZ77) made from a batch large enough to take the
+    device path must be the reference's, byte for byte."""
+    import ctypes as C
+    L = gpu.lib()
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    bufs = [corpus.block(kinds[i % 5], n, 70 + i) for i, n in enumerate([70000, 65536, 40000, 50001, 30000, 1, 2, 3, 255, 256, 257, 1000, 99999])]
+    n = len(bufs)
+    outs = [np.empty(max(b.size, 1), np.uint32) for b in bufs]
+    u8p, u32p = C.POINTER(C.c_ubyte), C.POINTER(C.c_uint32)
+    IA = (u8p * n)(*[b.ctypes.data_as(u8p) for b in bufs])
+    LN = (C.c_uint32 * n)(*[b.size for b in bufs])
+    OA = (u32p * n)(*[o.ctypes.data_as(u32p) for o in outs])
+    L.zpq_suffix_arrays_device.argtypes = [C.POINTER(u8p), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(u32p)]
+    L.zpq_suffix_array_host.argtypes = [u8p, C.c_uint32, u32p]
+    assert L.zpq_suffix_arrays_device(IA, LN, n, OA) == 0, L.zpq_last_error().decode()
+    for b, o in zip(bufs, outs):
+        want = np.empty(max(b.size, 1), np.uint32)
+        assert L.zpq_suffix_array_host(b.ctypes.data_as(u8p), b.size, want.ctypes.data_as(u32p)) == 0
+        assert (o[:b.size] == want[:b.size]).all(), (b.size, int(b[0]))
+    # through compressBlock's own methods, batches that take the device path (4 or more sorting blocks, 1 MiB or more)
+    blocks = [corpus.block(kinds[i % 4], 150000 + 1111 * i, 500 + i) for i in range(12)]
+    ph = (C.c_double * 8)()
+    for method in ("3", "3,128,1", "2"):        # byte-aligned LZ77 + ICM/ISSE, BWT + ICM/ISSE, bit-packed LZ77 (no model)
+        arch = gpu.compress_blocks(blocks, method)
+        L.zpq_last_api_timing(ph)
+        assert int(ph[7]) == len(blocks), (method, ph[7])          # every block's suffix array came from the device
+        for d, a in zip(blocks, arch):
+            assert a == ref.compress_block(d, method), (method, d.size)
+    assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)

@@ -301,6 +301,28 @@ void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]) {
 }
 void zpq_sha1_force_portable(int yes) { sha1_force_portable(yes != 0); }
 
+// the host's suffix sorter (SA-IS, host/preproc.cpp): what the library uses when the device is not asked
+int zpq_suffix_array_host(const uint8_t* in, uint32_t n, uint32_t* out) {
+  ZPQ_TRY
+  const std::vector<U32> sa = suffix_array(in, n);
+  if (n) memcpy(out, sa.data(), 4ull * n);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+// Suffix arrays of n host buffers, built on the device in one call (device/sa_kernels.hip); out[i] receives len[i] entries.
+int zpq_suffix_arrays_device(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint32_t* const* out) {
+  ZPQ_TRY
+  std::vector<std::pair<const U8*, U32>> blk;
+  for (uint32_t i = 0; i < n; ++i) blk.push_back({in[i], len[i]});
+  std::vector<std::vector<U32>> sa;
+  std::string note;
+  if (!engine_suffix_arrays(blk, sa, note)) fail(ZPQ_E_UNSUPPORTED, "suffix arrays on the device unavailable: " + note);
+  for (uint32_t i = 0; i < n; ++i) if (len[i]) memcpy(out[i], sa[i].data(), 4ull * len[i]);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char* out, size_t cap) {
   ZPQ_TRY
   const std::string m = expand_method(method ? method : "", data, n);
@@ -364,7 +386,7 @@ int zpq_last_api_timing(double out[8]) {
   if (!out) return ZPQ_E_ARG;
   const ApiTiming t = last_api_timing();
   out[0] = t.total_ms; out[1] = t.front_ms; out[2] = t.device_ms; out[3] = t.stitch_ms;
-  out[4] = t.kernel_init_ms; out[5] = t.kernel_code_ms; out[6] = (double)t.blocks; out[7] = 0;
+  out[4] = t.kernel_init_ms; out[5] = t.kernel_code_ms; out[6] = (double)t.blocks; out[7] = (double)t.sa_device_blocks;
   return ZPQ_OK;
 }
 

@@ -19,6 +19,7 @@
 
 #include "../host/codegen.hpp"
 #include "kernels.h"
+#include "sa_kernels.h"
 #include "spec_loader.hpp"
 
 // The pipelined encoder keeps seven HIP streams busy (one per kernel plus the caller's).  The runtime maps streams onto
@@ -1199,6 +1200,55 @@ void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n,
   HIP_CHECK(launch_sha1((const Sha1Job*)e.sha_jobs.p, n, (uint8_t*)e.sha_out.p, e.stream));
   HIP_CHECK(hipMemcpyAsync(out, e.sha_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, e.stream));
   HIP_CHECK(hipStreamSynchronize(e.stream));
+}
+
+bool engine_suffix_arrays(const std::vector<std::pair<const U8*, U32>>& blocks, std::vector<std::vector<U32>>& sa, std::string& note) {
+  const size_t n = blocks.size();
+  sa.assign(n, std::vector<U32>());
+  uint64_t total = 0;
+  uint32_t max_len = 0;
+  for (auto& b : blocks) { total += b.second; max_len = std::max(max_len, b.second); }
+  if (!total) return true;
+  if (n > 65535 || max_len >= (1u << 24) || total >= (1ull << 31)) { note = "batch outside the device sorter's range"; return false; }
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  bind_device(e);
+  wait_in_flight(e);
+  const size_t ws = sa_workspace_bytes(total, (uint32_t)n);
+  const uint64_t in_bytes = (total + 255) & ~255ull;
+  if (ws + in_bytes + 4 * total + (1u << 20) > e.budget) { note = "suffix sort workspace exceeds the device budget"; return false; }
+  // inputs back to back in io_in, the arrays in io_out, the sorter's workspace in the arena buffer (idle between batches)
+  e.io_in.ensure(in_bytes + 64);
+  e.io_out.ensure(4 * total + 64);
+  e.arena.ensure(ws);
+  e.jobs.ensure((n + 2) * 16 + 64);
+  std::vector<const uint8_t*> ptrs(n);
+  std::vector<uint64_t> off(n + 1, 0);
+  const bool pinned = in_bytes >= (1u << 20) && e.pin_in.ensure(in_bytes + 64);
+  std::unique_ptr<uint8_t[]> pageable;
+  uint8_t* stage = pinned ? (uint8_t*)e.pin_in.p : (pageable.reset(new uint8_t[in_bytes + 64]), pageable.get());
+  for (size_t i = 0; i < n; ++i) {
+    ptrs[i] = (const uint8_t*)e.io_in.p + off[i];
+    if (blocks[i].second) memcpy(stage + off[i], blocks[i].first, blocks[i].second);
+    off[i + 1] = off[i] + blocks[i].second;
+  }
+  uint8_t* meta = (uint8_t*)e.jobs.p;
+  HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, total, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(meta, ptrs.data(), n * 8, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(meta + ((n * 8 + 15) & ~15ull), off.data(), (n + 1) * 8, hipMemcpyHostToDevice, e.stream));
+  uint32_t rounds = 0;
+  const hipError_t rc = build_suffix_arrays((const uint8_t* const*)meta, (const uint64_t*)(meta + ((n * 8 + 15) & ~15ull)), (uint32_t)n, total, max_len,
+                                            (uint32_t*)e.io_out.p, e.arena.p, e.arena.cap, e.stream, &rounds);
+  if (rc != hipSuccess) { (void)hipGetLastError(); note = std::string("device suffix sort failed: ") + hipGetErrorString(rc); return false; }
+  for (size_t i = 0; i < n; ++i) {
+    sa[i].resize(blocks[i].second);
+    if (blocks[i].second)
+      HIP_CHECK(hipMemcpyAsync(sa[i].data(), (const uint32_t*)e.io_out.p + off[i], 4ull * blocks[i].second, hipMemcpyDeviceToHost, e.stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(e.stream));
+  note = "device, " + std::to_string(rounds) + " doubling rounds";
+  return true;
 }
 
 int engine_jit_threads() { return jit_threads(); }

@@ -64,6 +64,9 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
 struct PcompSeg { const U8* in; U32 in_len; U64 hint; std::vector<U8>* out; };
 bool engine_pcomp(const U8* code, size_t codelen, int ph, int pm, std::vector<PcompSeg>& segs, std::string& note);
 void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out);
+// Suffix arrays of host buffers, all in one device call (device/sa_kernels.hip: prefix doubling over the whole batch).
+// false + note when the device declines (then the host sorts): a buffer of 2^24 bytes or more, too many buffers, memory.
+bool engine_suffix_arrays(const std::vector<std::pair<const U8*, U32>>& blocks, std::vector<std::vector<U32>>& sa, std::string& note);
 int engine_selftest(int32_t out[8]);
 int engine_jit_threads();      // host threads spec_precompile() uses by default (the host cores the process may use, at most 16)
 

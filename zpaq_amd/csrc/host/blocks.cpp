@@ -167,22 +167,58 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     void off() { if (on) { engine_caller_leave(); on = false; } }
     ~Announce() { off(); }
   } announce;
-  // 1. host front half, parallel over blocks
+  // 1. host front half, parallel over blocks: method -> chain; then the pre-processor; then the archive's front
+  struct Front { int args[9]; Assembled as; bool sorts = false; };
+  std::vector<Front> front(nb);
   parallel_blocks(nb, [&](size_t b) {
     Work& w = work[b];
+    Front& f = front[b];
     const U32 n = in[b].n;
     if ((U64)n > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
     const std::string xm = expand_method(method, in[b].data, n);
-    int args[9];
-    const std::string cfg = make_config(xm, args);
-    const Assembled as = assemble(cfg.c_str(), args);
+    const std::string cfg = make_config(xm, f.args);
+    f.as = assemble(cfg.c_str(), f.args);
     // The segment trailer carries the SHA-1 of the ORIGINAL block.  A modelled block that is coded as it is goes to the
     // device unchanged, so it is hashed there (sha1_blocks_kernel, beside the coder); everything else here.
-    w.sha1_on_device = dosha1 && args[1] == 0 && as.hcomp[6] != 0;
+    w.sha1_on_device = dosha1 && f.args[1] == 0 && f.as.hcomp[6] != 0;
     if (dosha1 && !w.sha1_on_device) { Sha1 s; s.update(in[b].data, n); memcpy(w.sha1, s.result(), 20); }
-    if ((U64)n + 4096 > (0x100000ull << args[0])) fail(ZPQ_E_ARG, "block larger than the method's block size");
+    if ((U64)n + 4096 > (0x100000ull << f.args[0])) fail(ZPQ_E_ARG, "block larger than the method's block size");
+    f.sorts = n > 0 && preprocess_needs_suffix_array(f.args);
+  });
+  // Blocks whose pre-processor sorts suffixes (byte-aligned LZ77 with a suffix array: level 3; BWT): one suffix sort for
+  // all of them on the device when there are enough to fill it (device/sa_kernels.hip), the host's SA-IS per block otherwise
+  // or when the device declines (no GPU, blocks of 16 MiB and more, not enough memory).  The array is canonical: either
+  // source gives the reference's parse.  E8E9 comes first where the method has it (it changes the bytes that are sorted).
+  std::vector<std::vector<U32>> dev_sa(nb);
+  {
+    std::vector<size_t> sorting;
+    U64 sort_bytes = 0;
+    for (size_t b = 0; b < nb; ++b) if (front[b].sorts) { sorting.push_back(b); sort_bytes += in[b].n; }
+    if (sorting.size() >= 4 && sort_bytes >= (1u << 20) && engine_device_count() > 0) {
+      for (size_t b : sorting) if (front[b].args[1] > 4) e8e9_forward(in[b].data, in[b].n);
+      std::vector<std::pair<const U8*, U32>> blk;
+      for (size_t b : sorting) blk.push_back({in[b].data, in[b].n});
+      std::vector<std::vector<U32>> sa;
+      std::string note;
+      const bool got = engine_suffix_arrays(blk, sa, note);
+      for (size_t k = 0; k < sorting.size(); ++k) {
+        if (got) dev_sa[sorting[k]].swap(sa[k]);
+        front[sorting[k]].sorts = true;                 // (E8E9 is done either way)
+      }
+      tm.sa_device_blocks = got ? (U32)sorting.size() : 0;
+    } else {
+      for (size_t b : sorting) front[b].sorts = false;   // nothing was done up front: preprocess_block does it all
+    }
+  }
+  parallel_blocks(nb, [&](size_t b) {
+    Work& w = work[b];
+    const Front& f = front[b];
+    const int* args = f.args;
+    const Assembled& as = f.as;
+    const U32 n = in[b].n;
     // LZ77 / BWT / E8E9 (libzpaq.cpp:7709-7716); E8E9 rewrites the caller's buffer in place, as the reference does
-    w.use_pre = preprocess_block(in[b].data, n, args, w.pre);
+    w.use_pre = preprocess_block(in[b].data, n, args, w.pre, dev_sa[b].empty() ? nullptr : dev_sa[b].data(), f.sorts);
+    std::vector<U32>().swap(dev_sa[b]);
     std::string cs = std::to_string(n);
     if (in[b].comment) cs += std::string(" ") + in[b].comment;
     write_block_prologue(archives[b], as.hcomp, in[b].filename, cs);

@@ -24,6 +24,7 @@ struct ApiTiming {
   double total_ms = 0;
   double kernel_init_ms = 0, kernel_code_ms = 0;   // inside device_ms: the kernels alone (hipEvents)
   size_t blocks = 0;
+  U32 sa_device_blocks = 0;   // blocks whose suffix array was built on the device (LZ77 / BWT pre-processors)
 };
 ApiTiming last_api_timing();
 

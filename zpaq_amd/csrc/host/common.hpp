@@ -85,6 +85,10 @@ std::string make_config(const std::string& xmethod, int args[9]);
 void e8e9_forward(U8* buf, U32 n);
 std::vector<U32> suffix_array(const U8* in, U32 n);
 // false: the (possibly E8E9-filtered, in place) input itself is coded; true: `out` holds the LZ77 / BWT stream
-bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out);
+// sa = the suffix array of the (E8E9-filtered) block when the caller already has it (built on the device for a whole
+// batch: device/sa_kernels.hip), e8e9_done = the caller applied e8e9_forward itself (it must, before sorting)
+bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out, const U32* sa = nullptr, bool e8e9_done = false);
+// does this method's pre-processor sort the block's suffixes (BWT, or LZ77 searching through a suffix array)?
+bool preprocess_needs_suffix_array(const int args[9]);
 
 }  // namespace zpq

@@ -178,7 +178,7 @@ namespace {
 // One block through LZ77 (level 1: bit-packed codes, level 2: byte-aligned codes).
 class Lz77 {
  public:
-  Lz77(const U8* in, U32 n, const int args[9], std::vector<U8>& out)
+  Lz77(const U8* in, U32 n, const int args[9], std::vector<U8>& out, const U32* sa = nullptr)
       : in_(in), n_(n), out_(out), level_(args[1] & 3),
         use_sa_(args[5] - args[0] >= 21),
         checkbits_(use_sa_ ? 17 + args[0] : 12 - args[0]),
@@ -190,7 +190,8 @@ class Lz77 {
         rb_(args[0] > 4 ? (unsigned)(args[0] - 4) : 0u) {
     if ((min_match_ < 4 && level_ == 1) || (min_match_ < 1 && level_ == 2)) fail(ZPQ_E_ARG, "match length $3 too small");
     if (use_sa_) {
-      sa_ = suffix_array(in, n);
+      if (sa) sa_.assign(sa, sa + n);                 // built on the device for the whole batch (device/sa_kernels.hip)
+      else sa_ = suffix_array(in, n);
       // the inverse array for one aligned window of 2^checkbits positions at a time (like the reference: 8 MB that stay
       // in cache instead of 4 n bytes of scattered writes)
       isa_.assign((size_t)1 << checkbits_, 0);
@@ -405,15 +406,24 @@ class Lz77 {
 // What compressBlock feeds the coder for a method with args[1] != 0 (libzpaq.cpp:7709-7716).  `data` is modified in
 // place where the reference modifies its input buffer (E8E9).  Returns true when `out` holds the stream to code,
 // false when the (possibly E8E9-filtered) input itself is coded.
-bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out) {
+bool preprocess_needs_suffix_array(const int args[9]) {
+  const int kind = args[1];
+  if (kind < 1 || kind > 7 || kind == 4) return false;
+  const int level = kind & 3;
+  return level == 3 || ((level == 1 || level == 2) && args[5] - args[0] >= 21);
+}
+
+bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out, const U32* sa_in, bool e8e9_done) {
   out.clear();
   const int kind = args[1];
   if (kind < 1 || kind > 7) return false;
-  if (kind == 4) { e8e9_forward(data, n); return false; }
-  if (kind > 4) e8e9_forward(data, n);
+  if (kind == 4) { if (!e8e9_done) e8e9_forward(data, n); return false; }
+  if (kind > 4 && !e8e9_done) e8e9_forward(data, n);
   const int level = kind & 3;
   if (level == 3) {                                  // BWT: last column, end-of-string as 255, its index in 4 bytes
-    const std::vector<U32> sa = suffix_array(data, n);
+    std::vector<U32> own;
+    if (!sa_in) own = suffix_array(data, n);
+    const U32* sa = sa_in ? sa_in : own.data();
     out.reserve((size_t)n + 5);
     U32 idx = 0;
     out.push_back(n > 0 ? data[n - 1] : 255);
@@ -425,7 +435,7 @@ bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out) 
     return true;
   }
   out.reserve((size_t)n / 2 + 64);
-  Lz77 lz(data, n, args, out);
+  Lz77 lz(data, n, args, out, sa_in);
   lz.run();
   return true;
 }
