@@ -509,11 +509,16 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes -- only when THIS workload was profiled with THIS
     # code object (the cache key is part of kernel_origin); a stale entry is refused
     traffic = None
+    transactions = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         key = f"method {a.method} x {nb} x {bs} {a.kind} {a.mode}"
         if key in tj and tj[key].get("kernel_origin") == origin:
             traffic = tj[key]["traffic_bytes"]
+            # what really bounds the encoder: random memory TRANSACTIONS.  The counters tally 64 B per
+            # random read and 32 B per random store (calibrated on profiles/r03/gups.hip, which also gives the machine's rate)
+            transactions = {"per_input_byte": tj[key]["fetch_bytes_per_input_byte"] / 64.0 + tj[key]["write_bytes_per_input_byte"] / 32.0,
+                            "peak_G_per_s": 48.0, "peak_source": "profiles/r03/gups_results.txt: 24 G random read-modify-writes/s = 48 G transactions/s"}
     except Exception:
         pass
     total_bytes = float(total_blocks) * bs * a.steps
@@ -543,7 +548,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": kname, "kernel_origin": origin,
-                     "algo_bytes_per_launch": algo_bytes, "kernel_s_per_launch": code_s},
+                     "algo_bytes_per_launch": algo_bytes, "kernel_s_per_launch": code_s,
+                     "transactions": (dict(transactions, achieved_G_per_s=transactions["per_input_byte"] * float(nb) * bs / 1e9 / code_s,
+                                           frac=transactions["per_input_byte"] * float(nb) * bs / 1e9 / code_s / transactions["peak_G_per_s"])
+                                      if transactions and code_s > 0 else None)},
     }
     if rank == 0:
         # coded payloads of the timed run, for the identity check against the reference

@@ -248,6 +248,11 @@ int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t
  * E8E9, host/preproc.cpp): writes the stream the coder will see (the input itself when the method does not
  * transform it).  E8E9 methods rewrite `data` in place, as the reference rewrites its input buffer. */
 int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t* out, size_t cap, size_t* len);
+/* The same with the suffix array of the block supplied (zpq_suffix_arrays_device / zpq_suffix_array_host): what
+ * zpq_compress_blocks does for a batch.  For a method with E8E9 (x.,5 / x.,6 / x.,7) the caller filters first with
+ * zpq_e8e9 -- the suffixes sorted are those of the filtered bytes -- and this call then does not filter again. */
+int zpq_preprocess_block_sa(const char* xmethod, uint8_t* data, uint32_t n, const uint32_t* sa, uint8_t* out, size_t cap, size_t* len);
+void zpq_e8e9(uint8_t* data, uint32_t n);      /* e8e9 (libzpaq.cpp:6450-6459), in place */
 /* Compiler alone (libzpaq.cpp:2698): ZPAQL source text -> header / PCOMP bytes. */
 int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hcap,
                  size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);

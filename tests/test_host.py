@@ -492,3 +492,35 @@ def test_translated_pcomp_programs_equal_the_interpreter(zlib_, ref, monkeypatch
             n_native += 1
     assert n_native >= 50
     assert L.zpq_pcomp_is_translated(b"\x38\x00", 2, 0, 20) == 0          # anything else is interpreted
+
+
+def test_preprocessing_with_a_supplied_suffix_array(zlib_):
+    """zpq_compress_blocks hands the LZ77 / BWT pre-processors the suffix arrays the device built for the whole batch
+    (device/sa_kernels.hip).  Here the array comes from the host sorter instead -- the plumbing is the same: the stream must
+    equal what the pre-processor makes when it sorts by itself, for byte-aligned and bit-packed LZ77 through a suffix
+    array, BWT, and their E8E9 variants (filter first, then sort the filtered bytes)."""
+    import ctypes as C
+    L = zlib_.lib()
+    u8p, u32p = C.POINTER(C.c_ubyte), C.POINTER(C.c_uint32)
+    L.zpq_preprocess_block.argtypes = [C.c_char_p, u8p, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_preprocess_block_sa.argtypes = [C.c_char_p, u8p, C.c_uint32, u32p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_suffix_array_host.argtypes = [u8p, C.c_uint32, u32p]
+    L.zpq_e8e9.argtypes = [u8p, C.c_uint32]
+    datas = [corpus.block("text", 70000, 3), corpus.block("records", 50000, 4), _exe_like(60000, 5), corpus.block("zeros", 5000, 1),
+             corpus.block("lcg", 30000, 2), corpus.block("text", 1, 9)]
+    for xm in ("x0,2,12,0,7,21,1c0,0,511i2", "x0,1,4,0,7,21,1", "x0,3ci1", "x0,6,12,0,7,21,1c0,0,511i2", "x0,7ci1"):
+        e8 = int(xm.split(",")[1][0]) > 4
+        for d in datas:
+            a = np.array(d, dtype=np.uint8, copy=True)
+            b = np.array(d, dtype=np.uint8, copy=True)
+            out_a, out_b = np.empty(a.size * 2 + 4096, np.uint8), np.empty(a.size * 2 + 4096, np.uint8)
+            la, lb = C.c_size_t(0), C.c_size_t(0)
+            assert L.zpq_preprocess_block(xm.encode(), a.ctypes.data_as(u8p), a.size, out_a.ctypes.data_as(u8p), out_a.size, C.byref(la)) == 0
+            if e8:
+                L.zpq_e8e9(b.ctypes.data_as(u8p), b.size)
+            sa = np.empty(max(b.size, 1), np.uint32)
+            assert L.zpq_suffix_array_host(b.ctypes.data_as(u8p), b.size, sa.ctypes.data_as(u32p)) == 0
+            assert L.zpq_preprocess_block_sa(xm.encode(), b.ctypes.data_as(u8p), b.size, sa.ctypes.data_as(u32p),
+                                             out_b.ctypes.data_as(u8p), out_b.size, C.byref(lb)) == 0
+            assert la.value == lb.value and (out_a[:la.value] == out_b[:lb.value]).all(), (xm, d.size)
+            assert (a == b).all()          # E8E9 left both buffers in the same (filtered) state

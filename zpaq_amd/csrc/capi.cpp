@@ -301,6 +301,8 @@ void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]) {
 }
 void zpq_sha1_force_portable(int yes) { sha1_force_portable(yes != 0); }
 
+void zpq_e8e9(uint8_t* data, uint32_t n) { e8e9_forward(data, n); }
+
 // the host's suffix sorter (SA-IS, host/preproc.cpp): what the library uses when the device is not asked
 int zpq_suffix_array_host(const uint8_t* in, uint32_t n, uint32_t* out) {
   ZPQ_TRY
@@ -360,12 +362,19 @@ int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hc
 }
 
 int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t* out, size_t cap, size_t* len) {
+  return zpq_preprocess_block_sa(xmethod, data, n, nullptr, out, cap, len);
+}
+
+// ... with the block's suffix array supplied by the caller (what zpq_compress_blocks does with the arrays the device built
+// for a whole batch): for a method with E8E9 the caller applies zpq_e8e9 first -- the sort is over the filtered bytes --
+// and says so with sa != null (then the call does not filter again)
+int zpq_preprocess_block_sa(const char* xmethod, uint8_t* data, uint32_t n, const uint32_t* sa, uint8_t* out, size_t cap, size_t* len) {
   ZPQ_TRY
   if (!xmethod || (!data && n) || !len) fail(ZPQ_E_ARG, "null argument");
   int args[9];
   (void)make_config(xmethod, args);
   std::vector<U8> pre;
-  const bool made = preprocess_block(data, n, args, pre);
+  const bool made = preprocess_block(data, n, args, pre, sa, sa != nullptr);
   if (!made) pre.assign(data, data + n);
   *len = pre.size();
   if (pre.size() > cap) fail(ZPQ_E_OVERFLOW, "output buffer too small");

@@ -200,7 +200,8 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
       for (size_t b : sorting) blk.push_back({in[b].data, in[b].n});
       std::vector<std::vector<U32>> sa;
       std::string note;
-      const bool got = engine_suffix_arrays(blk, sa, note);
+      bool got = false;
+      try { got = engine_suffix_arrays(blk, sa, note); } catch (const Failure&) { got = false; }      // (any device trouble: the host sorts)
       for (size_t k = 0; k < sorting.size(); ++k) {
         if (got) dev_sa[sorting[k]].swap(sa[k]);
         front[sorting[k]].sorts = true;                 // (E8E9 is done either way)
