@@ -502,7 +502,7 @@ def main():
     # which kernel coded the blocks (4 pipelined encoder, 3 per-header wavefront kernel, 2 generic wave, 1 generic one-lane)
     note = C.create_string_buffer(512)
     dec = 1 if a.mode == "decode" else 0
-    kinds = sorted({int(L.zpq_plan_kernel_kind3(pl._h, dec, len(idx), note, 512)) for pl, idx in groups})
+    kinds = sorted({int(L.zpq_plan_kernel_kind4(pl._h, dec, len(idx), max(in_len[i] for i in idx), note, 512)) for pl, idx in groups})
     kname = {4: "zpq_pipe_{hcomp,rows,light,icm,isse,mix}: one launch of each per step, concurrent",
              3: "zpq_spec_" + ("decode" if dec else "encode"), 2: "code_wave_kernel", 1: "code_serial_kernel"}.get(kinds[-1], "?")
     origin = note.value.decode(errors="replace")

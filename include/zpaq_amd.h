@@ -97,8 +97,9 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * [11] threads per workgroup of the mix kernel, [12] of the rows kernel, [13] of the light kernel.
  * The encoder has two shapes per chain: mode 0 "throughput" (a lane per block; batches that fill the GPU) and mode 1
  * "latency" (MIX / CM / MIX2 with a lane per bit position as well; the engine uses it for chains with at most 640 blocks
- * in the batch).  The plain calls give mode 0; the _opts calls take the mode and, for tests, the chunk (bytes per step,
- * 0 = 512) and the group (blocks per wavefront, 0 = 32). */
+ * in the batch), mode 2 = mode 1 with 2048-byte steps (blocks of 128 KiB and more).  The plain calls give mode 0; the
+ * _opts calls take the mode and, for tests, the chunk (bytes per step, 0 = the mode's own) and the group (blocks per
+ * wavefront, 0 = 32). */
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
 int zpq_plan_pipe_source_opts(const zpq_plan*, int mode, int chunk, int group, char* src, size_t cap, size_t* len, char key41[41]);
@@ -131,6 +132,8 @@ int zpq_plan_kernel_kind(zpq_plan*, char* note, size_t cap);            /* compr
 int zpq_plan_kernel_kind2(zpq_plan*, int decode, char* note, size_t cap);
 /* ... for a batch that holds nblocks blocks of this plan (the encoder's mode and the decoder's workgroup shape depend on it) */
 int zpq_plan_kernel_kind3(zpq_plan*, int decode, uint32_t nblocks, char* note, size_t cap);
+/* ... whose longest block has block_bytes bytes (latency shape: 2048-byte steps for blocks of 128 KiB and more) */
+int zpq_plan_kernel_kind4(zpq_plan*, int decode, uint32_t nblocks, uint32_t block_bytes, char* note, size_t cap);
 /* Directories used by the specialisation cache / hipRTC include path. */
 const char* zpq_spec_cache_dir(void);
 const char* zpq_spec_include_dir(void);

@@ -53,11 +53,12 @@ def prebuild(cfg):
     for name, env in cfg["variants"]:
         knob_env(env)
         for h in headers:
-            src, key = pb.pipe_source_and_key(h, 1 if env.get("ZPAQ_AMD_PIPE_MODE") == "latency" else 0)
-            if src is None:
-                print(f"{name}: no pipelined encoder ({key})")
-                continue
-            jobs.append((src, key, cache, inc, dict(env)))
+            for variant in (0, 1, 2):                    # the engine picks one by batch size and block length
+                src, key = pb.pipe_source_and_key(h, variant)
+                if src is None:
+                    print(f"{name}: no pipelined encoder ({key})")
+                    continue
+                jobs.append((src, key, cache, inc, dict(env)))
             for waves in cfg.get("spec_waves", []):          # the per-header wavefront kernel (decoder) as well
                 os.environ["ZPAQ_AMD_SPEC_WAVES"] = str(waves)
                 src, key = pb.source_and_key(h)
@@ -147,7 +148,7 @@ def main():
             res = d_res.cpu().numpy()
             ok = bool((res[:, 2] == 0).all())
             note = C.create_string_buffer(512)
-            kd = int(L.zpq_plan_kernel_kind3(next(iter(plans.values()))._h, 0, nb, note, 512))
+            kd = int(L.zpq_plan_kernel_kind4(next(iter(plans.values()))._h, 0, nb, bs + 1, note, 512))
             if ref_out is None:
                 ref_out, ref_len = d_out.clone(), res[:, 0].copy()
                 same = True

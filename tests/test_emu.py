@@ -133,6 +133,11 @@ def test_pipe_encoder_standard_chains(zlib_, oracle):
         _pipe_check(oracle, h5, ragged[:4], chunk=128, group=64, mode=mode)
         _pipe_check(oracle, h5, ragged[:5], chunk=64, group=16, mode=mode)
         _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16, mode=mode)
+    # the third variant the engine uses: latency shape with its own 2048-byte steps (blocks of 128 KiB and more in
+    # production; here blocks that end inside the first, the second and the fifth step)
+    assert "PIPE_C = 2048" in emu.pipe_source(h5, None, mode=2) and "PIPE_MODE = 1" in emu.pipe_source(h5, None, mode=2)
+    long_ones = [b"\0" + corpus.block(k, n, 5 + i).tobytes() for i, (k, n) in enumerate([("text", 9000), ("records", 5000), ("lcg", 2049), ("zeros", 4096), ("text", 1)])]
+    _pipe_check(oracle, h5, long_ones, chunk=None, mode=2)
 
 
 def test_pipe_encoder_every_component_type_and_legacy_models(oracle, golden):

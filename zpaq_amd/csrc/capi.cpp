@@ -67,12 +67,13 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
 
 int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) { return zpq_plan_kernel_kind2(p, 0, note, cap); }
 
-int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) { return zpq_plan_kernel_kind3(p, decode, 0, note, cap); }
+int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) { return zpq_plan_kernel_kind4(p, decode, 0, 0, note, cap); }
+int zpq_plan_kernel_kind3(zpq_plan* p, int decode, uint32_t nblocks, char* note, size_t cap) { return zpq_plan_kernel_kind4(p, decode, nblocks, 0, note, cap); }
 
-int zpq_plan_kernel_kind3(zpq_plan* p, int decode, uint32_t nblocks, char* note, size_t cap) {
+int zpq_plan_kernel_kind4(zpq_plan* p, int decode, uint32_t nblocks, uint32_t block_bytes, char* note, size_t cap) {
   try {
     std::string n;
-    const int k = engine_plan_kernel_kind(p, n, decode != 0, nblocks);
+    const int k = engine_plan_kernel_kind(p, n, decode != 0, nblocks, block_bytes);
     if (note && cap) { strncpy(note, n.c_str(), cap - 1); note[cap - 1] = 0; }
     return k;
   } catch (const Failure& f) { set_last_error(f.what()); return -f.code; }
@@ -118,7 +119,7 @@ int zpq_plan_pipe_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   return zpq_plan_pipe_source_opts(p, 0, 0, 0, src, cap, len, key41);
 }
 
-static PipeOptions opts_of(int mode, int chunk, int group) {
+static PipeOptions opts_of(int mode, int chunk, int group) {     // mode: a variant number of pipe_options (0, 1, 2)
   PipeOptions o = pipe_options(mode);
   if (chunk) o.chunk = chunk;
   o.group = group;

@@ -326,7 +326,7 @@ void engine_plan_release(zpq_plan* p) {
   (void)hipGetDevice(&before);
   for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
     zpq_plan::OnDevice& od = p->dev[id];
-    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.spec[0] && !od.spec[1]) continue;
+    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.pipe[2] && !od.spec[0] && !od.spec[1]) continue;
     if (hipSetDevice(g_engines[id].device >= 0 ? g_engines[id].device : id) != hipSuccess) continue;
     set_plan_device_index(id);
     if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
@@ -351,12 +351,14 @@ struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe =
 // 1.40 x faster at 64 blocks, 1.07 x at 512, 0.95 x at 768, 0.86 x at 1024 (profiles/r03/call6_summary.txt).
 // ZPAQ_AMD_PIPE_MODE=latency|throughput forces one (A/B, tests).
 static const uint32_t kLatencyModeBlocks = 640;
-static int pipe_mode_for(uint32_t blocks_of_plan) {
+static const uint32_t kLongStepBytes = 128u << 10;       // latency shape: blocks this long take 2048-byte steps (codegen.hpp)
+static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block) {
+  bool latency = blocks_of_plan <= kLatencyModeBlocks;
   if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
-    if (!strcmp(m, "latency")) return 1;
-    if (!strcmp(m, "throughput")) return 0;
+    if (!strcmp(m, "latency")) latency = true;
+    if (!strcmp(m, "throughput")) latency = false;
   }
-  return blocks_of_plan <= kLatencyModeBlocks ? 1 : 0;
+  return !latency ? 0 : (longest_block >= kLongStepBytes ? 2 : 1);
 }
 
 static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode) {
@@ -396,13 +398,13 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   return r;
 }
 
-int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_t nblocks) {
+int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_t nblocks, uint32_t block_bytes) {
   Engine& e = eng();
   std::lock_guard<std::mutex> g(e.mu);
   require_ready(e);
   bind_device(e);
   e.jit_left = jit_budget();
-  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu));
+  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes));
   note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
@@ -688,13 +690,13 @@ static int kind_of_sorted(const std::vector<LaunchGroup>& groups, size_t k) {
 // kernels are compiled side by side on the host cores before the kernels are picked, so that such a batch pays about one
 // compilation time, not one per header.  The code objects land in the cache directory / the loader's in-process store;
 // kernel_kind() then finds them there.
-// blocks of the batch per plan -> the mode its pipelined encoder runs in
-template <class PlanOf>
-static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& order, PlanOf plan_of) {
-  std::map<const zpq_plan*, uint32_t> cnt;
-  for (uint32_t b : order) ++cnt[plan_of(b)];
+// blocks of the batch per plan (and the longest of them) -> the variant of its pipelined encoder
+template <class PlanOf, class LenOf>
+static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
+  std::map<const zpq_plan*, std::pair<uint32_t, uint32_t>> cnt;
+  for (uint32_t b : order) { auto& c = cnt[plan_of(b)]; ++c.first; c.second = std::max(c.second, (uint32_t)len_of(b)); }
   std::map<const zpq_plan*, int> mode;
-  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second);
+  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second);
   return mode;
 }
 
@@ -728,7 +730,7 @@ template <class PlanOf, class LenOf>
 static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
   const size_t cnt = order.size();
   const bool dense = cnt > (size_t)4 * e.cus;
-  const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of);
+  const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of, len_of);
   precompile_unseen(e, decode, dense, order, plan_of, mode_of);
   std::vector<KernelPick> pick(cnt);
   for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode, mode_of.at(plan_of(order[k])));

@@ -20,8 +20,10 @@ struct zpq_plan {
     // (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
     void* spec[2] = {nullptr, nullptr};   // SpecKernel*
     int spec_state[2] = {0, 0};           // 0 not tried, 1 loaded, -1 unavailable
-    void* pipe[2] = {nullptr, nullptr};   // PipeKernel*: the pipelined encoder (device/pipe_kernel.h), [0] throughput / [1] latency mode
-    int pipe_state[2] = {0, 0};
+    // PipeKernel*: the pipelined encoder (device/pipe_kernel.h) in its variants (host/codegen.hpp pipe_options):
+    // [0] throughput shape, [1] latency shape, [2] latency shape with 2048-byte steps
+    void* pipe[3] = {nullptr, nullptr, nullptr};
+    int pipe_state[3] = {0, 0, 0};
     std::string pipe_note, spec_note;     // where the last kernel came from / why it is unavailable
   };
   static const int kMaxDevices = 16;

@@ -377,7 +377,7 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
 }
 
 PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit, bool* did_jit) {
-  mode = mode ? 1 : 0;
+  if (mode < 0 || mode >= kPipeVariants) mode = 0;
   if (plan->cur().pipe_state[mode] > 0) return (PipeKernel*)plan->cur().pipe[mode];
   if (plan->cur().pipe_state[mode] < 0) return nullptr;
   plan->cur().pipe_state[mode] = -1;
@@ -493,7 +493,7 @@ PcompKernel* pcomp_kernel_for(const U8* code, size_t len, int ph, int pm, std::s
 }
 
 void spec_kernel_release(zpq_plan* plan) {
-  for (int m = 0; plan && m < 2; ++m) {
+  for (int m = 0; plan && m < kPipeVariants; ++m) {
     if (!plan->cur().pipe[m]) continue;
     PipeKernel* k = (PipeKernel*)plan->cur().pipe[m];
     if (k->module) (void)hipModuleUnload(k->module);

@@ -37,8 +37,8 @@ struct PipeKernel {
   hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hcomp, rows, light, icm, isse, mix
   std::string origin;
 };
-// mode: 0 throughput, 1 latency (host/codegen.hpp PipeOptions); one code object per (header, mode)
-PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit = true, bool* did_jit = nullptr);
+// variant: 0 throughput, 1 latency, 2 latency with long steps (host/codegen.hpp pipe_options); one code object per (header, variant)
+PipeKernel* pipe_kernel_for(zpq_plan* plan, int variant, bool allow_jit = true, bool* did_jit = nullptr);
 bool pipe_source_and_key(const zpq_plan& plan, const PipeOptions& opt, std::string& source, std::string& key, std::string& why_not);
 
 // A block's PCOMP post-processor translated for the device (device/pcomp_kernel.h), per (program, ph, pm) and device;

@@ -248,9 +248,10 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
 
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined encoder: dataflow levels + buffer layout (see device/pipe_kernel.h for the design)
-PipeOptions pipe_options(int mode) {
+PipeOptions pipe_options(int variant) {
   PipeOptions o;
-  o.mode = mode ? 1 : 0;
+  o.mode = variant ? 1 : 0;
+  o.chunk = variant == 2 ? 2048 : 0;
   return o;
 }
 
