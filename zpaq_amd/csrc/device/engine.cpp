@@ -351,14 +351,29 @@ struct KernelPick { int kind = 0; SpecKernel* spec = nullptr; PipeKernel* pipe =
 // 1.40 x faster at 64 blocks, 1.07 x at 512, 0.95 x at 768, 0.86 x at 1024 (profiles/r03/call6_summary.txt).
 // ZPAQ_AMD_PIPE_MODE=latency|throughput forces one (A/B, tests).
 static const uint32_t kLatencyModeBlocks = 640;
-static const uint32_t kLongStepBytes = 128u << 10;       // latency shape: blocks this long take 2048-byte steps (codegen.hpp)
-static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block) {
+static const uint32_t kLongStepBytes = 128u << 10;       // latency shape: blocks this long may take 2048-byte steps (codegen.hpp)
+// ... when what the units of one step pass each other stays small: a step's streams (blocks x 2048 bytes x the chain's
+// ctx / bh / p bytes per input byte) are written and read once within a few steps, and up to ~100 MB of them live in the
+// 256 MB Infinity Cache instead of HBM.  Measured (profiles/r03/call10_summary.txt): -m3's n = 2 chain on 256 blocks
+// (29 MB per step) 483 -> 440 ms; -m5 (588 B per byte) +4 % at 64 blocks (77 MB), +6 % at 512 (616 MB), -20 % at 640.
+static const uint64_t kLongStepStreamBytes = 96ull << 20;
+static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte) {
   bool latency = blocks_of_plan <= kLatencyModeBlocks;
   if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
     if (!strcmp(m, "latency")) latency = true;
     if (!strcmp(m, "throughput")) latency = false;
   }
-  return !latency ? 0 : (longest_block >= kLongStepBytes ? 2 : 1);
+  if (!latency) return 0;
+  const bool long_steps = longest_block >= kLongStepBytes && stream_bytes_per_byte &&
+                          (uint64_t)blocks_of_plan * 2048u * stream_bytes_per_byte <= kLongStepStreamBytes;
+  return long_steps ? 2 : 1;
+}
+// bytes the units of a chain pass each other per input byte (ctx 4, bh 8, p 16 per stream); 0: no pipelined encoder
+static uint32_t pipe_stream_bytes_per_byte(const zpq_plan* plan) {
+  PipeLayout L;
+  std::string why;
+  if (!pipe_layout(*plan, pipe_options(1), L, why)) return 0;
+  return (uint32_t)(L.nctx * 4 + L.nrow * 8 + L.n * 16);
 }
 
 static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode) {
@@ -404,7 +419,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_
   require_ready(e);
   bind_device(e);
   e.jit_left = jit_budget();
-  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes));
+  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes, pipe_stream_bytes_per_byte(p)));
   note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
@@ -696,7 +711,7 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
   std::map<const zpq_plan*, std::pair<uint32_t, uint32_t>> cnt;
   for (uint32_t b : order) { auto& c = cnt[plan_of(b)]; ++c.first; c.second = std::max(c.second, (uint32_t)len_of(b)); }
   std::map<const zpq_plan*, int> mode;
-  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second);
+  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second, pipe_stream_bytes_per_byte(kv.first));
   return mode;
 }
 

@@ -36,7 +36,8 @@ struct PipeOptions {
 // of 2048 bytes instead of 512.  A step costs a fixed ~0.3 ms of launches and dependencies between the six streams
 // whatever it holds; a batch that fills the GPU hides that behind 2 ms of work, a small one does not (-m5 on 64 blocks:
 // 0.98 ms per 512-byte step against 0.65 ms for the longest chain), so blocks long enough to fill a long pipeline
-// (128 KiB and more: 16 levels x 2048 bytes of fill) take four times fewer, four times longer steps.
+// (128 KiB and more: 16 levels x 2048 bytes of fill) take four times fewer, four times longer steps -- as long as the
+// streams of one step stay cache-sized (engine.cpp::pipe_mode_for has the rule and the measurements).
 static const int kPipeVariants = 3;
 PipeOptions pipe_options(int variant);
 
