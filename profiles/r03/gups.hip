@@ -85,6 +85,21 @@ int main(int argc, char** argv) {
     printf("calib: 134217728 loads, then 134217728 load+store pairs\n");
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "--inflight")) {
+    // rate against requests in flight: read-modify-write of random 16-byte rows over 32 GiB, 32 live lanes per wavefront,
+    // 1 / 2 / 4 independent rows per lane and 512 .. 8192 wavefronts (the encoder holds ~1 800 wavefronts with 1-2 rows
+    // in flight per lane)
+    unsigned char* b = nullptr; unsigned* sk = nullptr;
+    CK(hipMalloc((void**)&b, (32ull << 20) * 1024)); CK(hipMemset(b, 0, (32ull << 20) * 1024)); CK(hipMalloc((void**)&sk, 64));
+    printf("%-10s %12s %12s %12s   (G read-modify-writes / s; rows in flight = wavefronts x 32 x per-lane)\n", "wavefronts", "1 per lane", "2 per lane", "4 per lane");
+    for (unsigned waves = 512; waves <= 8192; waves *= 2) {
+      const int iters = (int)(4096u * 2048u / waves);
+      printf("%-10u %12.2f %12.2f %12.2f\n", waves, run<1, 1>(b, 32ull << 20, 1024u, 32u, waves, iters, sk),
+             run<1, 2>(b, 32ull << 20, 1024u, 32u, waves, iters / 2, sk), run<1, 4>(b, 32ull << 20, 1024u, 32u, waves, iters / 4, sk));
+      fflush(stdout);
+    }
+    return 0;
+  }
   size_t free_b = 0, total_b = 0;
   CK(hipMemGetInfo(&free_b, &total_b));
   const unsigned nregions = 1024;
