@@ -518,6 +518,8 @@ def main():
             # what really bounds the encoder: random memory TRANSACTIONS.  The counters tally 64 B per
             # random read and 32 B per random store (calibrated on profiles/r03/gups.hip, which also gives the machine's rate)
             transactions = {"per_input_byte": tj[key]["fetch_bytes_per_input_byte"] / 64.0 + tj[key]["write_bytes_per_input_byte"] / 32.0,
+                            "counted_as": "FETCH_SIZE / 64 B (a read request) + WRITE_SIZE / 32 B (a written sector); the coalesced "
+                                          "stream writes are in there sector by sector, so this overstates the random share",
                             "peak_G_per_s": 48.0, "peak_source": "profiles/r03/gups_results.txt: 24 G random read-modify-writes/s = 48 G transactions/s"}
     except Exception:
         pass
