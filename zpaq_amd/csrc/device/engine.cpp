@@ -15,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
 
 #include "../host/codegen.hpp"
@@ -376,7 +377,9 @@ static uint32_t pipe_stream_bytes_per_byte(const zpq_plan* plan) {
   return (uint32_t)(L.nctx * 4 + L.nrow * 8 + L.n * 16);
 }
 
-static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode) {
+// must_specialise: the plan has blocks of several segments in this batch; only the per-header kernels carry coder and model
+// state across segments, so such a plan compiles whatever the batch's JIT budget says.
+static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode, bool must_specialise = false) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
   KernelPick r;
   const int want = e.kernel_choice;
@@ -392,7 +395,7 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   // generic wave kernel this time and are picked up by later calls.
   if (!decode && (want == 0 || want == 4)) {
     bool did = false;
-    PipeKernel* k = pipe_kernel_for(p, mode, want == 4 || e.jit_left > 0, &did);
+    PipeKernel* k = pipe_kernel_for(p, mode, want == 4 || must_specialise || e.jit_left > 0, &did);
     if (did && e.jit_left > 0) --e.jit_left;
     if (k) { r.kind = 4; r.pipe = k; r.mode = mode; return r; }
     if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->cur().pipe_note);
@@ -404,7 +407,7 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
     const int variant = attempt == 0 ? first : 1 - first;
     if (attempt == 1 && p->cur().spec_state[variant] <= 0) break;                     // fall back only to a shape already loaded
     bool did = false;
-    SpecKernel* k = spec_kernel_for(p, variant, want >= 3 || e.jit_left > 0, nullptr, &did);
+    SpecKernel* k = spec_kernel_for(p, variant, want >= 3 || must_specialise || e.jit_left > 0, nullptr, &did);
     if (did && e.jit_left > 0) --e.jit_left;
     if (k) { r.kind = 3; r.spec = k; return r; }
   }
@@ -742,13 +745,17 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
 }
 
 template <class PlanOf, class LenOf>
-static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
+static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of,
+                                            const std::set<const zpq_plan*>* multi_segment = nullptr) {
   const size_t cnt = order.size();
   const bool dense = cnt > (size_t)4 * e.cus;
   const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of, len_of);
   precompile_unseen(e, decode, dense, order, plan_of, mode_of);
   std::vector<KernelPick> pick(cnt);
-  for (size_t k = 0; k < cnt; ++k) pick[k] = kernel_kind(e, plan_of(order[k]), dense, decode, mode_of.at(plan_of(order[k])));
+  for (size_t k = 0; k < cnt; ++k) {
+    const zpq_plan* pl = plan_of(order[k]);
+    pick[k] = kernel_kind(e, pl, dense, decode, mode_of.at(pl), multi_segment && multi_segment->count(pl));
+  }
   std::vector<uint32_t> idx(cnt);
   for (size_t k = 0; k < cnt; ++k) idx[k] = (uint32_t)k;
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
@@ -922,9 +929,11 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     e.results.ensure(cnt * sizeof(BlockResult));
     std::vector<uint32_t> order(cnt);
     for (size_t i = 0; i < cnt; ++i) order[i] = (uint32_t)(pos + i);
+    std::set<const zpq_plan*> multi_segment;
+    for (size_t i = pos; i < end; ++i) if (blocks[i].nseg > 1) multi_segment.insert(blocks[i].plan);
     std::vector<LaunchGroup> groups = make_groups(
         e, decode, order, [&](uint32_t b) { return blocks[b].plan; },
-        [&](uint32_t b) { return blocks[b].in_len + blocks[b].prefix_len; });
+        [&](uint32_t b) { return blocks[b].in_len + blocks[b].prefix_len; }, &multi_segment);
     std::vector<BlockJob> jobs(cnt);
     // inputs are gathered into one buffer and sent with one copy: pageable memory by default; with
     // ZPAQ_AMD_PINNED_STAGE=1 a page-locked buffer kept by the engine, filled by several threads (experimental)
