@@ -513,7 +513,11 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         key = f"method {a.method} x {nb} x {bs} {a.kind} {a.mode}"
-        if key in tj and tj[key].get("kernel_origin") == origin:
+        entries = tj.get(key, [])
+        entries = entries if isinstance(entries, list) else [entries]       # one entry per code object that was profiled
+        hit = [e for e in entries if e.get("kernel_origin") == origin]
+        if hit:
+            tj = {key: hit[0]}
             traffic = tj[key]["traffic_bytes"]
             # what really bounds the encoder: random memory TRANSACTIONS.  The counters tally 64 B per
             # random read and 32 B per random store (calibrated on profiles/r03/gups.hip, which also gives the machine's rate)
