@@ -225,6 +225,11 @@ int zpq_compress_blocks(const char* method, uint8_t* const* in, const uint32_t* 
  * SHA-1 trailers when present (status ZPQ_E_CORRUPT on mismatch). */
 int zpq_decompress(const uint8_t* archive, uint64_t n, uint8_t* out, uint64_t cap,
                    uint64_t* out_len);
+/* Work bound for archives from untrusted sources: the ZPAQL steps ONE call of a block's own (non-standard) PCOMP
+ * post-processor may take before the block is rejected with ZPQ_E_VM.  The reference (PostProcessor / ZPAQL::run,
+ * libzpaq.cpp:1310-1330, 2236-2330) has no bound at all and a damaged program loops for good; the default here is 2^34
+ * (about a minute), which no useful program comes near.  0 restores the default.  Process-wide. */
+void zpq_set_pcomp_step_limit(uint64_t steps);
 
 /* ---- host-side pieces of the boundary, exposed for reuse and for tests ---- */
 /* SHA1 (libzpaq.h:934-954). */

@@ -6,6 +6,8 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 
@@ -524,3 +526,36 @@ def test_preprocessing_with_a_supplied_suffix_array(zlib_):
                                              out_b.ctypes.data_as(u8p), out_b.size, C.byref(lb)) == 0
             assert la.value == lb.value and (out_a[:la.value] == out_b[:lb.value]).all(), (xm, d.size)
             assert (a == b).all()          # E8E9 left both buffers in the same (filtered) state
+
+
+def test_damaged_inputs_never_crash_the_host_paths(zlib_):
+    """tests/fuzz_host.py, a short round: damaged archives (stored / LZ77 / BWT blocks, decoded on the host), damaged block
+    headers, random ZPAQL configs and method strings all end in a result or a ZpaqError."""
+    import fuzz_host
+    st = fuzz_host.run(2400, 20260926)
+    assert st["decoded"] and st["rejected"] and st["plans"] and st["bad_plans"] and st["asm_ok"] and st["asm_bad"]
+
+
+def test_host_paths_agree_with_the_reference_on_random_and_damaged_inputs(zlib_, ref):
+    """The same generator with the reference beside it: configs assemble to the same bytes or are refused by both, method
+    strings give the same header and PCOMP, damaged archives that the reference decodes decode to the same bytes (the
+    documented differences: SHA-1 trailers are verified here, pre-processor types > 7 are refused here)."""
+    import fuzz_host
+    st = fuzz_host.run(1600, 7, ref=ref)
+    assert st["differences"] == [], st["differences"][:3]
+    assert st.get("ref_decoded", 0) > 0
+
+
+def test_stray_semicolons_in_a_program_and_unmodeled_block_headers(zlib_, ref):
+    """Two findings of the differential run: compile_comp ignores a ";" between instructions (libzpaq.cpp:2686 stores only
+    op <= 255), and ZPAQL::read's header checks apply to blocks without components too."""
+    cfg = "comp 3 3 0 0 1\n 0 icm 5\nhcomp\n a=b ; *d=a ; halt\nend"
+    assert zlib_.assemble(cfg) == ref.compile(cfg)
+    a = bytearray(zlib_.compress_block(b"stored bytes", "0", "f", None))
+    i = a.find(b"zPQ") + 5
+    assert a[i + 6] == 0 and a[i + 7] == 0          # n = 0, COMP END
+    a[i + 7] = 0x80
+    with pytest.raises(zlib_.ZpaqError, match="COMP END"):
+        zlib_.decompress(bytes(a))
+    with pytest.raises(Exception):
+        ref.decompress(bytes(a), 1 << 16)

@@ -301,6 +301,7 @@ void zpq_sha1(const uint8_t* in, uint64_t n, uint8_t out20[20]) {
   Sha1 s; s.update(in, (size_t)n); memcpy(out20, s.result(), 20);
 }
 void zpq_sha1_force_portable(int yes) { sha1_force_portable(yes != 0); }
+void zpq_set_pcomp_step_limit(uint64_t steps) { postproc_set_step_limit(steps); }
 
 void zpq_e8e9(uint8_t* data, uint32_t n) { e8e9_forward(data, n); }
 

@@ -391,7 +391,10 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
   while (find_block(a, n, pos, blk)) {
     const size_t this_block = nblocks++;
     const bool modeled = blk.header[6] != 0;
-    zpq_plan* plan = modeled ? plan_for(plans, blk.header) : nullptr;
+    // every block header goes through the parser (ZPAQL::read's checks, libzpaq.cpp:1145-1216: sizes, COMP END, HCOMP
+    // END), also the ones without a model, whose segments never see a plan
+    zpq_plan* parsed = plan_for(plans, blk.header);
+    zpq_plan* plan = modeled ? parsed : nullptr;
     int nseg = 0;
     (void)nseg;
     for (;;) {

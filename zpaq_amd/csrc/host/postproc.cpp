@@ -8,6 +8,7 @@
 // byte for byte one of those runs natively -- the reference gets the same effect from its x86 JIT
 // (libzpaq.cpp:3231-3811) -- and anything else is interpreted.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -18,6 +19,8 @@
 namespace zpq {
 
 namespace {
+
+std::atomic<U64> g_pcomp_steps{(U64)1 << 34};   // steps one call of a custom post-processor may take (postproc_set_step_limit)
 
 class PcompVm {
  public:
@@ -33,9 +36,9 @@ class PcompVm {
     // standard programs need a few dozen steps per array element at most (inverse BWT at the end of a segment): 64 per
     // element of H and M, and never less than 2^28, ends a hostile stream in about a second instead of a minute.  That
     // bound is only safe for programs whose cost is known, so it applies to the standard ones (set_standard(true)); a
-    // custom program keeps 2^34 steps per call (about a minute) -- the one deviation from the reference here, which
+    // custom program keeps 2^34 steps per call (about a minute; zpq_set_pcomp_step_limit changes it) -- the one deviation from the reference here, which
     // would never give up.
-    max_steps_ = (U64)1 << 34;
+    max_steps_ = g_pcomp_steps.load(std::memory_order_relaxed);
     tight_steps_ = std::max<U64>((U64)1 << 28, 64ull * ((U64)H_.size() + (U64)M_.size()));
   }
 
@@ -145,6 +148,8 @@ class PcompVm {
 };
 
 }  // namespace
+
+void postproc_set_step_limit(U64 steps) { g_pcomp_steps.store(steps ? steps : (U64)1 << 34, std::memory_order_relaxed); }
 
 // PostProcessor of ONE block (the reference initialises it once per block, libzpaq.cpp:2320-2330: only the first
 // segment carries the PP header; later segments continue in the same mode and, for PROG, with the same machine).

@@ -199,7 +199,7 @@ int assemble_code(Lexer& lx, std::vector<U8>& code, size_t header_overhead) {
         operand2 = a >> 8;
       }
     } else if (op == P_SEMI) {
-      lx.err("unexpected");
+      continue;             // a stray ";" inside a program emits nothing (compile_comp stores only op <= 255, libzpaq.cpp:2686)
     } else if ((op & 7) == 7) {
       if (op == OP_LJ) {
         const int v = lx.number(0, 65535);
