@@ -211,7 +211,9 @@ class Decompresser {
   void readComment(Writer* comment = 0);
   void setOutput(Writer* out) { out_ = out; }
   void setSHA1(SHA1* s) { sha1_ = s; }
-  bool decompress(int n = -1);               // n more bytes (-1: to end of segment); false at end
+  bool decompress(int n = -1);               // n more OUTPUT bytes (-1: to end of segment); false at end.  (The reference
+                                             // counts n bytes into the post-processor and flushes its output every 64 KiB:
+                                             // same totals, different pieces for LZ77 / BWT blocks.)
   bool pcomp(Writer* out2);
   void readSegmentEnd(char* sha1string = 0); // 21 bytes: flag + digest
   int buffered() { return (int)(buf_.size() - rpos_); }

@@ -2,10 +2,13 @@
 way zpaq.cpp uses libzpaq: compiled here with g++ against the in-tree library."""
 import os
 import subprocess
+import sys
 
 import pytest
 
 from conftest import ROOT
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def _build(tmp_path):
@@ -99,3 +102,61 @@ def test_blocks_of_several_segments(tmp_path, gpu, ref):
         ours = open(dst, "rb").read()
         assert ours == ref.compress_level_segments(parts, level), level
         assert gpu.decompress(ours) == b"".join(parts)
+
+
+def test_decompresser_call_sequences_match_the_reference_on_valid_and_damaged_archives(tmp_path, zlib_, ref):
+    """tests/cpp/decomp_driver.cpp -- ONE source, built against include/libzpaq.h + libzpaq_amd.so and against the
+    reference's libzpaq.h + libzpaq.cpp -- walks archives the way zpaq.cpp does (findBlock(&mem), hcomp, findFilename,
+    readComment, decompress() / decompress(n) loops, pcomp, readSegmentEnd, skipped and half-read segments).  Blocks
+    without a model (methods 0-2, BWT without a model) decode on the host, so this runs without a GPU.  The two programs
+    must print the same events: memory figures, headers, names, comments, bytes, SHA-1 state and trailers, the position
+    in the input (buffered()).  Damaged archives: both reject, or both print the same (what the reference delivered
+    before it noticed is not compared, nor is how much of a half-read segment had left its output buffer)."""
+    import random
+    import fuzz_host
+    ref_dir = "/root/reference"
+    if not os.path.exists(os.path.join(ref_dir, "libzpaq.cpp")):
+        pytest.skip("reference sources not present")
+    drv = os.path.join(ROOT, "tests", "cpp", "decomp_driver.cpp")
+    mine, theirs = str(tmp_path / "mine"), str(tmp_path / "theirs")
+    for cmd in (["g++", "-O1", "-std=c++17", drv, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "zpaq_amd"), "-lzpaq_amd",
+                 "-Wl,-rpath," + os.path.join(ROOT, "zpaq_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", mine],
+                ["g++", "-O1", "-std=c++17", "-DNDEBUG", "-Dunix", drv, "-I" + ref_dir, os.path.join(ref_dir, "libzpaq.cpp"), "-pthread", "-o", theirs]):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    rng = random.Random(5)
+    seeds = fuzz_host.seeds(zlib_)
+    seeds.append(seeds[0] + seeds[3])           # several blocks in one stream
+    path = str(tmp_path / "a.zpaq")
+
+    def run(exe, piece, mode):
+        try:
+            p = subprocess.run([exe, path, str(piece), str(mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=3)
+            return p.returncode, p.stdout.decode(), p.stderr.decode()
+        except subprocess.TimeoutExpired:
+            return "hang", "", ""
+
+    same = errors = 0
+    for it in range(3 * len(seeds) + 90):
+        if it < 3 * len(seeds):
+            a, mode = seeds[it % len(seeds)], it // len(seeds)      # every valid archive in every mode
+        else:
+            a, mode = fuzz_host.mutate(rng, rng.choice(seeds)), rng.choice([0, 0, 1, 2])
+        piece = rng.choice([-1, -1, 1, 7, 100, 4096, 1 << 20])
+        with open(path, "wb") as fh:
+            fh.write(a)
+        t = run(theirs, piece, mode)
+        if t[0] == "hang":
+            continue                     # a damaged PCOMP program: the reference never gives up
+        m = run(mine, piece, mode)
+        if "NODEVICE" in m[2] or "no GPU" in m[2] or "device" in m[2].lower():
+            continue                     # damaged into a modelled block
+        assert m[0] == 0 and t[0] == 0, (it, m, t)
+        if mode == 2:
+            m, t = [(o[0], "".join(l + "\n" for l in o[1].splitlines() if not l.startswith("data "))) for o in (m, t)]
+        if m[1].rstrip().endswith("error") and t[1].rstrip().endswith("error"):
+            errors += 1
+            continue
+        assert m[1] == t[1], (it, piece, mode, a.hex()[:400], m[1][-400:], t[1][-400:])
+        same += 1
+    assert same > 3 * len(seeds) and errors > 10, (same, errors)

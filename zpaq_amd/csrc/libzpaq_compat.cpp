@@ -284,15 +284,12 @@ bool Decompresser::findBlock(double* memptr) {
   }
   if (hsize < 6) error("header too short");
   if (level == 1 && header_[6] == 0) error("ZPAQ level 1 requires at least 1 component");
-  if (memptr) {
-    if (header_[6]) {
-      guarded([&] {
-        zpq_plan* p = zpq::plan_from_header(header_.data(), header_.size());
-        *memptr = p->memory;
-        delete p;
-      });
-    } else *memptr = 0;
-  }
+  // ZPAQL::read's checks and ZPAQL::memory() for every block, modelled or not (libzpaq.cpp:1145-1216, 1228-1270)
+  guarded([&] {
+    zpq_plan* p = zpq::plan_from_header(header_.data(), header_.size());
+    if (memptr) *memptr = p->memory;
+    delete p;
+  });
   segs_in_block_ = 0;
   block_cache_.clear();
   skipped_in_block_ = false;
