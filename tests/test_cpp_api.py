@@ -104,6 +104,36 @@ def test_blocks_of_several_segments(tmp_path, gpu, ref):
         assert gpu.decompress(ours) == b"".join(parts)
 
 
+def _build_both(tmp_path, source, name):
+    """One driver source against this library's libzpaq.h + .so, and against the reference's libzpaq.h + libzpaq.cpp."""
+    ref_dir = "/root/reference"
+    if not os.path.exists(os.path.join(ref_dir, "libzpaq.cpp")):
+        pytest.skip("reference sources not present")
+    drv = os.path.join(ROOT, "tests", "cpp", source)
+    mine, theirs = str(tmp_path / (name + "_mine")), str(tmp_path / (name + "_ref"))
+    for cmd in (["g++", "-O1", "-std=c++17", drv, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "zpaq_amd"), "-lzpaq_amd",
+                 "-Wl,-rpath," + os.path.join(ROOT, "zpaq_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", mine],
+                ["g++", "-O1", "-std=c++17", "-DNDEBUG", "-Dunix", drv, "-I" + ref_dir, os.path.join(ref_dir, "libzpaq.cpp"), "-pthread", "-o", theirs]):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+    return mine, theirs
+
+
+def test_compressor_call_sequences_write_the_reference_archives(tmp_path, zlib_):
+    """tests/cpp/comp_driver.cpp through both libraries: Compressor on blocks without a model -- config text with and without
+    a PCOMP section and its command, header bytes, postProcess() with and without a program, setVerify, segments with and
+    without names / comments / checksums, compress() in pieces, endSegmentChecksum / getSize / getChecksum, calls out of
+    order, a config error: same archive bytes, same return values, same error text."""
+    mine, theirs = _build_both(tmp_path, "comp_driver.cpp", "comp")
+    for scenario in range(7):
+        for seed in range(1, 11):
+            out = [subprocess.run([exe, str(scenario), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+                   for exe in (mine, theirs)]
+            assert out[0].returncode == 0 and out[1].returncode == 0, (scenario, seed, out[0].stdout[-300:], out[1].stdout[-300:])
+            assert out[0].stdout == out[1].stdout, (scenario, seed, out[0].stdout[:600], out[1].stdout[:600])
+            assert "archive=" in out[0].stdout
+
+
 def test_decompresser_call_sequences_match_the_reference_on_valid_and_damaged_archives(tmp_path, zlib_, ref):
     """tests/cpp/decomp_driver.cpp -- ONE source, built against include/libzpaq.h + libzpaq_amd.so and against the
     reference's libzpaq.h + libzpaq.cpp -- walks archives the way zpaq.cpp does (findBlock(&mem), hcomp, findFilename,
@@ -114,16 +144,7 @@ def test_decompresser_call_sequences_match_the_reference_on_valid_and_damaged_ar
     before it noticed is not compared, nor is how much of a half-read segment had left its output buffer)."""
     import random
     import fuzz_host
-    ref_dir = "/root/reference"
-    if not os.path.exists(os.path.join(ref_dir, "libzpaq.cpp")):
-        pytest.skip("reference sources not present")
-    drv = os.path.join(ROOT, "tests", "cpp", "decomp_driver.cpp")
-    mine, theirs = str(tmp_path / "mine"), str(tmp_path / "theirs")
-    for cmd in (["g++", "-O1", "-std=c++17", drv, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "zpaq_amd"), "-lzpaq_amd",
-                 "-Wl,-rpath," + os.path.join(ROOT, "zpaq_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", mine],
-                ["g++", "-O1", "-std=c++17", "-DNDEBUG", "-Dunix", drv, "-I" + ref_dir, os.path.join(ref_dir, "libzpaq.cpp"), "-pthread", "-o", theirs]):
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        assert r.returncode == 0, r.stdout
+    mine, theirs = _build_both(tmp_path, "decomp_driver.cpp", "decomp")
     rng = random.Random(5)
     seeds = fuzz_host.seeds(zlib_)
     seeds.append(seeds[0] + seeds[3])           # several blocks in one stream

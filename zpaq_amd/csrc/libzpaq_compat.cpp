@@ -528,6 +528,7 @@ bool Compressor::pcomp(Writer* out2) {
 }
 
 void Compressor::startSegment(const char* filename, const char* comment) {
+  if (header_.size() < 7) error("no block started");     // the reference asserts (and reads a null header under NDEBUG)
   std::vector<U8> head;
   head.push_back(1);
   while (filename && *filename) head.push_back((U8)*filename++);
@@ -560,6 +561,7 @@ void Compressor::postProcess(const char* pcomp, int len) {
 }
 
 bool Compressor::compress(int n) {
+  if (!in_) error("no input");
   if (state_ == SEG1) postProcess();
   char buf[1 << 14];
   while (n) {
@@ -603,6 +605,7 @@ static void put_trailer(std::vector<U8>& t, const char* sha1) {
 }
 
 void Compressor::endSegment(const char* sha1string) {
+  if (header_.size() < 7) error("no block started");     // the reference asserts (and reads a null header under NDEBUG)
   flush_segment();
   std::vector<U8> t;
   put_trailer(t, sha1string);
@@ -612,6 +615,7 @@ void Compressor::endSegment(const char* sha1string) {
 }
 
 char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
+  if (header_.size() < 7) error("no block started");     // the reference asserts (and reads a null header under NDEBUG)
   flush_segment();
   if (verify_) {
     if (size) *size = (int64_t)seg_sha1_.usize();
@@ -626,6 +630,7 @@ char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
 }
 
 void Compressor::endBlock() {
+  if (header_.size() < 7) error("no block started");     // the reference asserts (and reads a null header under NDEBUG)
   if (header_[6] != 0 && !segq_.empty()) {
     // the block's segments through the model in one device job (Predictor and Encoder are initialised once per block,
     // libzpaq.cpp:2889-2891), then the bytes in archive order
