@@ -515,7 +515,13 @@ def main():
         key = f"method {a.method} x {nb} x {bs} {a.kind} {a.mode}"
         entries = tj.get(key, [])
         entries = entries if isinstance(entries, list) else [entries]       # one entry per code object that was profiled
-        hit = [e for e in entries if e.get("kernel_origin") == origin]
+        obj_sha = None
+        if origin.startswith("cache:"):          # the code object that ran: same machine code as the profiled one also counts
+            import hashlib
+            obj = os.path.join(ROOT, "zpaq_amd", "spec_cache", origin[6:].split()[0] + ".hsaco")
+            if os.path.exists(obj):
+                obj_sha = hashlib.sha256(open(obj, "rb").read()).hexdigest()
+        hit = [e for e in entries if e.get("kernel_origin") == origin or (obj_sha and e.get("code_object_sha256") == obj_sha)]
         if hit:
             tj = {key: hit[0]}
             traffic = tj[key]["traffic_bytes"]

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Random MODELS through the device code on the host: a random but valid ZPAQL config (1..8 components of every type with
+random sizes, inputs, rates and masks, a random HCOMP program) is assembled, and the kernels the engine would build for
+that header -- the per-header wavefront coder (encode and decode, spec_kernel.h) and the pipelined encoder in its shapes
+(pipe_kernel.h) -- are run by the wavefront emulator (tests/emu) on a few small blocks.  Every coded stream must be the
+oracle's, every decode must return the input.  No GPU; about 20 s of compilation per model.
+
+    python tests/fuzz_emu.py [models] [seed]
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+
+def random_model(rng: random.Random) -> str:
+    import fuzz_host
+    n = rng.randrange(1, 9)
+    hh, hm = rng.randrange(0, 8), rng.randrange(0, 10)
+    lines = ["comp %d %d 0 0 %d" % (hh, hm, n)]
+    for i in range(n):
+        t = rng.choice(["const", "cm", "icm", "match", "avg", "mix2", "mix", "isse", "sse"]) if i else rng.choice(["const", "cm", "icm", "match"])
+        j = rng.randrange(i) if i else 0
+        k = rng.randrange(i) if i else 0
+        sz = rng.randrange(0, 12)
+        m0 = rng.randrange(i) if i else 0
+        args = {"const": [rng.randrange(256)], "cm": [sz, rng.randrange(256)], "icm": [sz], "match": [sz, rng.randrange(0, 12)],
+                "avg": [j, k, rng.randrange(256)], "mix2": [sz, j, k, rng.randrange(256), rng.choice([0, 255, rng.randrange(256)])],
+                "mix": [min(sz, 9), m0, rng.randrange(1, i - m0 + 1) if i else 1, rng.randrange(256), rng.choice([0, 255, rng.randrange(256)])],
+                "isse": [sz, j], "sse": [sz, j, rng.randrange(0, 64), rng.randrange(64, 256)]}[t]
+        lines.append("  %d %s %s" % (i, t, " ".join(map(str, args))))
+    code = [w for w in fuzz_host.random_code(rng, 0, False) + fuzz_host.random_code(rng, 0, False) if not w.startswith(("out", "error", "lj", "jt", "jf", "jmp", "halt", "a+= $", "a= $"))]
+    lines += ["hcomp"] + ["  " + " ".join(code)] + ["  halt", "end"]
+    return "\n".join(lines)
+
+
+def main():
+    import numpy as np
+    import emu
+    import zpaq_amd as z
+    from oracle.oracle_py import Oracle
+    from zpaq_amd import corpus
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    models = int(pos[0]) if pos else 10
+    rng = random.Random(int(pos[1]) if len(pos) > 1 else 1)
+    orc = Oracle()
+    done = skipped = 0
+    t0 = time.time()
+    while done < models:
+        cfg = random_model(rng)
+        try:
+            header, _ = z.assemble(cfg)
+            z.Plan(header)
+        except z.ZpaqError:
+            skipped += 1
+            continue
+        datas = [corpus.block("text", 700, rng.randrange(1 << 20)).tobytes(), corpus.block("lcg", 300, 3).tobytes(),
+                 bytes(400), corpus.block("records", 500, rng.randrange(1 << 20)).tobytes(), b""]
+        inputs = [b"\0" + d for d in datas]
+        want = []
+        try:
+            want = [orc.encode(header, i) for i in inputs]
+        except Exception as ex:          # HCOMP that fails at run time (division by zero is fine in ZPAQL; jumps out of range are not)
+            skipped += 1
+            continue
+        try:
+            enc = emu.run(header, inputs, waves=4)
+            for w, (coded, status, consumed), i in zip(want, enc, inputs):
+                assert status == 0 and consumed == len(i) and coded == w, ("spec encode", status, consumed, len(i))
+            dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=4, out_cap=max(len(x) for x in inputs))
+            for i, (plain, status, consumed) in zip(inputs, dec):
+                assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
+            for mode in (0, 1):
+                out = emu.pipe_run(header, inputs, mode=mode)
+                for w, (coded, status, _consumed), i in zip(want, out, inputs):
+                    assert status == 0 and coded == w, ("pipe mode %d" % mode, status)
+        except AssertionError as ex:
+            print("MISMATCH", ex.args, "\n" + cfg, flush=True)
+            return 1
+        except RuntimeError as ex:
+            print("BUILD/RUN FAILURE", str(ex)[-1500:], "\n" + cfg, flush=True)
+            return 1
+        done += 1
+        print("model %d ok (%d comps, %.0f s)" % (done, header[6], time.time() - t0), flush=True)
+    print("models", done, "skipped", skipped)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -50,7 +50,7 @@ _REG = ["a", "b", "c", "d", "*b", "*c", "*d"]
 _BIN = ["+=", "-=", "*=", "/=", "%=", "&=", "&~", "|=", "^=", "<<=", ">>=", "==", "<", ">"]
 
 
-def random_code(rng: random.Random, depth: int = 0) -> list:
+def random_code(rng: random.Random, depth: int = 0, loops: bool = True) -> list:
     """A ZPAQL instruction sequence with matched if / do structures (libzpaq.cpp:6884-7190 compiles it)."""
     out = []
     for _ in range(rng.randrange(0, 12)):
@@ -68,11 +68,11 @@ def random_code(rng: random.Random, depth: int = 0) -> list:
         elif k == 6:
             out.append(rng.choice(["hash", "hashd", "out", "r=a %d" % rng.randrange(256), "%s=r %d" % (rng.choice(_REG[:4]), rng.randrange(256))]))
         elif k == 7 and depth < 3:
-            out += [rng.choice(["if", "ifnot", "ifl", "ifnotl"])] + random_code(rng, depth + 1)
+            out += [rng.choice(["if", "ifnot", "ifl", "ifnotl"])] + random_code(rng, depth + 1, loops)
             if rng.random() < .5:
-                out += [rng.choice(["else", "elsel"])] + random_code(rng, depth + 1)
+                out += [rng.choice(["else", "elsel"])] + random_code(rng, depth + 1, loops)
             out.append("endif")
-        elif k == 8 and depth < 3:
+        elif k == 8 and depth < 3 and loops:
             out += ["do"] + random_code(rng, depth + 1) + [rng.choice(["while", "until", "forever"])]
         elif k == 9:
             out.append("a+= $%d" % rng.randrange(1, 10) if rng.random() < .5 else "a= $%d+%d" % (rng.randrange(1, 10), rng.randrange(200)))
