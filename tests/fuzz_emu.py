@@ -41,15 +41,13 @@ def random_model(rng: random.Random) -> str:
     return "\n".join(lines)
 
 
-def main():
-    import numpy as np
+def run(models: int, seed: int, verbose: bool = True) -> int:
+    """0: every model agreed with the oracle; 1: a mismatch (printed with the config)."""
     import emu
     import zpaq_amd as z
     from oracle.oracle_py import Oracle
     from zpaq_amd import corpus
-    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
-    models = int(pos[0]) if pos else 10
-    rng = random.Random(int(pos[1]) if len(pos) > 1 else 1)
+    rng = random.Random(seed)
     orc = Oracle()
     done = skipped = 0
     t0 = time.time()
@@ -88,9 +86,16 @@ def main():
             print("BUILD/RUN FAILURE", str(ex)[-1500:], "\n" + cfg, flush=True)
             return 1
         done += 1
-        print("model %d ok (%d comps, %.0f s)" % (done, header[6], time.time() - t0), flush=True)
-    print("models", done, "skipped", skipped)
+        if verbose:
+            print("model %d ok (%d comps, %.0f s)" % (done, header[6], time.time() - t0), flush=True)
+    if verbose:
+        print("models", done, "skipped", skipped)
     return 0
+
+
+def main():
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    return run(int(pos[0]) if pos else 10, int(pos[1]) if len(pos) > 1 else 1)
 
 
 if __name__ == "__main__":
