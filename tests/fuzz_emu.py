@@ -5,7 +5,8 @@ that header -- the per-header wavefront coder (encode and decode, spec_kernel.h)
 (pipe_kernel.h) -- are run by the wavefront emulator (tests/emu) on a few small blocks.  Every coded stream must be the
 oracle's, every decode must return the input.  No GPU; about 20 s of compilation per model.
 
-    python tests/fuzz_emu.py [models] [seed]
+    python tests/fuzz_emu.py [models] [seed] [--big]      (--big: 9..24 components, the 8-block workgroup shape, the
+                                                           latency shapes of the pipelined encoder)
 """
 from __future__ import annotations
 
@@ -20,9 +21,9 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "emu"))
 
 
-def random_model(rng: random.Random) -> str:
+def random_model(rng: random.Random, big: bool = False) -> str:
     import fuzz_host
-    n = rng.randrange(1, 9)
+    n = rng.randrange(9, 25) if big else rng.randrange(1, 9)
     hh, hm = rng.randrange(0, 8), rng.randrange(0, 10)
     lines = ["comp %d %d 0 0 %d" % (hh, hm, n)]
     for i in range(n):
@@ -41,7 +42,7 @@ def random_model(rng: random.Random) -> str:
     return "\n".join(lines)
 
 
-def run(models: int, seed: int, verbose: bool = True) -> int:
+def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
     """0: every model agreed with the oracle; 1: a mismatch (printed with the config)."""
     import emu
     import zpaq_amd as z
@@ -52,7 +53,7 @@ def run(models: int, seed: int, verbose: bool = True) -> int:
     done = skipped = 0
     t0 = time.time()
     while done < models:
-        cfg = random_model(rng)
+        cfg = random_model(rng, big)
         try:
             header, _ = z.assemble(cfg)
             z.Plan(header)
@@ -69,13 +70,14 @@ def run(models: int, seed: int, verbose: bool = True) -> int:
             skipped += 1
             continue
         try:
-            enc = emu.run(header, inputs, waves=4)
+            waves = 8 if big else 4
+            enc = emu.run(header, inputs, waves=waves)
             for w, (coded, status, consumed), i in zip(want, enc, inputs):
                 assert status == 0 and consumed == len(i) and coded == w, ("spec encode", status, consumed, len(i))
-            dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=4, out_cap=max(len(x) for x in inputs))
+            dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=waves, out_cap=max(len(x) for x in inputs))
             for i, (plain, status, consumed) in zip(inputs, dec):
                 assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
-            for mode in (0, 1):
+            for mode in ((1, 2) if big else (0, 1)):
                 out = emu.pipe_run(header, inputs, mode=mode)
                 for w, (coded, status, _consumed), i in zip(want, out, inputs):
                     assert status == 0 and coded == w, ("pipe mode %d" % mode, status)
@@ -95,7 +97,7 @@ def run(models: int, seed: int, verbose: bool = True) -> int:
 
 def main():
     pos = [a for a in sys.argv[1:] if not a.startswith("--")]
-    return run(int(pos[0]) if pos else 10, int(pos[1]) if len(pos) > 1 else 1)
+    return run(int(pos[0]) if pos else 10, int(pos[1]) if len(pos) > 1 else 1, big="--big" in sys.argv)
 
 
 if __name__ == "__main__":
