@@ -148,6 +148,15 @@ def test_decompresser_call_sequences_match_the_reference_on_valid_and_damaged_ar
     rng = random.Random(5)
     seeds = fuzz_host.seeds(zlib_)
     seeds.append(seeds[0] + seeds[3])           # several blocks in one stream
+    # blocks of several segments that share one post-processor (custom PCOMP programs, unnamed segments, with and without
+    # checksums): what tests/cpp/comp_driver.cpp writes through the Compressor
+    cmine, _ = _build_both(tmp_path, "comp_driver.cpp", "comp")
+    for scenario in range(4):
+        for seed in (1, 2, 3):
+            r = subprocess.run([cmine, str(scenario), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+            arch = [l for l in r.stdout.splitlines() if l.startswith("archive=")]
+            assert r.returncode == 0 and arch, r.stdout[-300:]
+            seeds.append(bytes.fromhex(arch[0][len("archive="):]))
     path = str(tmp_path / "a.zpaq")
 
     def run(exe, piece, mode):

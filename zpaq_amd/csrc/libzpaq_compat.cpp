@@ -408,6 +408,9 @@ void Decompresser::decode_segment() {
 
 bool Decompresser::decompress(int n) {
   if (state_ != DATA) error("decompression after skipped segment");
+  // a segment of this block was left before its end (readSegmentEnd in the DATA state: Decoder::skip, decode_state = SKIP,
+  // libzpaq.cpp:2346-2352): the reference refuses every later segment of the block, with or without a model (2300)
+  if (skipped_in_block_) error("decompression after skipped segment");
   if (!seg_decoded_) decode_segment();
   size_t avail = decoded_.size() - dpos_;
   size_t take = (n < 0 || (size_t)n > avail) ? avail : (size_t)n;
@@ -432,7 +435,6 @@ void Decompresser::readSegmentEnd(char* sha1string) {
         while (curr == 0) { c = getc(); if (c < 0) error("unexpected end of file"); curr = (U32)c; }
         while (curr && (c = getc()) >= 0) curr = curr << 8 | (U32)c;
         ++segs_in_block_;
-        if (block_cache_.empty()) skipped_in_block_ = true;     // the model missed this segment (Decoder::skip, SKIP state)
       } else {
         for (;;) {
           U32 len = 0;
@@ -443,6 +445,7 @@ void Decompresser::readSegmentEnd(char* sha1string) {
       }
     }
     while ((c = getc()) == 0) {}
+    skipped_in_block_ = true;      // left before its end, read or not: no later segment of this block decodes
   } else {
     while ((c = getc()) == 0) {}   // a flush byte of 00 leaves extra zeros before the marker
   }
