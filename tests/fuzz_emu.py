@@ -62,6 +62,21 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
             continue
         datas = [corpus.block("text", 700, rng.randrange(1 << 20)).tobytes(), corpus.block("lcg", 300, 3).tobytes(),
                  bytes(400), corpus.block("records", 500, rng.randrange(1 << 20)).tobytes(), b""]
+        # lengths around the step size of the emulated pipeline (64 bytes), a random walk, a short period
+        for _ in range(rng.randrange(0, 3)):
+            n = rng.choice([1, 2, 63, 64, 65, 130, 517])
+            kind = rng.randrange(3)
+            if kind == 0:
+                datas.append(corpus.block(rng.choice(["text", "lcg", "records"]), n, rng.randrange(1 << 20)).tobytes())
+            elif kind == 1:
+                v, walk = 0, bytearray()
+                for _ in range(n):
+                    v = (v + rng.randrange(-3, 4)) & 255
+                    walk.append(v)
+                datas.append(bytes(walk))
+            else:
+                unit = bytes(rng.randrange(256) for _ in range(7))
+                datas.append((unit * (n // 7 + 1))[:n])
         inputs = [b"\0" + d for d in datas]
         want = []
         try:
@@ -78,7 +93,7 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
             for i, (plain, status, consumed) in zip(inputs, dec):
                 assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
             for mode in ((1, 2) if big else (0, 1)):
-                out = emu.pipe_run(header, inputs, mode=mode)
+                out = emu.pipe_run(header, inputs, mode=mode, group=rng.choice([None, None, None, 8, 16]))
                 for w, (coded, status, _consumed), i in zip(want, out, inputs):
                     assert status == 0 and coded == w, ("pipe mode %d" % mode, status)
         except AssertionError as ex:
