@@ -559,3 +559,11 @@ def test_stray_semicolons_in_a_program_and_unmodeled_block_headers(zlib_, ref):
         zlib_.decompress(bytes(a))
     with pytest.raises(Exception):
         ref.decompress(bytes(a), 1 << 16)
+
+
+def test_random_pcomp_programs_three_ways(zlib_, ref):
+    """tests/fuzz_pcomp.py, 25 programs: random PCOMP post-processors run by the reference, by this library's interpreter
+    and by the translator that serves the device (its output compiled for the host): same bytes, same failures.
+    (1500 programs of seed 2 were run when this was added.)"""
+    import fuzz_pcomp
+    assert fuzz_pcomp.run(25, 20260926, verbose=False) == 0
