@@ -37,7 +37,11 @@ def random_model(rng: random.Random, big: bool = False) -> str:
                 "mix": [min(sz, 9), m0, rng.randrange(1, i - m0 + 1) if i else 1, rng.randrange(256), rng.choice([0, 255, rng.randrange(256)])],
                 "isse": [sz, j], "sse": [sz, j, rng.randrange(0, 64), rng.randrange(64, 256)]}[t]
         lines.append("  %d %s %s" % (i, t, " ".join(map(str, args))))
-    code = [w for w in fuzz_host.random_code(rng, 0, False) + fuzz_host.random_code(rng, 0, False) if not w.startswith(("out", "error", "lj", "jt", "jf", "jmp", "halt", "a+= $", "a= $"))]
+    code = fuzz_host.random_code(rng, 0, False) + fuzz_host.random_code(rng, 0, False)
+    if rng.random() < 0.4:              # a counted loop (backward jumps: the translators' step budget is in the path)
+        code += ["b= %d" % rng.randrange(1, 30), "do"] + [w for w in fuzz_host.random_code(rng, 1, False) if not w.startswith(("b", "*b=", "a<>b"))] + \
+                ["b--", "a=b", "a> 0", "while"] + fuzz_host.random_code(rng, 0, False)
+    code = [w for w in code if not w.startswith(("out", "error", "lj", "jt", "jf", "jmp", "halt", "a+= $", "a= $"))]
     lines += ["hcomp"] + ["  " + " ".join(code)] + ["  halt", "end"]
     return "\n".join(lines)
 
