@@ -98,7 +98,7 @@ struct Engine {
   DevBuf segs;                         // segment tables of multi-segment blocks
   DevBuf sha_jobs, sha_out;            // SHA-1 of the staged inputs (sha1_blocks_kernel)
   DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
-  HostPinned pin_in;                   // staging of host inputs (ZPAQ_AMD_PINNED_STAGE=1; experimental, off by default)
+  HostPinned pin_in;                   // page-locked staging of host inputs, kept between calls (ZPAQ_AMD_PINNED_STAGE=0: pageable)
   hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
@@ -935,8 +935,8 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
         e, decode, order, [&](uint32_t b) { return blocks[b].plan; },
         [&](uint32_t b) { return blocks[b].in_len + blocks[b].prefix_len; }, &multi_segment);
     std::vector<BlockJob> jobs(cnt);
-    // inputs are gathered into one buffer and sent with one copy: pageable memory by default; with
-    // ZPAQ_AMD_PINNED_STAGE=1 a page-locked buffer kept by the engine, filled by several threads (experimental)
+    // inputs are gathered into one buffer and sent with one copy: a page-locked buffer kept by the engine, filled by
+    // several threads (+3 % on the headline's API figure in round 3); ZPAQ_AMD_PINNED_STAGE=0 = pageable memory
     std::unique_ptr<uint8_t[]> stage_buf;
     uint8_t* stage = nullptr;
     const char* pin_env = getenv("ZPAQ_AMD_PINNED_STAGE");          // (A/B of round 3: "0" = pageable staging)
