@@ -16,6 +16,17 @@ EMU = os.path.join(ROOT, "tests", "emu")
 BUILD = os.path.join(ROOT, "build", "emu")
 
 
+def _sanitize_flags():
+    """ZPQ_EMU_SANITIZE=1: the device code under UBSan: indices into the fixed arrays (LDS tables, per-slot registers),
+    misaligned and null accesses, bad bool loads abort the run.  Not checked: shift counts and signed overflow -- idle
+    lanes compute on their dummy parameters and discard the result (spec_kernel.h:515: a CONST lane's "sizebits" as a shift
+    count; :199: the multiply-add of a lane that is no ISSE), and the hardware wraps both.  No AddressSanitizer: the
+    lanes are fibers that switch stacks."""
+    if os.environ.get("ZPQ_EMU_SANITIZE") != "1":
+        return ()
+    return ("-fsanitize=undefined", "-fno-sanitize=shift,signed-integer-overflow", "-fno-sanitize-recover=undefined", "-g")
+
+
 def kernel_source(header: bytes, waves: int) -> str:
     import zpaq_amd as z
     L = z.lib()
@@ -44,9 +55,10 @@ def build(header: bytes, waves: int, extra_flags: Sequence[str] = ()) -> str:
     import zpaq_amd as z
     src = kernel_source(header, waves)
     deps = b"".join(open(p, "rb").read() for p in (
-        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "emu_main.cpp"),
+        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "emu_main.cpp"), os.path.join(EMU, "guard_alloc.h"),
         os.path.join(ROOT, "zpaq_amd", "csrc", "device", "spec_kernel.h"),
         os.path.join(ROOT, "zpaq_amd", "csrc", "device", "layout.h")))
+    extra_flags = tuple(extra_flags) + _sanitize_flags()
     key = hashlib.sha1(src.encode() + deps + " ".join(extra_flags).encode()).hexdigest()[:20]
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, f"emu_{key}")
@@ -133,9 +145,10 @@ def pipe_build(header: bytes, chunk: int | None = None, group: int | None = None
     src = pipe_source(header, chunk, group, mode)
     dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
     deps = b"".join(open(p, "rb").read() for p in (
-        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"),
+        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"), os.path.join(EMU, "guard_alloc.h"),
         os.path.join(dev, "pipe_kernel.h"), os.path.join(dev, "spec_kernel.h"), os.path.join(dev, "layout.h")))
-    key = hashlib.sha1(src.encode() + deps).hexdigest()[:20]
+    extra_flags = _sanitize_flags()
+    key = hashlib.sha1(src.encode() + deps + " ".join(extra_flags).encode()).hexdigest()[:20]
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, f"pipe_{key}")
     if os.path.exists(exe):
@@ -144,7 +157,7 @@ def pipe_build(header: bytes, chunk: int | None = None, group: int | None = None
     with open(gen, "w") as fh:
         fh.write('#include "wave_emu.h"\n' + src)
     libdir = os.path.dirname(z.library_path())
-    cmd = ["g++", "-O1", "-std=c++17", "-w", "-I", EMU, "-I", dev, "-I", os.path.join(ROOT, "include"), gen,
+    cmd = ["g++", "-O1", "-std=c++17", "-w", *extra_flags, "-I", EMU, "-I", dev, "-I", os.path.join(ROOT, "include"), gen,
            os.path.join(EMU, "pipe_emu_main.cpp"), os.path.join(EMU, "wave_emu.cpp"),
            "-L", libdir, "-lzpaq_amd", f"-Wl,-rpath,{libdir}", "-o", exe + ".tmp"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

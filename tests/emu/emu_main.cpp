@@ -10,6 +10,7 @@
 // arena layout and the constant tables come from libzpaq_amd.so's host code -- the same
 // objects the engine uploads to the GPU; the arena is initialised here the way
 // init_arena_kernel does it (device/kernels.hip).
+#include "guard_alloc.h"
 #include "wave_emu.h"
 
 #include <string>
@@ -99,17 +100,25 @@ int main(int argc, char** argv) {
   std::vector<std::vector<uint8_t>> ins(njobs), outs(njobs);
   std::vector<zpq::BlockJob> jobs(njobs);
   std::vector<zpq::BlockResult> res(njobs);
-  // one contiguous arena pool like the engine's, so that neighbouring blocks' arenas touch
-  uint8_t* pool = (uint8_t*)calloc((size_t)njobs, ph->arena_bytes);
-  if (!pool) { fprintf(stderr, "arena pool: out of memory\n"); return 2; }
+  // every block's arena and input between inaccessible pages (guard_alloc.h); ZPQ_EMU_GUARD=0: one contiguous arena pool
+  // like the engine's, so that neighbouring blocks' arenas touch
+  const bool guard = emu::guard_on();
+  uint8_t* pool = guard ? nullptr : (uint8_t*)calloc((size_t)njobs, ph->arena_bytes);
+  if (!guard && !pool) { fprintf(stderr, "arena pool: out of memory\n"); return 2; }
   for (unsigned b = 0; b < njobs; ++b) {
     if (b < nb) ins[b] = slurp(argv[6 + b]);
     outs[b].assign((size_t)out_cap + 64, 0xEE);
-    init_arena(pool + (size_t)b * ph->arena_bytes, blob, tb);
+    uint8_t* const arena = guard ? emu::guard_alloc(ph->arena_bytes, 256, 0) : pool + (size_t)b * ph->arena_bytes;
+    init_arena(arena, blob, tb);
     memset(&jobs[b], 0, sizeof(jobs[b]));
     jobs[b].plan = blob;
-    jobs[b].arena = pool + (size_t)b * ph->arena_bytes;
+    jobs[b].arena = arena;
     jobs[b].in = ins[b].data();
+    if (guard) {      // the engine pads every input to a multiple of 64 bytes: that much may be read, not more
+      uint8_t* gin = emu::guard_alloc(ins[b].size(), 64, 0);
+      if (!ins[b].empty()) memcpy(gin, ins[b].data(), ins[b].size());
+      jobs[b].in = gin;
+    }
     jobs[b].out = outs[b].data();
     jobs[b].in_len = (uint32_t)ins[b].size();
     jobs[b].out_cap = b < nb ? out_cap : 0;

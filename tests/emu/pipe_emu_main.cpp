@@ -7,6 +7,7 @@
 // launches them on the GPU -- same grids, same stream buffer, same arenas -- except that inside a step the
 // workgroups run in REVERSE dataflow order (consumers before producers): a unit that wrongly depended on data
 // produced in the same step would read a stale slot here and fail the comparison with the oracle.
+#include "guard_alloc.h"
 #include "wave_emu.h"
 
 #include <string>
@@ -102,21 +103,29 @@ int main(int argc, char** argv) {
   std::vector<std::vector<uint8_t>> ins(nb), outs(nb);
   std::vector<zpq::BlockJob> jobs(nb);
   std::vector<zpq::BlockResult> res(nb);
-  uint8_t* pool = (uint8_t*)calloc((size_t)nb, ph->arena_bytes);
+  // arenas, inputs and the stream buffer between inaccessible pages (guard_alloc.h); ZPQ_EMU_GUARD=0: plain allocations
+  const bool guard = emu::guard_on();
+  uint8_t* pool = guard ? nullptr : (uint8_t*)calloc((size_t)nb, ph->arena_bytes);
   const unsigned ngroups = (nb + G - 1) / G;
   // 0xA5 everywhere: a unit reading a stream slot nobody wrote gets garbage, not zeros
-  uint8_t* pipe = (uint8_t*)malloc((size_t)ngroups * group_bytes);
-  if (!pool || !pipe) { fprintf(stderr, "out of memory\n"); return 2; }
-  memset(pipe, 0xA5, (size_t)ngroups * group_bytes);
+  uint8_t* pipe = guard ? emu::guard_alloc((size_t)ngroups * group_bytes, 256, 0xA5) : (uint8_t*)malloc((size_t)ngroups * group_bytes);
+  if ((!guard && !pool) || !pipe) { fprintf(stderr, "out of memory\n"); return 2; }
+  if (!guard) memset(pipe, 0xA5, (size_t)ngroups * group_bytes);
   unsigned maxlen = 0;
   for (unsigned b = 0; b < nb; ++b) {
     ins[b] = slurp(argv[4 + b]);
     outs[b].assign((size_t)out_cap + 64, 0xEE);
-    init_arena(pool + (size_t)b * ph->arena_bytes, blob, tb);
+    uint8_t* const arena = guard ? emu::guard_alloc(ph->arena_bytes, 256, 0) : pool + (size_t)b * ph->arena_bytes;
+    init_arena(arena, blob, tb);
     memset(&jobs[b], 0, sizeof(jobs[b]));
     jobs[b].plan = blob;
-    jobs[b].arena = pool + (size_t)b * ph->arena_bytes;
+    jobs[b].arena = arena;
     jobs[b].in = ins[b].data();
+    if (guard) {      // the engine pads every input to a multiple of 64 bytes: that much may be read, not more
+      uint8_t* gin = emu::guard_alloc(ins[b].size(), 64, 0);
+      if (!ins[b].empty()) memcpy(gin, ins[b].data(), ins[b].size());
+      jobs[b].in = gin;
+    }
     jobs[b].out = outs[b].data();
     jobs[b].in_len = (uint32_t)ins[b].size();
     jobs[b].out_cap = out_cap;
@@ -146,7 +155,7 @@ int main(int argc, char** argv) {
            res[b].steps);
   }
   free(pool);
-  free(pipe);
+  if (!guard) free(pipe);
   zpq_plan_destroy(plan);
   return 0;
 }
