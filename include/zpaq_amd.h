@@ -100,6 +100,8 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * in the batch), mode 2 = mode 1 with 2048-byte steps (blocks of 128 KiB and more).  The plain calls give mode 0; the
  * _opts calls take the mode and, for tests, the chunk (bytes per step, 0 = the mode's own) and the group (blocks per
  * wavefront, 0 = 32). */
+/* The decoder with two blocks per wavefront (device/spec_dual_kernel.h): chains of up to 32 components. */
+int zpq_plan_spec_dual_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
 int zpq_plan_pipe_source_opts(const zpq_plan*, int mode, int chunk, int group, char* src, size_t cap, size_t* len, char key41[41]);

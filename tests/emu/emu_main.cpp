@@ -23,6 +23,10 @@ extern "C" void zpq_spec_encode(const zpq::BlockJob* jobs, zpq::BlockResult* res
                                 const zpq::DeviceTables* tb);
 extern "C" void zpq_spec_decode(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
                                 const zpq::DeviceTables* tb);
+#ifdef ZPQ_EMU_DUAL
+extern "C" void zpq_spec_decode2(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
+                                 const zpq::DeviceTables* tb);
+#endif
 
 namespace {
 
@@ -39,6 +43,7 @@ std::vector<uint8_t> slurp(const char* path) {
 
 struct Launch {
   bool dec;
+  bool dual;
   const zpq::BlockJob* jobs;
   zpq::BlockResult* res;
   unsigned nblocks;
@@ -47,6 +52,9 @@ struct Launch {
 
 void kernel_thunk(void* p) {
   Launch* l = (Launch*)p;
+#ifdef ZPQ_EMU_DUAL
+  if (l->dual) { zpq_spec_decode2(l->jobs, l->res, l->nblocks, l->tb); return; }
+#endif
   if (l->dec) zpq_spec_decode(l->jobs, l->res, l->nblocks, l->tb);
   else zpq_spec_encode(l->jobs, l->res, l->nblocks, l->tb);
 }
@@ -74,7 +82,8 @@ void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb
 
 int main(int argc, char** argv) {
   if (argc < 7) { fprintf(stderr, "usage: emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
-  const bool dec = !strcmp(argv[1], "dec");
+  const bool dual = !strcmp(argv[1], "dec2");      // two blocks per wavefront (spec_dual_kernel.h)
+  const bool dec = dual || !strcmp(argv[1], "dec");
   const unsigned waves = (unsigned)atoi(argv[2]);
   const std::vector<uint8_t> header = slurp(argv[3]);
   const uint32_t out_cap = (uint32_t)strtoul(argv[4], nullptr, 10);
@@ -102,8 +111,11 @@ int main(int argc, char** argv) {
   std::vector<zpq::BlockResult> res(njobs);
   // every block's arena and input between inaccessible pages (guard_alloc.h); ZPQ_EMU_GUARD=0: one contiguous arena pool
   // like the engine's, so that neighbouring blocks' arenas touch
-  const bool guard = emu::guard_on();
-  uint8_t* pool = guard ? nullptr : (uint8_t*)calloc((size_t)njobs, ph->arena_bytes);
+  // (the two-blocks-per-wavefront kernel addresses the second block's arena relative to the first's: back to back, as the
+  // engine lays them out; the pool as a whole sits between guard pages then)
+  const bool guard = emu::guard_on() && !dual;
+  uint8_t* pool = guard ? nullptr : (dual && emu::guard_on() ? emu::guard_alloc((size_t)njobs * ph->arena_bytes, 256, 0)
+                                                             : (uint8_t*)calloc((size_t)njobs, ph->arena_bytes));
   if (!guard && !pool) { fprintf(stderr, "arena pool: out of memory\n"); return 2; }
   for (unsigned b = 0; b < njobs; ++b) {
     if (b < nb) ins[b] = slurp(argv[6 + b]);
@@ -125,9 +137,9 @@ int main(int argc, char** argv) {
     jobs[b].res_slot = b;
     res[b] = zpq::BlockResult{0, 0, -1, 0};
   }
-  Launch l{dec, jobs.data(), res.data(), nb, &tb};
-  const unsigned per_wg = waves;      // blocks per workgroup
-  for (unsigned wg = 0; wg < (nb + per_wg - 1) / per_wg; ++wg) emu::run_workgroup(kernel_thunk, &l, 64 * waves, wg);
+  Launch l{dec, dual, jobs.data(), res.data(), nb, &tb};
+  const unsigned per_wg = dual ? 8 : waves;      // blocks per workgroup
+  for (unsigned wg = 0; wg < (nb + per_wg - 1) / per_wg; ++wg) emu::run_workgroup(kernel_thunk, &l, dual ? 256 : 64 * waves, wg);
   for (unsigned b = 0; b < nb; ++b) {
     // guard bytes past the capacity must be untouched
     for (unsigned k = 0; k < 64; ++k)
@@ -142,7 +154,7 @@ int main(int argc, char** argv) {
            res[b].steps);
   }
   printf("cross_lane_ops %lu\n", emu::cross_lane_ops());
-  free(pool);
+  if (!(dual && emu::guard_on())) free(pool);
   zpq_plan_destroy(plan);
   return 0;
 }

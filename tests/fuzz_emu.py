@@ -96,6 +96,16 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
             dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=waves, out_cap=max(len(x) for x in inputs))
             for i, (plain, status, consumed) in zip(inputs, dec):
                 assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
+            # the decoder with two blocks per wavefront (chains of up to 32 components whose MIX inputs fit a half)
+            try:
+                emu.dual_source(header)
+                has_dual = True
+            except RuntimeError:
+                has_dual = False
+            if has_dual:
+                dec2 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), dual=True)
+                for i, (plain, status, consumed) in zip(inputs, dec2):
+                    assert status == 0 and plain == i, ("dual decode", status, len(plain), len(i))
             for mode in ((1, 2) if big else (0, 1)):
                 out = emu.pipe_run(header, inputs, mode=mode, group=rng.choice([None, None, None, 8, 16]))
                 for w, (coded, status, _consumed), i in zip(want, out, inputs):

@@ -36,7 +36,7 @@ int zpq_device_count(void) { return engine_device_count(); }
 void zpq_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi) { engine_shard_range(n, parts ? parts : 1, k, lo, hi); }
 void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
 int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
-int zpq_set_kernel(int which) { if (which < 0 || which > 4) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
+int zpq_set_kernel(int which) { if (which < 0 || which > 5) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
 
 int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out) {
   ZPQ_TRY
@@ -57,6 +57,19 @@ int zpq_plan_spec_source(const zpq_plan* p, char* src, size_t cap, size_t* len, 
   std::string source, key, why;
   const int variant = spec_variant_forced() > 0 ? spec_variant_forced() : 0;   // ZPAQ_AMD_SPEC_WAVES selects the shape
   if (!spec_source_and_key(*p, variant, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (len) *len = source.size();
+  if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
+  if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
+  memcpy(src, source.c_str(), source.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+int zpq_plan_spec_dual_source(const zpq_plan* p, char* src, size_t cap, size_t* len, char key41[41]) {
+  ZPQ_TRY
+  if (!p) fail(ZPQ_E_ARG, "null plan");
+  std::string source, key, why;
+  if (!spec_source_and_key(*p, 2, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
   if (len) *len = source.size();
   if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
   if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");

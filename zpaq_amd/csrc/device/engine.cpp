@@ -327,7 +327,7 @@ void engine_plan_release(zpq_plan* p) {
   (void)hipGetDevice(&before);
   for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
     zpq_plan::OnDevice& od = p->dev[id];
-    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.pipe[2] && !od.spec[0] && !od.spec[1]) continue;
+    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.pipe[2] && !od.spec[0] && !od.spec[1] && !od.spec[2]) continue;
     if (hipSetDevice(g_engines[id].device >= 0 ? g_engines[id].device : id) != hipSuccess) continue;
     set_plan_device_index(id);
     if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
@@ -393,7 +393,7 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   // Each unseen header costs a hipRTC compile of several seconds.  A batch whose blocks all carry different
   // (data-dependent) chains must not spend minutes compiling: a few per call, the rest run on the
   // generic wave kernel this time and are picked up by later calls.
-  if (!decode && (want == 0 || want == 4)) {
+  if (!decode && (want == 0 || want == 4 || want == 5)) {      // (5 chooses among the decoders only)
     bool did = false;
     PipeKernel* k = pipe_kernel_for(p, mode, want == 4 || must_specialise || e.jit_left > 0, &did);
     if (did && e.jit_left > 0) --e.jit_left;
@@ -401,6 +401,15 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
     if (want == 4) fail(ZPQ_E_UNSUPPORTED, "pipelined encoder unavailable: " + p->cur().pipe_note);
   }
   const int forced = spec_variant_forced();
+  // Decoding a launch that fills the machine: two blocks per wavefront (device/spec_dual_kernel.h) where the chain allows
+  // it (up to 32 components, no block of several segments).  zpq_set_kernel(5) forces it, 3 keeps one block per wavefront.
+  if (decode && !must_specialise && forced < 0 && (want == 5 || (want == 0 && dense)) && p->cur().spec_state[2] >= 0) {
+    bool did = false;
+    SpecKernel* k = spec_kernel_for(p, 2, want == 5 || e.jit_left > 0, nullptr, &did);
+    if (did && e.jit_left > 0) --e.jit_left;
+    if (k) { r.kind = 3; r.spec = k; return r; }
+    if (want == 5) fail(ZPQ_E_UNSUPPORTED, "decoder with two blocks per wavefront unavailable: " + p->cur().spec_note);
+  }
   const int first = forced >= 0 ? forced : (dense ? 1 : 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1 && forced >= 0) break;                                     // a forced shape has no fallback
@@ -454,7 +463,8 @@ static hipError_t launch_spec(SpecKernel* k, bool decode, const BlockJob* d_jobs
                               const DeviceTables* d_tb, hipStream_t st) {
   void* args[4] = {(void*)&d_jobs, (void*)&d_res, (void*)&n, (void*)&d_tb};
   const uint32_t w = (uint32_t)k->waves;
-  return hipModuleLaunchKernel(decode ? k->decode : k->encode, (n + w - 1) / w, 1, 1, 64 * w, 1, 1, 0, st, args, nullptr);
+  if (!decode && !k->encode) return hipErrorInvalidDeviceFunction;
+  return hipModuleLaunchKernel(decode ? k->decode : k->encode, (n + w - 1) / w, 1, 1, (uint32_t)k->threads, 1, 1, 0, st, args, nullptr);
 }
 
 // The pipelined encoder: every step launches the six kernels of every pipe group on six streams (they are
@@ -723,9 +733,10 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
                               const std::map<const zpq_plan*, int>& mode_of) {
   const int want = e.kernel_choice;
   if (want == 1 || want == 2 || e.jit_left <= 1) return;
-  const bool pipe = !decode && (want == 0 || want == 4);
+  const bool pipe = !decode && (want == 0 || want == 4 || want == 5);
   const int forced = spec_variant_forced();
-  const int variant = forced >= 0 ? forced : (dense ? 1 : 0);
+  const bool dual = decode && forced < 0 && (want == 5 || (want == 0 && dense));     // as kernel_kind() will choose
+  const int variant = forced >= 0 ? forced : (dual ? 2 : (dense ? 1 : 0));
   std::vector<const zpq_plan*> unseen;
   std::vector<int> modes;
   const zpq_plan* last = nullptr;

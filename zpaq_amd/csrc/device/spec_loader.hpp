@@ -13,7 +13,8 @@ struct SpecKernel {
   hipModule_t module = nullptr;
   hipFunction_t encode = nullptr;
   hipFunction_t decode = nullptr;
-  int waves = 4;        // blocks per workgroup (the kernel's launch bound / 64)
+  int waves = 4;        // blocks per workgroup
+  int threads = 256;    // lanes per workgroup (64 per block; 32 per block for the decoder with two blocks per wavefront)
   std::string origin;   // "cache:<file>" or "hiprtc"
 };
 

@@ -185,7 +185,7 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with
 
 }  // namespace
 
-bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not) {
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, bool dual) {
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
@@ -193,13 +193,18 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   const CompDesc* comp = plan.comps();
   // LDS plan for the wave's region: H first, then ICM/ISSE side tables while they fit
   if (waves != 4 && waves != 8) { why_not = "unsupported workgroup shape"; return false; }
+  if (dual) {
+    if (waves != 8) { why_not = "two blocks per wavefront use the LDS plan of the 8-block shape"; return false; }
+    if (n > 32) { why_not = "more than 32 components"; return false; }
+    if (ph.arena_bytes >= (1ull << 31)) { why_not = "model state of 2 GiB or more per block"; return false; }
+  }
   const int wave_lds = spec_wave_lds_bytes(waves);          // LDS of ONE block
   int lds_used = 0, h_lds = -1;
   const int h_bytes = (int)(4u * (ph.hmask + 1));
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
-       "#include \"spec_kernel.h\"\n"
+       "#include \"" << (dual ? "spec_dual_kernel.h" : "spec_kernel.h") << "\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
   int nmix = 0, nsse = 0;
@@ -218,6 +223,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
     if (c.type == C_MIX) slot = nmix++;
     if (c.type == C_SSE) slot = nsse++;
     if (c.type == C_MIX && (c.a3 > 64 || c.a2 + c.a3 > 64)) { why_not = "MIX wider than a wavefront"; return false; }
+    if (dual && c.type == C_MIX && c.a2 + c.a3 > 32) { why_not = "MIX wider than half a wavefront"; return false; }
     comps << "    {" << c.type << "u," << c.a1 << "u," << c.a2 << "u," << c.a3 << "u," << c.a4 << "u," << c.a5 << "u, "
           << c.limit << "u," << c.mask0 << "u," << c.mask1 << "u, " << c.t0 << "ull," << c.t1 << "ull, " << lds << ","
           << slot << "," << c.stride << "u},\n";
@@ -234,6 +240,15 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   const U8* prog = plan.blob.data() + ph.off_prog;
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
   const char* body = "zpq::spec_kernel_body";
+  if (dual) {
+    o << "};\n"
+         "}  // namespace zpq_gen\n"
+         "extern \"C\" __global__ __launch_bounds__(256) void zpq_spec_decode2(const zpq::BlockJob* jobs, "
+         "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
+         "  zpq::spec_dual_decode_body<zpq_gen::Chain>(jobs, res, nblocks, tb);\n}\n";
+    source = o.str();
+    return true;
+  }
   o << "};\n"
        "}  // namespace zpq_gen\n"
        "extern \"C\" __global__ __launch_bounds__(64 * zpq_gen::Chain::WAVES) void zpq_spec_encode(const zpq::BlockJob* jobs, "

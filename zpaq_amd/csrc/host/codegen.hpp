@@ -15,7 +15,8 @@ static const int kCodegenVersion = 5;
 // untranslatable HCOMP): such plans run on the generic kernels.
 // `waves` = blocks per workgroup the kernel is laid out for (4: every side table that fits 30 KiB in LDS,
 // one workgroup per CU; 8: half the LDS per block, two wavefronts per SIMD)
-bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not);
+// dual: the decoder with two blocks per wavefront (device/spec_dual_kernel.h; chains of up to 32 components, waves = 8's LDS plan)
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, bool dual = false);
 
 // ---- pipelined encoder (device/pipe_kernel.h) ----
 // Dataflow plan of a chain: the level of every unit, the stream/state layout of one group of blocks and the
