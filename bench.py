@@ -238,7 +238,7 @@ def main():
                     help="blocks of the end-to-end API leg on host buffers (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
     ap.add_argument("--verify-bytes", type=int, default=32768)
-    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="zpq_set_kernel: 0 the engine's choice, 3 / 5 with --mode decode: one / two blocks per wavefront")
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
                     help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
     ap.add_argument("--distribute", dest="distribute", action="store_true", default=None,

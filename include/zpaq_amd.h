@@ -61,8 +61,10 @@ void zpq_shutdown(void);
 int zpq_set_state_budget(uint64_t bytes);
 /* Select the coding kernel: 0 = auto (best available for each plan: the pipelined encoder for compression, the
  * per-header specialised wavefront kernel for decompression), 1 = generic one-lane kernel, 2 = generic
- * wave-parallel kernel, 3 = per-header specialised wavefront kernel in both directions, 4 = pipelined encoder
- * (decompression as with 3).  3 and 4 fail with ZPQ_E_UNSUPPORTED when the kernel cannot be built. */
+ * wave-parallel kernel, 3 = per-header specialised wavefront kernel in both directions (one block per wavefront),
+ * 4 = pipelined encoder (decompression as with 3), 5 = the decoder with two blocks per wavefront (what 0 picks for a
+ * launch of more than 4 x CUs blocks whose chain has up to 32 components; compression as with 0).  3, 4 and 5 fail
+ * with ZPQ_E_UNSUPPORTED when the kernel cannot be built. */
 int zpq_set_kernel(int which);
 
 /* ---- model plan: a parsed block header + device arena layout ---- */

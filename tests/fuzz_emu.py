@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Random MODELS through the device code on the host: a random but valid ZPAQL config (1..8 components of every type with
 random sizes, inputs, rates and masks, a random HCOMP program) is assembled, and the kernels the engine would build for
-that header -- the per-header wavefront coder (encode and decode, spec_kernel.h) and the pipelined encoder in its shapes
-(pipe_kernel.h) -- are run by the wavefront emulator (tests/emu) on a few small blocks.  Every coded stream must be the
-oracle's, every decode must return the input.  No GPU; about 20 s of compilation per model.
+that header -- the per-header wavefront coder (encode and decode, spec_kernel.h), the decoder with two blocks per
+wavefront (spec_dual_kernel.h) and the pipelined encoder in its shapes (pipe_kernel.h) -- are run by the wavefront
+emulator (tests/emu) on a few small blocks.  Every coded stream must be the oracle's, every decode must return the input.  No GPU; about 20 s of compilation per model.
 
     python tests/fuzz_emu.py [models] [seed] [--big]      (--big: 9..24 components, the 8-block workgroup shape, the
                                                            latency shapes of the pipelined encoder)

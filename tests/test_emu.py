@@ -106,6 +106,52 @@ def test_decoder_contract_on_bad_and_partial_streams(zlib_, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# The decoder with two blocks per wavefront (zpaq_amd/csrc/device/spec_dual_kernel.h)
+
+def _dual_check(oracle, header, datas):
+    inputs = [b"\0" + bytes(d) for d in datas]
+    coded = [oracle.encode(header, i) for i in inputs]
+    dec = emu.run(header, [c + b"\0\0\0\0" for c in coded], decode=True, out_cap=max(len(x) for x in inputs), dual=True)
+    for inp, c, (plain, status, consumed) in zip(inputs, coded, dec):
+        assert status == 0 and plain == inp
+        assert consumed in (0, len(c) + 4)        # 0: the block filled the capacity exactly and stopped before the marker
+
+
+@pytest.mark.parametrize("method", ["5", DEEP_ISSE])
+def test_two_blocks_per_wavefront_decoder(zlib_, oracle, method):
+    """Standard chains, the chain whose side tables do not fit the LDS, ragged lengths, an empty block, an odd number of
+    blocks (the last wavefront has one block only) and more than one workgroup."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header = zlib_.method_to_header(method if method.startswith("x") else zlib_.expand_method(method, blk))[0]
+    _dual_check(oracle, header, _ragged(600) + [corpus.block("text", n, n).tobytes() for n in (1, 64, 333, 600)])
+
+
+def test_two_blocks_per_wavefront_decoder_on_every_component_type(zlib_, oracle, golden):
+    for e in [golden["config_cases"][0]] + golden["level_cases"][1:] + golden["vm_cases"][:1]:
+        header = bytes.fromhex(e["header"])
+        if header[6] > 32:
+            continue
+        d = gen_input(e).tobytes()[:1200]
+        _dual_check(oracle, header, [d, d[:700], d[:1]])
+
+
+def test_two_blocks_per_wavefront_decoder_contract_on_bad_streams(zlib_, oracle):
+    """The same answers as the one-block kernel gives on a truncated stream, on garbage and on a capacity below the block."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    d = b"\0" + corpus.block("text", 1500, 77).tobytes()
+    c = oracle.encode(header, d)
+    good = c + b"\0\0\0\0"
+    garbage = np.random.default_rng(5).integers(0, 256, 400, dtype=np.uint8).tobytes()
+    streams = [c[:len(c) // 2], good, garbage, good]
+    one = emu.run(header, streams, decode=True, waves=8, out_cap=len(d) + 8)
+    two = emu.run(header, streams, decode=True, out_cap=len(d) + 8, dual=True)
+    assert one == two
+    assert two[1][1] == 0 and two[1][0] == d and two[1][2] == len(c) + 4
+    assert emu.run(header, [good], decode=True, out_cap=701, dual=True) == emu.run(header, [good], decode=True, waves=8, out_cap=701)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # The pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h): the same generated source the GPU runs, executed
 # step by step on the host with consumers launched BEFORE producers inside a step (tests/emu/pipe_emu_main.cpp).
 

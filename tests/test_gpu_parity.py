@@ -364,6 +364,37 @@ def test_large_batch_picks_its_own_kernels(gpu, oracle):
     assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)
 
 
+def test_two_blocks_per_wavefront_decoder(gpu, golden):
+    """device/spec_dual_kernel.h, which a dense decode launch takes by itself: forced here (zpq_set_kernel(5)) on every
+    golden archive whose chain it accepts (the reference wrote them; zpq_decompress checks their SHA-1 trailers) and on a
+    batch that has an odd number of blocks, an empty one and a one-byte one -- the same bytes as the one-block kernel (3)
+    and the engine's own choice return."""
+    tried = 0
+    gpu.set_kernel(5)
+    try:
+        for sect in ("config_cases", "level_cases", "vm_cases", "method_cases"):
+            for e in golden[sect]:
+                hdr = bytes.fromhex(e["header"])
+                if "archive_b64" not in e or hdr[6] == 0 or hdr[6] > 32:
+                    continue
+                want = gen_input(e).tobytes()
+                assert gpu.decompress(b64(e), cap=len(want) + 64) == want, (sect, e.get("name") or e.get("method"))
+                tried += 1
+    finally:
+        gpu.set_kernel(0)
+    assert tried >= 40
+    blocks = [corpus.block("text", 20000 + 77 * i, 300 + i).tobytes() for i in range(9)] + [b"", b"x"]
+    arch = b"".join(gpu.compress_blocks(blocks, "5"))
+    outs = []
+    for kernel in (5, 3, 0):
+        gpu.set_kernel(kernel)
+        try:
+            outs.append(gpu.decompress(arch))
+        finally:
+            gpu.set_kernel(0)
+    assert outs[0] == outs[1] == outs[2] == b"".join(blocks)
+
+
 def test_4_mib_zeros_known_answer(gpu):
     """4 MiB zeros, method 5 -> 410 B (175 MiB of model state per block)."""
     a, = gpu.compress_blocks([np.zeros(4 << 20, np.uint8)], "5")
