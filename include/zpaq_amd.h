@@ -119,6 +119,7 @@ int zpq_pcomp_is_translated(const uint8_t* code, size_t codelen, int ph, int pm)
 /* Runs only the hipRTC compilation of that source (needs no GPU; nothing is loaded or cached):
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
+size_t zpq_plan_spec_dual_jit(const zpq_plan*, char* log, size_t cap);      /* the decoder with two blocks per wavefront */
 /* Headers nobody prebuilt (level-5 chains whose periodic models depend on the data): compile the kernels of `n` plans
  * with hipRTC on up to `threads` host threads at once (0 = as many as the process may use, at most 16) -- the pipelined
  * encoder when decode == 0, the wavefront kernel otherwise -- into the code-object cache.  The engine does the same at

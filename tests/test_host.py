@@ -567,3 +567,17 @@ def test_random_pcomp_programs_three_ways(zlib_, ref):
     (1500 programs of seed 2 were run when this was added.)"""
     import fuzz_pcomp
     assert fuzz_pcomp.run(25, 20260926, verbose=False) == 0
+
+
+def test_two_blocks_per_wavefront_decoder_compiles_with_hiprtc(zlib_):
+    """A chain nobody prebuilt (method 5 on records: periodic models that depend on the data, 29 components) through the
+    run-time compiler the engine would use for it (no GPU needed)."""
+    import ctypes as C
+    L = zlib_.lib()
+    L.zpq_plan_spec_dual_jit.restype = C.c_size_t
+    L.zpq_plan_spec_dual_jit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    h = zlib_.method_to_header(zlib_.expand_method("5", corpus.block("records", 1 << 20, 3)))[0]
+    p = zlib_.Plan(h)
+    log = C.create_string_buffer(8192)
+    assert 20 < p.ncomp <= 32
+    assert L.zpq_plan_spec_dual_jit(p._h, log, 8192) > 10000, log.value.decode()[:2000]

@@ -105,6 +105,18 @@ size_t zpq_plan_spec_jit(const zpq_plan* p, char* log, size_t cap) {
   }
 }
 
+size_t zpq_plan_spec_dual_jit(const zpq_plan* p, char* log, size_t cap) {
+  try {
+    std::string l;
+    const size_t n = p ? spec_jit_compile_only(*p, 2, l) : 0;
+    if (log && cap) { strncpy(log, l.c_str(), cap - 1); log[cap - 1] = 0; }
+    return n;
+  } catch (const std::exception& ex) {
+    if (log && cap) { strncpy(log, ex.what(), cap - 1); log[cap - 1] = 0; }
+    return 0;
+  }
+}
+
 int zpq_pcomp_is_translated(const uint8_t* code, size_t codelen, int ph, int pm) {
   return code && pcomp_is_translated(code, codelen, ph, pm) ? 1 : 0;
 }
