@@ -506,6 +506,8 @@ def main():
     kname = {4: "zpq_pipe_{hcomp,rows,light,icm,isse,mix}: one launch of each per step, concurrent",
              3: "zpq_spec_" + ("decode" if dec else "encode"), 2: "code_wave_kernel", 1: "code_serial_kernel"}.get(kinds[-1], "?")
     origin = note.value.decode(errors="replace")
+    if dec and "zpq_spec_decode2" in origin:
+        kname = "zpq_spec_decode2 (two blocks per wavefront)"
     # HBM traffic per launch from the committed rocprofv3 PMC passes -- only when THIS workload was profiled with THIS
     # code object (the cache key is part of kernel_origin); a stale entry is refused
     traffic = None

@@ -432,7 +432,9 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_
   bind_device(e);
   e.jit_left = jit_budget();
   const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes, pipe_stream_bytes_per_byte(p)));
-  note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
+  // (the note of the kernel that was PICKED: the plan's spec_note is the note of whichever shape was loaded last)
+  if (k.kind == 3 && k.spec) note = k.spec->origin + (k.spec->encode ? "" : " (zpq_spec_decode2: two blocks per wavefront)");
+  else note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
 
