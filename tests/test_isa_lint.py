@@ -71,3 +71,33 @@ def test_m5_kernel_properties(zlib_, tmp_path, waves):
     start = next(i for i, l in enumerate(enc) if "Loop Header: Depth=1" in l and i > len(enc) // 4)
     loop = [l for l in enc[start:] if re.match(r"^\t[a-z_0-9]+(\s|$)", l)]
     assert 3000 < len(loop) < 4600, len(loop)
+
+
+def test_m5_two_blocks_per_wavefront_decoder_properties(zlib_, tmp_path):
+    """device/spec_dual_kernel.h: one workgroup of four wavefronts per CU (the LDS is full), so up to 512 registers per
+    lane would do -- what matters is no scratch, no flat accesses, and that the byte loop serves TWO blocks with about the
+    instructions the one-block kernel needs for one (4 495 against 4 329 when this was written: DESIGN.md section 4.2)."""
+    from zpaq_amd import corpus, prebuild
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    src, _ = prebuild.dual_source_and_key(header)
+    d = tmp_path / "dual"
+    d.mkdir()
+    (d / "k.hip").write_text(src)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-mllvm",
+                    "-simplifycfg-sink-common=false", "-I", os.path.join(ROOT, "zpaq_amd", "csrc", "device"), "--genco",
+                    "k.hip", "-o", "k.hsaco", "-save-temps"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asm = (d / "k-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    shutil.rmtree(d)
+    ks = _kernels(asm)
+    assert set(ks) == {"zpq_spec_decode2"}
+    k = ks["zpq_spec_decode2"]
+    assert k["private_segment_fixed_size"] == 0 and k["group_segment_fixed_size"] <= 160 * 1024
+    assert k["max_flat_workgroup_size"] == 256 and k["vgpr_count"] <= 256
+    code = [l.split()[0] for l in asm.split("\n") if re.match(r"^\t[a-z_0-9]+(\s|$)", l)]
+    assert not [op for op in code if op.startswith(("flat_", "scratch_"))]
+    body = asm[asm.index("zpq_spec_decode2:"):]
+    body = body[:body.index("s_endpgm")].split("\n")
+    start = next(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and i > len(body) // 5)
+    loop = [l for l in body[start:] if re.match(r"^\t[a-z_0-9]+(\s|$)", l)]
+    assert 3500 < len(loop) < 5200, len(loop)
