@@ -266,9 +266,10 @@ def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
 
 
 def test_random_models_through_both_coders(zlib_, oracle):
-    """tests/fuzz_emu.py, three models: random components of every type with random parameters and a random HCOMP program,
-    through the per-header wavefront coder (both ways) and the pipelined encoder (both shapes), against the oracle.
+    """tests/fuzz_emu.py, two models: random components of every type with random parameters and a random HCOMP program,
+    through the per-header wavefront coder (both ways), the decoder with two blocks per wavefront and the pipelined encoder
+    (both shapes), against the oracle.
     (240 models of seeds 2 and 3 were run when this was added: no mismatch.)"""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_emu
-    assert fuzz_emu.run(3, 20260926, verbose=False) == 0
+    assert fuzz_emu.run(2, 20260926, verbose=False) == 0

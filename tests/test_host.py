@@ -541,7 +541,7 @@ def test_host_paths_agree_with_the_reference_on_random_and_damaged_inputs(zlib_,
     strings give the same header and PCOMP, damaged archives that the reference decodes decode to the same bytes (the
     documented differences: SHA-1 trailers are verified here, pre-processor types > 7 are refused here)."""
     import fuzz_host
-    st = fuzz_host.run(1600, 7, ref=ref)
+    st = fuzz_host.run(900, 7, ref=ref)
     assert st["differences"] == [], st["differences"][:3]
     assert st.get("ref_decoded", 0) > 0
 
