@@ -167,10 +167,7 @@ int jit_budget() {
   return 64;
 }
 int jit_threads() {
-  unsigned hw = std::thread::hardware_concurrency();
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw ? hw : 1, (unsigned)CPU_COUNT(&set));
-  return (int)std::max(1u, std::min(hw, 16u));
+  return (int)std::max(1u, std::min(usable_cpus(), 16u));
 }
 
 void engine_init_device(Engine& e, int slot, int device);

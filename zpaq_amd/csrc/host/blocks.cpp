@@ -8,6 +8,8 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -19,6 +21,40 @@
 #include "container.hpp"
 
 namespace zpq {
+
+// nproc says what the machine has, not what this process gets: the affinity mask, and the CPU quota of the cgroup
+// (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- a container with 16 CPUs of quota on a
+// 256-thread host runs 16 threads at full speed and is throttled with more.
+unsigned usable_cpus() {
+  static const unsigned cached = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!hw) hw = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw, (unsigned)std::max(1, CPU_COUNT(&set)));
+    auto read_two = [](const char* path, double& a, double& b) -> int {
+      FILE* f = fopen(path, "r");
+      if (!f) return 0;
+      char x[64] = {0}, y[64] = {0};
+      const int got = fscanf(f, "%63s %63s", x, y);
+      fclose(f);
+      if (got >= 1 && strcmp(x, "max") == 0) return -1;          // no quota
+      a = atof(x);
+      b = got >= 2 ? atof(y) : 0;
+      return got;
+    };
+    double q = 0, p = 0;
+    int r = read_two("/sys/fs/cgroup/cpu.max", q, p);
+    if (r == 0) {
+      double q1 = 0, p1 = 0, unused = 0;
+      if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, unused) >= 1 && read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, unused) >= 1) {
+        q = q1; p = p1; r = 2;
+      }
+    }
+    if (r >= 2 && q > 0 && p > 0) hw = std::min<unsigned>(hw, (unsigned)std::max(1.0, q / p + 0.5));
+    return hw;
+  }();
+  return cached;
+}
 
 namespace {
 
@@ -122,9 +158,7 @@ void encode_jobs(std::vector<EncJob>& jobs, bool* announced = nullptr) {
 // block: spread it over the host cores the process may use, like zpaq.cpp's compressThread pool.
 template <class F>
 void parallel_blocks(size_t n, F&& fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = std::min<unsigned>(hw ? hw : 1, (unsigned)CPU_COUNT(&set));
+  const unsigned hw = usable_cpus();
   const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 32), n / 4));
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   std::atomic<size_t> next(0);

@@ -28,6 +28,7 @@ void set_last_error(const std::string& s);
 // ---- sha1.cpp ----
 void sha1_compress(U32 h[5], const U8* block64);   // one 64-byte block
 void postproc_set_step_limit(U64 steps);             // ZPAQL steps one call of a custom PCOMP program may take (0: 2^34)
+unsigned usable_cpus();                             // host CPUs this process may really use: affinity mask and cgroup CPU quota
 void sha1_force_portable(bool yes);                 // tests: the portable compression function instead of the SHA extensions
 class Sha1 {
  public:
