@@ -182,6 +182,8 @@ def run(iterations: int, seed: int, verbose: bool = False, ref=None) -> dict:
                 ex = ex_
                 mine = "error"
                 stats["rejected"] += 1
+                if "too big" in str(ex):
+                    mine = None                       # hh > 24 / hm > 28: this library's documented limit
                 if "checksum mismatch" in str(ex):
                     mine = "checksum"                 # zpq_decompress verifies the SHA-1 trailers, libzpaq::decompress discards them
                 if "[NODEVICE]" in str(ex) or "[DEVICE]" in str(ex):

@@ -581,3 +581,15 @@ def test_two_blocks_per_wavefront_decoder_compiles_with_hiprtc(zlib_):
     log = C.create_string_buffer(8192)
     assert 20 < p.ncomp <= 32
     assert L.zpq_plan_spec_dual_jit(p._h, log, 8192) > 10000, log.value.decode()[:2000]
+
+
+def test_two_swaps_in_a_row_follow_the_interpreter(zlib_, ref):
+    """Found by tests/fuzz_pcomp.py: the reference's x86 JIT runs "b<>a b<>a" as ONE swap, its own interpreter (-DNOJIT, the
+    ZPAQ specification: ZPAQL::run, libzpaq.cpp:1027-1262) as two.  This library -- host interpreter and the translator
+    that serves the device -- follows the interpreter."""
+    from oracle.oracle_py import Ref
+    interp = Ref(nojit=True)
+    cfg = "comp 0 0 5 6 0 hcomp halt pcomp prog ; b<>a b<>a out halt end"
+    a = ref.compress_config(b"ABCDEFG", cfg, None, "f", None, False)
+    assert interp.decompress(a, 100) == b"ABCDEFG\xff"
+    assert zlib_.decompress(a) == b"ABCDEFG\xff"
