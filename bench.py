@@ -56,22 +56,32 @@ def _gen_block(args):
     return corpus.block(kind, nbytes, seed)
 
 
-def make_corpus(kind, nblocks, block_bytes, first):
+def make_corpus(kind, nblocks, block_bytes, first, dev=None):
     """[nblocks, block_bytes] uint8, block b = corpus.block(kind, block_bytes, 12345 + first + b);
-    kind "mixed" = BASELINE configs[3]: text, text, LCG-random, records by (first + b) mod 4."""
+    kind "mixed" = BASELINE configs[3]: text, text, LCG-random, records by (first + b) mod 4.  With a torch device the
+    text blocks (minutes of numpy on a few host cores) are generated there, bit-identical (corpus_torch)."""
     from zpaq_amd import corpus
     mix = ["text", "text", "lcg", "records"]
-    jobs = [(mix[(first + b) % 4] if kind == "mixed" else kind, block_bytes, corpus.BASE_SEED + first + b)
-            for b in range(nblocks)]
+    kinds = [mix[(first + b) % 4] if kind == "mixed" else kind for b in range(nblocks)]
     out = np.empty((nblocks, block_bytes), np.uint8)
-    nproc = min(len(jobs), os.cpu_count() or 1, 64)
-    if nproc > 1 and nblocks * block_bytes >= (8 << 20):
+    on_dev = [b for b in range(nblocks) if kinds[b] == "text"] if dev is not None else []
+    if on_dev:
+        from zpaq_amd import corpus_torch
+        for i0 in range(0, len(on_dev), 256):
+            idx = on_dev[i0:i0 + 256]
+            t = corpus_torch.text_blocks(len(idx), block_bytes, 0, dev, seeds=[corpus.BASE_SEED + first + b for b in idx])
+            out[idx] = t.cpu().numpy()
+            del t
+    jobs = [(kinds[b], block_bytes, corpus.BASE_SEED + first + b) for b in range(nblocks) if b not in set(on_dev)]
+    rest = [b for b in range(nblocks) if b not in set(on_dev)]
+    nproc = min(max(len(jobs), 1), usable_cores(), 64)
+    if nproc > 1 and len(jobs) * block_bytes >= (8 << 20):
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:
-            for b, blk in enumerate(pool.imap(_gen_block, jobs, chunksize=max(1, len(jobs) // (nproc * 4)))):
+            for b, blk in zip(rest, pool.imap(_gen_block, jobs, chunksize=max(1, len(jobs) // (nproc * 4)))):
                 out[b] = blk
     else:
-        for b, j in enumerate(jobs):
+        for b, j in zip(rest, jobs):
             out[b] = _gen_block(j)
     return out
 
@@ -187,7 +197,7 @@ def in_library_bench(a, torch, z):
             host[b0:b0 + k] = corpus_torch.text_blocks(k, bs, corpus.BASE_SEED + b0, dev0).cpu().numpy()
         torch.cuda.empty_cache()
     else:
-        host = make_corpus(a.kind, total_blocks, bs, first=0)
+        host = make_corpus(a.kind, total_blocks, bs, first=0, dev=dev0)
     rows = [host[i] for i in range(total_blocks)]
     for _ in range(a.warmup):
         z.compress_blocks(rows, a.method)
@@ -230,7 +240,9 @@ def main():
                          "2048 with --mode decode: configs[4] decodes the 8192-block archive of the 8-GPU run on ONE GPU, "
                          "which holds 2048 blocks of model state at a time -- one such residency wave is a step")
     ap.add_argument("--block-bytes", type=int, default=1 << 20)
-    ap.add_argument("--kind", default="text", help="text | lcg | zeros | records | pattern | mixed (configs[3])")
+    ap.add_argument("--kind", default=None,
+                    help="text | lcg | zeros | records | pattern | mixed; default: text on one GPU (BASELINE configs[2]), "
+                         "mixed on several (configs[3]: text, text, LCG, records by block index mod 4)")
     ap.add_argument("--method", default="5")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the cpu_baseline leg (0 = skip)")
@@ -239,6 +251,9 @@ def main():
     ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
     ap.add_argument("--verify-bytes", type=int, default=32768)
     ap.add_argument("--kernel", type=int, default=0, help="zpq_set_kernel: 0 the engine's choice, 3 / 5 with --mode decode: one / two blocks per wavefront")
+    ap.add_argument("--decode-blocks", type=int, default=2048,
+                    help="blocks of the `decode` leg of an encode run on one GPU (BASELINE configs[4]'s operating point: one "
+                         "residency wave of the 8192-block archive = 2048 x 1 MiB), outside the timed region; 0 = skip")
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
                     help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
     ap.add_argument("--distribute", dest="distribute", action="store_true", default=None,
@@ -252,6 +267,8 @@ def main():
     a = ap.parse_args()
     if a.blocks is None:
         a.blocks = 2048 if a.mode == "decode" else 1024
+    if a.kind is None:
+        a.kind = "text" if a.gpus == 1 else "mixed"
 
     import torch
 
@@ -308,7 +325,7 @@ def main():
             from zpaq_amd import corpus, corpus_torch
             full = corpus_torch.text_blocks(total_blocks, bs, corpus.BASE_SEED, dev)
         elif rank == 0:
-            full = make_corpus(a.kind, total_blocks, bs, first=0)
+            full = make_corpus(a.kind, total_blocks, bs, first=0, dev=dev)
         zd.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
         mine = zd.scatter_blocks(full, total_blocks, bs)
         torch.cuda.synchronize(); zd.barrier()
@@ -326,7 +343,7 @@ def main():
         del d_blocks
         torch.cuda.empty_cache()
     else:
-        blocks = make_corpus(a.kind, nb, bs, first=first)
+        blocks = make_corpus(a.kind, nb, bs, first=first, dev=dev)
 
     # What the coder sees per block: the PP header (0, or 1 + the PCOMP program of a pre-processing method) followed by
     # the block -- or by its LZ77 / BWT stream, made on the host like compressBlock does (host/preproc.cpp).  One plan
@@ -334,27 +351,31 @@ def main():
     L = z.lib()
     L.zpq_preprocess_block.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 
-    def coder_input(b):
-        xm = z.expand_method(a.method, blocks[b])
-        h, pc, _ = z.method_to_header(xm)
-        pp = (b"\x01" + pc) if pc else b"\x00"
-        m = re.match(r"[xs](\d+)[,.](\d+)", xm)          # args[1]: 0 = the block itself is coded
-        if m and int(m.group(2)) != 0:
-            buf = np.array(blocks[b], dtype=np.uint8, copy=True)
-            out = np.empty(buf.size + buf.size // 2 + 4096, np.uint8)
-            ln = C.c_size_t(0)
-            if L.zpq_preprocess_block(xm.encode(), buf.ctypes.data, buf.size, out.ctypes.data, out.size, C.byref(ln)):
-                raise RuntimeError(L.zpq_last_error().decode())
-            return h, pp, out[:ln.value]
-        return h, pp, blocks[b]
-
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(32, usable_cores())) as ex:
-        prepared = list(ex.map(coder_input, range(nb)))
+
+    def coder_input_of(arr):
+        def one(b):
+            xm = z.expand_method(a.method, arr[b])
+            h, pc, _ = z.method_to_header(xm)
+            pp = (b"\x01" + pc) if pc else b"\x00"
+            m = re.match(r"[xs](\d+)[,.](\d+)", xm)
+            if m and int(m.group(2)) != 0:
+                buf = np.array(arr[b], dtype=np.uint8, copy=True)
+                out = np.empty(buf.size + buf.size // 2 + 4096, np.uint8)
+                ln = C.c_size_t(0)
+                if L.zpq_preprocess_block(xm.encode(), buf.ctypes.data, buf.size, out.ctypes.data, out.size, C.byref(ln)):
+                    raise RuntimeError(L.zpq_last_error().decode())
+                return h, pp, out[:ln.value]
+            return h, pp, arr[b]
+        with ThreadPoolExecutor(max_workers=min(32, usable_cores())) as ex:
+            return list(ex.map(one, range(len(arr))))
+
+    prepared = coder_input_of(blocks)
     headers = {}
     for b, (h, pp, stream) in enumerate(prepared):
         headers.setdefault(h, []).append(b)
-    groups = [(z.Plan(h), idx) for h, idx in headers.items()]
+    plan_cache = {h: z.Plan(h) for h in headers}
+    groups = [(plan_cache[h], idx) for h, idx in headers.items()]
     in_len = [len(pp) + len(stream) for _, pp, stream in prepared]
     algo_bytes = sum(pl.algo_bytes_per_byte * sum(in_len[i] for i in idx) for pl, idx in groups)
     state_bytes = sum(pl.state_bytes * len(idx) for pl, idx in groups)
@@ -363,10 +384,15 @@ def main():
     stride_in = (max(in_len) + 255) // 256 * 256
     cap = max(in_len) + max(in_len) // 4 + 4096
     stride_out = (cap + 255) // 256 * 256
-    host_in = np.zeros((nb, stride_in), np.uint8)
-    for b, (_, pp, stream) in enumerate(prepared):
-        host_in[b, :len(pp)] = np.frombuffer(pp, np.uint8)
-        host_in[b, len(pp):in_len[b]] = stream
+
+    def rows_of(prep, stride):
+        host = np.zeros((len(prep), stride), np.uint8)
+        for b, (_, pp, stream) in enumerate(prep):
+            host[b, :len(pp)] = np.frombuffer(pp, np.uint8)
+            host[b, len(pp):len(pp) + len(stream)] = stream
+        return host
+
+    host_in = rows_of(prepared, stride_in)
     del prepared
     d_in = torch.from_numpy(host_in).to(dev)
     del host_in
@@ -401,6 +427,98 @@ def main():
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
+
+
+    def decode_leg(nd):
+        """BASELINE configs[4] beside the headline: Decoder::decompress (libzpaq.cpp:2104-2155) over nd blocks of the same
+        corpus in ONE launch -- the nb coded payloads of the timed run plus nd - nb more blocks coded here --, every decoded
+        byte compared with the coder's input on the device; its own roofline and the reference's Decompresser beside it."""
+        extra = max(nd - nb, 0)
+        nd = nb + extra if extra else min(nd, nb)
+        ins, lens_in, plans = [d_in[:nd]], list(in_len[:nd]), list(plan_of[:nd])
+        codes, lens_out = [d_out[:nd]], [int(x) for x in out_len[:nd]]
+        if extra:
+            from zpaq_amd import corpus, corpus_torch
+            if a.kind == "text":
+                more = corpus_torch.text_blocks(extra, bs, corpus.BASE_SEED + first + nb, dev).cpu().numpy()
+            else:
+                more = make_corpus(a.kind, extra, bs, first=first + nb, dev=dev)
+            prep = coder_input_of(more)
+            del more
+            for h, _, _ in prep:
+                if h not in plan_cache:
+                    plan_cache[h] = z.Plan(h)
+            lens2 = [len(pp) + len(st) for _, pp, st in prep]
+            if max(lens2) > stride_in - 8:
+                return {"skipped": "a block of the second batch is longer than the first batch's row stride"}
+            pl2 = [plan_cache[h] for h, _, _ in prep]
+            d_in2 = torch.from_numpy(rows_of(prep, stride_in)).to(dev)
+            del prep
+            d_out2 = torch.empty((extra, stride_out), dtype=torch.uint8, device=dev)
+            r1 = torch.zeros((extra, 4), dtype=torch.int32, device=dev)
+            rc = L.zpq_code_device_multi(0, (C.c_void_p * extra)(*[p._h for p in pl2]), C.c_void_p(d_in2.data_ptr()),
+                                         (C.c_uint64 * extra)(*[i * stride_in for i in range(extra)]), (C.c_uint32 * extra)(*lens2),
+                                         extra, C.c_void_p(d_out2.data_ptr()), (C.c_uint64 * extra)(*[i * stride_out for i in range(extra)]),
+                                         (C.c_uint32 * extra)(*[cap] * extra), C.c_void_p(r1.data_ptr()), None, 1)
+            if rc:
+                raise RuntimeError(L.zpq_last_error().decode())
+            r1h = r1.cpu().numpy()
+            if not (r1h[:, 2] == 0).all():
+                return {"skipped": "coding the second batch failed"}
+            ins.append(d_in2); codes.append(d_out2)
+            lens_in += lens2; plans += pl2; lens_out += [int(x) for x in r1h[:, 0]]
+        src = torch.cat(ins) if len(ins) > 1 else ins[0]
+        code = torch.cat(codes) if len(codes) > 1 else codes[0].clone()
+        del ins, codes
+        # the container's 4-zero terminator behind every coded payload
+        lt = torch.tensor(lens_out, dtype=torch.int64, device=dev)
+        code.scatter_(1, torch.arange(4, device=dev)[None, :] + lt[:, None], torch.zeros((nd, 4), dtype=torch.uint8, device=dev))
+        back = torch.empty((nd, stride_in), dtype=torch.uint8, device=dev)
+        r2 = torch.zeros((nd, 4), dtype=torch.int32, device=dev)
+        args = ((C.c_void_p * nd)(*[p._h for p in plans]), C.c_void_p(code.data_ptr()),
+                (C.c_uint64 * nd)(*[i * stride_out for i in range(nd)]), (C.c_uint32 * nd)(*[n + 4 for n in lens_out]), nd,
+                C.c_void_p(back.data_ptr()), (C.c_uint64 * nd)(*[i * stride_in for i in range(nd)]),
+                (C.c_uint32 * nd)(*[n + 8 for n in lens_in]), C.c_void_p(r2.data_ptr()), None, 1)
+        torch.cuda.synchronize()
+        td0 = time.perf_counter()
+        rc = L.zpq_code_device_multi(1, *args)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - td0
+        if rc:
+            raise RuntimeError(L.zpq_last_error().decode())
+        tm = z.last_timing()
+        r2h = r2.cpu().numpy()
+        good = bool((r2h[:, 2] == 0).all() and (r2h[:, 0] == np.array(lens_in)).all())
+        cols = torch.arange(stride_in, device=dev)[None, :] < torch.tensor(lens_in, device=dev)[:, None]
+        good = good and bool(((back == src) | ~cols).all())
+        del back, code, src
+        torch.cuda.empty_cache()
+        algo = float(sum(p.algo_bytes_per_byte * n for p, n in zip(plans, lens_in)))
+        code_s = tm[1] / 1e3
+        note2 = C.create_string_buffer(512)
+        kk = sorted({int(L.zpq_plan_kernel_kind4(p._h, 1, nd, max(lens_in), note2, 512)) for p in set(plans)})
+        org = note2.value.decode(errors="replace")
+        kn = "zpq_spec_decode"
+        for tag, nm in (("zpq_spec_decode3", "zpq_spec_decode3 (row / mixer wavefronts, blocks of a workgroup in lockstep)"),
+                        ("zpq_spec_decode2", "zpq_spec_decode2 (two blocks per wavefront)")):
+            if tag in org:
+                kn = nm
+                break
+        obj = {"metric": f"decompress MB/s, -m{a.method} over {nd}x{_size_name(bs)} blocks (BASELINE configs[4]: one residency "
+                         f"wave of the 8-GPU archive on one GPU)",
+               "value": float(nd) * bs / 1e6 / wall, "unit": "MB/s", "blocks": nd, "block_bytes": bs, "corpus": a.kind,
+               "ms": {"wall": wall * 1e3, "init_arena": tm[0], "code": tm[1]},
+               "every_byte_verified": good,
+               "roofline": {"bound": "hbm", "achieved": algo / 1e9 / code_s if code_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (algo / 1e9 / code_s / HBM_PEAK_GBS) if code_s > 0 else 0.0, "traffic": None,
+                            "kernel": kn, "kernel_kind": kk, "kernel_origin": org,
+                            "algo_bytes_per_launch": algo, "kernel_s_per_launch": code_s},
+               "cpu_baseline": None}
+        if a.cpu_seconds > 0:
+            base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
+            obj["cpu_baseline"] = base
+            obj["vs_cpu"] = obj["value"] / base["value"] if base and base["value"] else None
+        return obj
 
     for _ in range(a.warmup):
         step()
@@ -541,6 +659,17 @@ def main():
     value = total_bytes / 1e6 / elapsed
     code_s = code_ms / 1e3 / max(a.steps, 1)          # coding time per step (this rank)
     achieved = algo_bytes / 1e9 / code_s if code_s > 0 else 0.0
+    # which BASELINE.json configuration this run is, said only when it really is that one
+    std = a.method == "5" and bs == (1 << 20) and nb == 1024 and a.scaling == "weak"
+    which_config = ""
+    if std and world == 1 and a.kind == "text" and a.mode == "encode":
+        which_config = " = BASELINE configs[2]"
+    elif std and world == 8 and a.kind == "mixed" and a.mode == "encode":
+        which_config = " = BASELINE configs[3]"
+    elif std and world > 1 and a.kind == "mixed" and a.mode == "encode":
+        which_config = f" = BASELINE configs[3]'s corpus and per-GPU load on {world} of its 8 GPUs"
+    elif a.mode == "decode" and a.method == "5" and bs == (1 << 20) and nb == 2048 and world == 1:
+        which_config = " = one residency wave of BASELINE configs[4]"
     line = {
         # BASELINE.json's metric, spelled with the method / batch shape of THIS run (the default is its -m5, 1024 x 1 MiB)
         "metric": ("compress" if a.mode == "encode" else "decompress") +
@@ -548,13 +677,14 @@ def main():
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"method \"{a.method}\" x {nb} blocks x {bs} B '{a.kind}' per GPU, {total_blocks} in total "
-                               f"(BASELINE configs[2] when 1024 x 1 MiB text on one GPU; configs[3] when 'mixed' on 8 GPUs)",
+        "config": {"workload": f"method \"{a.method}\" x {nb} blocks x {bs} B '{a.kind}' per GPU, {total_blocks} in total" + which_config,
                    "blocks_per_gpu": nb, "blocks_total": total_blocks, "block_bytes": bs, "corpus": a.kind,
                    "method": a.method, "plans": len(groups), "ncomp": [g[0].ncomp for g in groups],
                    "parallelism": f"blocks/{world}gpu", "state_GiB_per_gpu": state_bytes / 2 ** 30,
                    # code-generation / engine knobs in force (none = the product's defaults)
                    "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ZPAQ_AMD_")}},
+        "value_is": "coding throughput with the inputs resident in HBM when the timed region starts (the bench contract); "
+                    "api.value is SURVEY 8(d)'s end-to-end figure through zpq_compress_blocks on HOST buffers (PCIe-inclusive)",
         "ratio": coded_total / (float(nb) * bs) if nb else None,
         "all_status_ok": ok, "roundtrip_verified_blocks": verified,
         "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
@@ -571,6 +701,11 @@ def main():
         # coded payloads of the timed run, for the identity check against the reference
         ncmp = min(nb, 512)
         host_out = d_out[:ncmp].cpu().numpy()
+        if a.mode == "encode" and world == 1 and a.decode_blocks > 0 and ok:
+            try:
+                line["decode"] = decode_leg(a.decode_blocks)
+            except Exception as e:            # the headline line must survive a failing side leg
+                line["decode"] = {"error": str(e)[:500]}
         del d_out
         torch.cuda.empty_cache()
         # ---- end-to-end through the drop-in API on host buffers (SURVEY 8(d)'s metric), outside the timed region ----

@@ -27,8 +27,9 @@ def _lcg_u32(n: int, seeds: torch.Tensor) -> torch.Tensor:
     return (x + ((_C * geo) & _M32)[None, :]) & _M32
 
 
-def text_blocks(nblocks: int, n: int, first_seed: int, device, chunk: int = 32) -> torch.Tensor:
-    """[nblocks, n] uint8 on `device`; block b == corpus.zipf_text(n, first_seed + b)."""
+def text_blocks(nblocks: int, n: int, first_seed: int, device, chunk: int = 32, seeds=None) -> torch.Tensor:
+    """[nblocks, n] uint8 on `device`; block b == corpus.zipf_text(n, first_seed + b) -- or, with `seeds` (a list of
+    nblocks ints), corpus.zipf_text(n, seeds[b]): the text blocks of the "mixed" corpus are not consecutive."""
     lens_np, letters_np, cdf_np = corpus._vocab()
     lens = torch.from_numpy(lens_np).to(device)
     letters = torch.from_numpy(letters_np.astype(np.int64)).to(device)            # [4096, 10]
@@ -38,8 +39,11 @@ def text_blocks(nblocks: int, n: int, first_seed: int, device, chunk: int = 32) 
     out = torch.empty((nblocks, n), dtype=torch.uint8, device=device)
     for b0 in range(0, nblocks, chunk):
         k = min(chunk, nblocks - b0)
-        seeds = torch.arange(first_seed + b0, first_seed + b0 + k, dtype=torch.int64, device=device)
-        r = _lcg_u32(2 * nw, seeds)                                                # [k, 2nw]
+        if seeds is None:
+            sd = torch.arange(first_seed + b0, first_seed + b0 + k, dtype=torch.int64, device=device)
+        else:
+            sd = torch.tensor(list(seeds[b0:b0 + k]), dtype=torch.int64, device=device)
+        r = _lcg_u32(2 * nw, sd)                                                # [k, 2nw]
         u = r[:, 0::2] >> 4                                                        # 28 random bits
         # (u * total) >> 28 without leaving int64: total < 2^36, u < 2^28 (numpy does this in uint64)
         t1, t0 = total >> 14, total & 0x3FFF
