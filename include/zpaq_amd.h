@@ -62,9 +62,10 @@ int zpq_set_state_budget(uint64_t bytes);
 /* Select the coding kernel: 0 = auto (best available for each plan: the pipelined encoder for compression, the
  * per-header specialised wavefront kernel for decompression), 1 = generic one-lane kernel, 2 = generic
  * wave-parallel kernel, 3 = per-header specialised wavefront kernel in both directions (one block per wavefront),
- * 4 = pipelined encoder (decompression as with 3), 5 = the decoder with two blocks per wavefront (what 0 picks for a
- * launch of more than 4 x CUs blocks whose chain has up to 32 components; compression as with 0).  3, 4 and 5 fail
- * with ZPQ_E_UNSUPPORTED when the kernel cannot be built. */
+ * 4 = pipelined encoder (decompression as with 3), 5 = the decoder with two blocks per wavefront (compression as with 0),
+ * 6 = the lockstep decoder (row / mixer wavefronts, the 8 blocks of a workgroup bit by bit together: what 0 picks for a
+ * launch of more than 4 x CUs blocks whose chain it takes; compression as with 0).  3, 4, 5 and 6 fail with
+ * ZPQ_E_UNSUPPORTED when the kernel cannot be built. */
 int zpq_set_kernel(int which);
 
 /* ---- model plan: a parsed block header + device arena layout ---- */
@@ -104,6 +105,10 @@ int zpq_plan_spec_source(const zpq_plan*, char* src, size_t cap, size_t* len, ch
  * wavefront, 0 = 32). */
 /* The decoder with two blocks per wavefront (device/spec_dual_kernel.h): chains of up to 32 components. */
 int zpq_plan_spec_dual_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
+/* The lockstep decoder (device/spec_team_kernel.h): the 8 blocks of a workgroup advance bit by bit together, their ICM /
+ * ISSE components on row wavefronts (16 lanes per block), everything else on mixer wavefronts (two blocks each).  Chains of
+ * up to 32 components whose ISSEs are fed by the ICM / ISSE right before them. */
+int zpq_plan_spec_team_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_source(const zpq_plan*, char* src, size_t cap, size_t* len, char key41[41]);
 int zpq_plan_pipe_layout(const zpq_plan*, uint64_t out[16]);
 int zpq_plan_pipe_source_opts(const zpq_plan*, int mode, int chunk, int group, char* src, size_t cap, size_t* len, char key41[41]);
@@ -120,6 +125,7 @@ int zpq_pcomp_is_translated(const uint8_t* code, size_t codelen, int ph, int pm)
  * returns the size of the gfx950 code object, or 0 with the compiler log in `log`. */
 size_t zpq_plan_spec_jit(const zpq_plan*, char* log, size_t cap);
 size_t zpq_plan_spec_dual_jit(const zpq_plan*, char* log, size_t cap);      /* the decoder with two blocks per wavefront */
+size_t zpq_plan_spec_team_jit(const zpq_plan*, char* log, size_t cap);      /* the lockstep decoder */
 /* Headers nobody prebuilt (level-5 chains whose periodic models depend on the data): compile the kernels of `n` plans
  * with hipRTC on up to `threads` host threads at once (0 = as many as the process may use, at most 16) -- the pipelined
  * encoder when decode == 0, the wavefront kernel otherwise -- into the code-object cache.  The engine does the same at

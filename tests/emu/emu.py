@@ -123,10 +123,64 @@ def build_dual(header: bytes) -> str:
     return exe
 
 
-def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int = 4, out_cap: int | None = None, dual: bool = False):
-    """Code every input as one block (one wavefront each; dual: the decoder with two blocks per wavefront).
-    Returns [(bytes, status, consumed)]."""
-    exe = build_dual(header) if dual else build(header, waves)
+def team_source(header: bytes) -> str:
+    """The translation unit of the lockstep decoder (zpq_plan_spec_team_source)."""
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_spec_team_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    plan = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    if L.zpq_plan_spec_team_source(plan._h, buf, len(buf), C.byref(ln), key) != 0:
+        raise RuntimeError(L.zpq_last_error().decode())
+    return buf.value.decode()
+
+
+def team_threads(src: str) -> int:
+    import re
+    return int(re.search(r"__launch_bounds__\((\d+)\) void zpq_spec_decode3", src).group(1))
+
+
+def build_team(header: bytes):
+    import zpaq_amd as z
+    src = team_source(header)
+    dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
+    deps = b"".join(open(p, "rb").read() for p in (
+        os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "emu_main.cpp"), os.path.join(EMU, "guard_alloc.h"),
+        os.path.join(dev, "spec_kernel.h"), os.path.join(dev, "spec_dual_kernel.h"), os.path.join(dev, "spec_team_kernel.h"),
+        os.path.join(dev, "layout.h")))
+    flags = _sanitize_flags()
+    key = hashlib.sha1(src.encode() + deps + " ".join(flags).encode()).hexdigest()[:20]
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, f"team_{key}")
+    if os.path.exists(exe):
+        return exe, team_threads(src)
+    gen = os.path.join(BUILD, f"tgen_{key}.cpp")
+    stubs = ('extern "C" void zpq_spec_encode(const zpq::BlockJob*, zpq::BlockResult*, unsigned, const zpq::DeviceTables*) {}\n'
+             'extern "C" void zpq_spec_decode(const zpq::BlockJob*, zpq::BlockResult*, unsigned, const zpq::DeviceTables*) {}\n')
+    with open(gen, "w") as fh:
+        fh.write('#include "wave_emu.h"\n' + src + stubs)
+    libdir = os.path.dirname(z.library_path())
+    cmd = ["g++", "-O1", "-std=c++17", "-w", "-DZPQ_EMU_TEAM", *flags, "-I", EMU, "-I", dev, "-I", os.path.join(ROOT, "include"), gen,
+           os.path.join(EMU, "emu_main.cpp"), os.path.join(EMU, "wave_emu.cpp"), "-L", libdir, "-lzpaq_amd", f"-Wl,-rpath,{libdir}", "-o", exe + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    os.remove(gen)
+    if r.returncode != 0:
+        raise RuntimeError("team emulator build failed:\n" + r.stdout[-6000:])
+    os.replace(exe + ".tmp", exe)
+    return exe, team_threads(src)
+
+
+def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int = 4, out_cap: int | None = None, dual: bool = False,
+        team: bool = False):
+    """Code every input as one block (one wavefront each; dual: the decoder with two blocks per wavefront; team: the
+    lockstep decoder).  Returns [(bytes, status, consumed)]."""
+    if team:
+        exe, thr = build_team(header)
+        waves, dual = thr // 64, False
+    else:
+        exe = build_dual(header) if dual else build(header, waves)
     cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
     with tempfile.TemporaryDirectory(dir=BUILD) as td:
         hp = os.path.join(td, "h.bin")
@@ -136,7 +190,7 @@ def run(header: bytes, inputs: Sequence[bytes], decode: bool = False, waves: int
             p = os.path.join(td, f"in{i}")
             open(p, "wb").write(bytes(d))
             paths.append(p)
-        r = subprocess.run([exe, "dec2" if dual else ("dec" if decode else "enc"), str(waves), hp, str(cap), os.path.join(td, "out"), *paths],
+        r = subprocess.run([exe, "dec3" if team else ("dec2" if dual else ("dec" if decode else "enc")), str(waves), hp, str(cap), os.path.join(td, "out"), *paths],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if r.returncode != 0:
             raise RuntimeError(f"emulator failed ({r.returncode}): {r.stderr[-2000:]}")

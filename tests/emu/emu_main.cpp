@@ -27,6 +27,10 @@ extern "C" void zpq_spec_decode(const zpq::BlockJob* jobs, zpq::BlockResult* res
 extern "C" void zpq_spec_decode2(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
                                  const zpq::DeviceTables* tb);
 #endif
+#ifdef ZPQ_EMU_TEAM
+extern "C" void zpq_spec_decode3(const zpq::BlockJob* jobs, zpq::BlockResult* res, unsigned nblocks,
+                                 const zpq::DeviceTables* tb);
+#endif
 
 namespace {
 
@@ -55,6 +59,9 @@ void kernel_thunk(void* p) {
 #ifdef ZPQ_EMU_DUAL
   if (l->dual) { zpq_spec_decode2(l->jobs, l->res, l->nblocks, l->tb); return; }
 #endif
+#ifdef ZPQ_EMU_TEAM
+  if (l->dual) { zpq_spec_decode3(l->jobs, l->res, l->nblocks, l->tb); return; }
+#endif
   if (l->dec) zpq_spec_decode(l->jobs, l->res, l->nblocks, l->tb);
   else zpq_spec_encode(l->jobs, l->res, l->nblocks, l->tb);
 }
@@ -82,7 +89,10 @@ void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb
 
 int main(int argc, char** argv) {
   if (argc < 7) { fprintf(stderr, "usage: emu_run enc|dec <waves> <header.bin> <out_cap> <out_prefix> <input>...\n"); return 2; }
-  const bool dual = !strcmp(argv[1], "dec2");      // two blocks per wavefront (spec_dual_kernel.h)
+  // "dec2": two blocks per wavefront (spec_dual_kernel.h); "dec3": the lockstep decoder (spec_team_kernel.h), <waves> = its
+  // threads per workgroup / 64; both address the blocks of a workgroup relative to its first arena: one contiguous pool
+  const bool team = !strcmp(argv[1], "dec3");
+  const bool dual = team || !strcmp(argv[1], "dec2");
   const bool dec = dual || !strcmp(argv[1], "dec");
   const unsigned waves = (unsigned)atoi(argv[2]);
   const std::vector<uint8_t> header = slurp(argv[3]);
@@ -139,7 +149,7 @@ int main(int argc, char** argv) {
   }
   Launch l{dec, dual, jobs.data(), res.data(), nb, &tb};
   const unsigned per_wg = dual ? 8 : waves;      // blocks per workgroup
-  for (unsigned wg = 0; wg < (nb + per_wg - 1) / per_wg; ++wg) emu::run_workgroup(kernel_thunk, &l, dual ? 256 : 64 * waves, wg);
+  for (unsigned wg = 0; wg < (nb + per_wg - 1) / per_wg; ++wg) emu::run_workgroup(kernel_thunk, &l, team ? 64 * waves : (dual ? 256 : 64 * waves), wg);
   for (unsigned b = 0; b < nb; ++b) {
     // guard bytes past the capacity must be untouched
     for (unsigned k = 0; k < 64; ++k)

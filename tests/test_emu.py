@@ -152,6 +152,47 @@ def test_two_blocks_per_wavefront_decoder_contract_on_bad_streams(zlib_, oracle)
 
 
 # ---------------------------------------------------------------------------------------------------------
+# The lockstep decoder (zpaq_amd/csrc/device/spec_team_kernel.h): row wavefronts + mixer wavefronts, workgroup barriers
+
+def _team_check(oracle, header, datas):
+    inputs = [b"\0" + bytes(d) for d in datas]
+    coded = [oracle.encode(header, i) for i in inputs]
+    dec = emu.run(header, [c + b"\0\0\0\0" for c in coded], decode=True, out_cap=max(len(x) for x in inputs), team=True)
+    for inp, c, (plain, status, consumed) in zip(inputs, coded, dec):
+        assert status == 0 and plain == inp
+        assert consumed in (0, len(c) + 4)
+
+
+@pytest.mark.parametrize("method", ["5", DEEP_ISSE])
+def test_lockstep_decoder(zlib_, oracle, method):
+    """-m5 (16 ICM / ISSE components: 16 row lanes per block, 384 threads) and the chain of 18 whose side tables do not fit
+    the LDS (32 row lanes per block, 512 threads); ragged lengths, an empty block, 9 blocks = a full workgroup and one
+    with a single block."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header = zlib_.method_to_header(method if method.startswith("x") else zlib_.expand_method(method, blk))[0]
+    _team_check(oracle, header, _ragged(500) + [corpus.block("text", n, n).tobytes() for n in (1, 64, 333, 500)])
+
+
+def test_lockstep_decoder_on_every_component_type_and_bad_streams(zlib_, oracle, golden):
+    for e in [golden["config_cases"][0]] + golden["level_cases"][1:] + golden["vm_cases"][:1]:
+        header = bytes.fromhex(e["header"])
+        d = gen_input(e).tobytes()[:1000]
+        _team_check(oracle, header, [d, d[:600], d[:1]])
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    header, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    d = b"\0" + corpus.block("text", 1200, 77).tobytes()
+    c = oracle.encode(header, d)
+    good = c + b"\0\0\0\0"
+    garbage = np.random.default_rng(5).integers(0, 256, 400, dtype=np.uint8).tobytes()
+    streams = [c[:len(c) // 2], good, garbage, good]
+    one = emu.run(header, streams, decode=True, waves=8, out_cap=len(d) + 8)
+    team = emu.run(header, streams, decode=True, out_cap=len(d) + 8, team=True)
+    assert one == team
+    assert team[1][1] == 0 and team[1][0] == d and team[1][2] == len(c) + 4
+    assert emu.run(header, [good], decode=True, out_cap=701, team=True) == emu.run(header, [good], decode=True, waves=8, out_cap=701)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # The pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h): the same generated source the GPU runs, executed
 # step by step on the host with consumers launched BEFORE producers inside a step (tests/emu/pipe_emu_main.cpp).
 

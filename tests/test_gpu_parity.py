@@ -395,6 +395,46 @@ def test_two_blocks_per_wavefront_decoder(gpu, golden):
     assert outs[0] == outs[1] == outs[2] == b"".join(blocks)
 
 
+def test_lockstep_decoder(gpu, golden):
+    """device/spec_team_kernel.h (row + mixer wavefronts, the 8 blocks of a workgroup bit by bit together), which a dense
+    decode launch takes by itself: forced here (zpq_set_kernel(6)) on every golden archive whose chain it accepts (the
+    reference wrote them; zpq_decompress checks their SHA-1 trailers), on a batch with an odd number of blocks, an empty
+    and a one-byte one, and on 2 048 blocks in one launch (the configs[4] operating point: every CU holds a workgroup) --
+    the same bytes as the one-block kernel (3), the two-block kernel (5) and the engine's own choice return."""
+    tried = 0
+    gpu.set_kernel(6)
+    try:
+        for sect in ("config_cases", "level_cases", "vm_cases", "method_cases"):
+            for e in golden[sect]:
+                hdr = bytes.fromhex(e["header"])
+                if "archive_b64" not in e or hdr[6] == 0 or hdr[6] > 32:
+                    continue
+                want = gen_input(e).tobytes()
+                assert gpu.decompress(b64(e), cap=len(want) + 64) == want, (sect, e.get("name") or e.get("method"))
+                tried += 1
+    finally:
+        gpu.set_kernel(0)
+    assert tried >= 40
+    blocks = [corpus.block("text", 20000 + 77 * i, 300 + i).tobytes() for i in range(9)] + [b"", b"x"]
+    arch = b"".join(gpu.compress_blocks(blocks, "5"))
+    outs = []
+    for kernel in (6, 5, 3, 0):
+        gpu.set_kernel(kernel)
+        try:
+            outs.append(gpu.decompress(arch))
+        finally:
+            gpu.set_kernel(0)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == b"".join(blocks)
+    many = [corpus.block(("text", "records", "lcg", "zeros")[i % 4], 3000 + (i * 37) % 1500, 900 + i).tobytes() for i in range(2048)]
+    arch = b"".join(gpu.compress_blocks(many, "5"))
+    for kernel in (6, 5):
+        gpu.set_kernel(kernel)
+        try:
+            assert gpu.decompress(arch) == b"".join(many), kernel
+        finally:
+            gpu.set_kernel(0)
+
+
 def test_4_mib_zeros_known_answer(gpu):
     """4 MiB zeros, method 5 -> 410 B (175 MiB of model state per block)."""
     a, = gpu.compress_blocks([np.zeros(4 << 20, np.uint8)], "5")

@@ -78,6 +78,19 @@ int zpq_plan_spec_dual_source(const zpq_plan* p, char* src, size_t cap, size_t* 
   ZPQ_CATCH
 }
 
+int zpq_plan_spec_team_source(const zpq_plan* p, char* src, size_t cap, size_t* len, char key41[41]) {
+  ZPQ_TRY
+  if (!p) fail(ZPQ_E_ARG, "null plan");
+  std::string source, key, why;
+  if (!spec_source_and_key(*p, 3, source, key, why)) fail(ZPQ_E_UNSUPPORTED, why);
+  if (len) *len = source.size();
+  if (key41) { memcpy(key41, key.c_str(), 40); key41[40] = 0; }
+  if (source.size() + 1 > cap) fail(ZPQ_E_OVERFLOW, "source buffer too small");
+  memcpy(src, source.c_str(), source.size() + 1);
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_plan_kernel_kind(zpq_plan* p, char* note, size_t cap) { return zpq_plan_kernel_kind2(p, 0, note, cap); }
 
 int zpq_plan_kernel_kind2(zpq_plan* p, int decode, char* note, size_t cap) { return zpq_plan_kernel_kind4(p, decode, 0, 0, note, cap); }
@@ -109,6 +122,18 @@ size_t zpq_plan_spec_dual_jit(const zpq_plan* p, char* log, size_t cap) {
   try {
     std::string l;
     const size_t n = p ? spec_jit_compile_only(*p, 2, l) : 0;
+    if (log && cap) { strncpy(log, l.c_str(), cap - 1); log[cap - 1] = 0; }
+    return n;
+  } catch (const std::exception& ex) {
+    if (log && cap) { strncpy(log, ex.what(), cap - 1); log[cap - 1] = 0; }
+    return 0;
+  }
+}
+
+size_t zpq_plan_spec_team_jit(const zpq_plan* p, char* log, size_t cap) {
+  try {
+    std::string l;
+    const size_t n = p ? spec_jit_compile_only(*p, 3, l) : 0;
     if (log && cap) { strncpy(log, l.c_str(), cap - 1); log[cap - 1] = 0; }
     return n;
   } catch (const std::exception& ex) {

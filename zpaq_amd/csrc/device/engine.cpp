@@ -376,6 +376,7 @@ static uint32_t pipe_stream_bytes_per_byte(const zpq_plan* plan) {
 
 // must_specialise: the plan has blocks of several segments in this batch; only the per-header kernels carry coder and model
 // state across segments, so such a plan compiles whatever the batch's JIT budget says.
+static const bool kAutoTeam = true;     // kernel choice 0 prefers the lockstep decoder for launches that fill the machine
 static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool decode, int mode, bool must_specialise = false) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
   KernelPick r;
@@ -390,7 +391,7 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   // Each unseen header costs a hipRTC compile of several seconds.  A batch whose blocks all carry different
   // (data-dependent) chains must not spend minutes compiling: a few per call, the rest run on the
   // generic wave kernel this time and are picked up by later calls.
-  if (!decode && (want == 0 || want == 4 || want == 5)) {      // (5 chooses among the decoders only)
+  if (!decode && (want == 0 || want == 4 || want == 5 || want == 6)) {      // (5 and 6 choose among the decoders only)
     bool did = false;
     PipeKernel* k = pipe_kernel_for(p, mode, want == 4 || must_specialise || e.jit_left > 0, &did);
     if (did && e.jit_left > 0) --e.jit_left;
@@ -400,6 +401,14 @@ static KernelPick kernel_kind(Engine& e, const zpq_plan* plan, bool dense, bool 
   const int forced = spec_variant_forced();
   // Decoding a launch that fills the machine: two blocks per wavefront (device/spec_dual_kernel.h) where the chain allows
   // it (up to 32 components, no block of several segments).  zpq_set_kernel(5) forces it, 3 keeps one block per wavefront.
+  // The lockstep decoder (device/spec_team_kernel.h) first: zpq_set_kernel(6) forces it.
+  if (decode && !must_specialise && forced < 0 && (want == 6 || (want == 0 && dense && kAutoTeam)) && p->cur().spec_state[3] >= 0) {
+    bool did = false;
+    SpecKernel* k = spec_kernel_for(p, 3, want == 6 || e.jit_left > 0, nullptr, &did);
+    if (did && e.jit_left > 0) --e.jit_left;
+    if (k) { r.kind = 3; r.spec = k; return r; }
+    if (want == 6) fail(ZPQ_E_UNSUPPORTED, "lockstep decoder unavailable: " + p->cur().spec_note);
+  }
   if (decode && !must_specialise && forced < 0 && (want == 5 || (want == 0 && dense)) && p->cur().spec_state[2] >= 0) {
     bool did = false;
     SpecKernel* k = spec_kernel_for(p, 2, want == 5 || e.jit_left > 0, nullptr, &did);
@@ -430,7 +439,9 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_
   e.jit_left = jit_budget();
   const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes, pipe_stream_bytes_per_byte(p)));
   // (the note of the kernel that was PICKED: the plan's spec_note is the note of whichever shape was loaded last)
-  if (k.kind == 3 && k.spec) note = k.spec->origin + (k.spec->encode ? "" : " (zpq_spec_decode2: two blocks per wavefront)");
+  if (k.kind == 3 && k.spec)
+    note = k.spec->origin + (k.spec->encode ? "" : (k.spec->threads > 256 ? " (zpq_spec_decode3: row / mixer wavefronts in lockstep)"
+                                                                          : " (zpq_spec_decode2: two blocks per wavefront)"));
   else note = k.kind == 4 ? p->cur().pipe_note : p->cur().spec_note;
   return k.kind;
 }
@@ -732,10 +743,11 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
                               const std::map<const zpq_plan*, int>& mode_of) {
   const int want = e.kernel_choice;
   if (want == 1 || want == 2 || e.jit_left <= 1) return;
-  const bool pipe = !decode && (want == 0 || want == 4 || want == 5);
+  const bool pipe = !decode && (want == 0 || want == 4 || want == 5 || want == 6);
   const int forced = spec_variant_forced();
-  const bool dual = decode && forced < 0 && (want == 5 || (want == 0 && dense));     // as kernel_kind() will choose
-  const int variant = forced >= 0 ? forced : (dual ? 2 : (dense ? 1 : 0));
+  const bool team = decode && forced < 0 && (want == 6 || (want == 0 && dense && kAutoTeam));   // as kernel_kind() will choose
+  const bool dual = decode && forced < 0 && (want == 5 || (want == 0 && dense));
+  const int variant = forced >= 0 ? forced : (team ? 3 : (dual ? 2 : (dense ? 1 : 0)));
   std::vector<const zpq_plan*> unseen;
   std::vector<int> modes;
   const zpq_plan* last = nullptr;

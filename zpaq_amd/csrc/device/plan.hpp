@@ -18,8 +18,8 @@ struct zpq_plan {
     // per-header specialised kernels (device/spec_loader.hpp), one per workgroup shape: [0] 4 blocks per workgroup
     // (all side tables in LDS, one wavefront per SIMD), [1] 8 (two per SIMD); the engine chooses per launch.
     // (12/16-block shapes were measured in round 2 and lost: profiles/r02_ab_matrix.txt.)
-    void* spec[3] = {nullptr, nullptr, nullptr};   // SpecKernel*: 4 / 8 blocks per workgroup, two blocks per wavefront (decoder)
-    int spec_state[3] = {0, 0, 0};                 // 0 not tried, 1 loaded, -1 unavailable
+    void* spec[4] = {nullptr, nullptr, nullptr, nullptr};   // SpecKernel*: 4 / 8 blocks per workgroup, two blocks per wavefront (decoder), lockstep decoder
+    int spec_state[4] = {0, 0, 0, 0};              // 0 not tried, 1 loaded, -1 unavailable
     // PipeKernel*: the pipelined encoder (device/pipe_kernel.h) in its variants (host/codegen.hpp pipe_options):
     // [0] throughput shape, [1] latency shape, [2] latency shape with 2048-byte steps
     void* pipe[3] = {nullptr, nullptr, nullptr};

@@ -98,12 +98,14 @@ int spec_variant_forced() {
 }
 
 bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source, std::string& key, std::string& why_not) {
-  // variant 0 / 1: one block per wavefront, 4 / 8 blocks per workgroup; 2: the decoder with two blocks per wavefront
-  if (!generate_spec_source(plan, variant >= 1 ? 8 : 4, source, why_not, variant == 2)) return false;
-  std::string h1, h2, h3;
+  // variant 0 / 1: one block per wavefront, 4 / 8 blocks per workgroup; 2: the decoder with two blocks per wavefront;
+  // 3: the lockstep decoder (row / mixer wavefronts, device/spec_team_kernel.h)
+  if (!generate_spec_source(plan, variant >= 1 ? 8 : 4, source, why_not, variant == 2 ? 1 : (variant == 3 ? 2 : 0))) return false;
+  std::string h1, h2, h3, h4;
   const std::string inc = spec_include_dir();
   if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) ||
-      (variant == 2 && !read_file(inc + "/spec_dual_kernel.h", h3))) {
+      (variant >= 2 && !read_file(inc + "/spec_dual_kernel.h", h3)) ||
+      (variant == 3 && !read_file(inc + "/spec_team_kernel.h", h4))) {
     why_not = "kernel template headers not found under " + inc;
     return false;
   }
@@ -112,6 +114,7 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
   s.update(h1.data(), h1.size());
   s.update(h2.data(), h2.size());
   s.update(h3.data(), h3.size());
+  s.update(h4.data(), h4.size());
   if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));   // e.g. -DZPQ_PROF
   key = hex20(s.result());
   return true;
@@ -278,7 +281,10 @@ int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int va
     std::string why;
     bool have = false;
     if (pipe) have = pipe_source_and_key(*p, pipe_options(modes && pi < modes->size() ? (*modes)[pi] : 0), it.source, it.key, why);
-    if (!have) have = spec_source_and_key(*p, variant, it.source, it.key, why);
+    // a chain the wanted decoder shape does not take (more than 32 components, an ISSE fed from afar ...) gets the next
+    // one down, as kernel_kind() will choose it: 3 lockstep -> 2 two blocks per wavefront -> 1 one block per wavefront
+    for (int v = variant; !pipe && !have && v >= 1; --v) have = spec_source_and_key(*p, v, it.source, it.key, why);
+    if (!have && (pipe || variant < 1)) have = spec_source_and_key(*p, variant, it.source, it.key, why);
     if (!have) continue;
     bool dup = false;
     for (const std::string& k : seen) dup = dup || k == it.key;
@@ -323,7 +329,7 @@ size_t spec_jit_compile_only(const zpq_plan& plan, int variant, std::string& log
 }
 
 SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* jit_deferred, bool* did_jit) {
-  if (variant < 0 || variant > 2) variant = 0;
+  if (variant < 0 || variant > 3) variant = 0;
   if (plan->cur().spec_state[variant] > 0) return (SpecKernel*)plan->cur().spec[variant];
   if (plan->cur().spec_state[variant] < 0) return nullptr;
   plan->cur().spec_state[variant] = -1;
@@ -361,17 +367,19 @@ SpecKernel* spec_kernel_for(zpq_plan* plan, int variant, bool allow_jit, bool* j
     }
   }
   SpecKernel* k = new SpecKernel;
-  const bool dual = variant == 2;           // the decoder alone, two blocks per wavefront (device/spec_dual_kernel.h)
+  const bool team = variant == 3;           // the decoder alone, 8 blocks of a workgroup in lockstep (device/spec_team_kernel.h)
+  const bool dual = variant == 2 || team;   // the decoder alone, two blocks per wavefront (device/spec_dual_kernel.h)
   if (hipModuleLoadData(&k->module, code.data()) != hipSuccess ||
       (!dual && hipModuleGetFunction(&k->encode, k->module, "zpq_spec_encode") != hipSuccess) ||
-      hipModuleGetFunction(&k->decode, k->module, dual ? "zpq_spec_decode2" : "zpq_spec_decode") != hipSuccess) {
+      hipModuleGetFunction(&k->decode, k->module, team ? "zpq_spec_decode3" : (dual ? "zpq_spec_decode2" : "zpq_spec_decode")) != hipSuccess) {
     plan->cur().spec_note = "hipModuleLoadData failed for " + origin;
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
     return nullptr;
   }
   int maxthr = 0;
-  if (dual) { k->waves = 8; k->threads = 256; }
+  if (team) { k->waves = 8; k->threads = team_threads(*plan); }
+  else if (dual) { k->waves = 8; k->threads = 256; }
   else if (hipFuncGetAttribute(&maxthr, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, k->encode) == hipSuccess && maxthr >= 64) {
     k->waves = maxthr / 64;
     k->threads = 64 * k->waves;
@@ -508,7 +516,7 @@ void spec_kernel_release(zpq_plan* plan) {
     plan->cur().pipe[m] = nullptr;
     plan->cur().pipe_state[m] = 0;
   }
-  for (int v = 0; plan && v < 3; ++v) {
+  for (int v = 0; plan && v < 4; ++v) {
     if (!plan->cur().spec[v]) continue;
     SpecKernel* k = (SpecKernel*)plan->cur().spec[v];
     if (k->module) (void)hipModuleUnload(k->module);

@@ -1,0 +1,705 @@
+// Decoder with the blocks of a workgroup in LOCKSTEP and the work of a bit split by KIND over its wavefronts:
+//
+//   ROW wavefronts    lane = (block, ICM / ISSE component): 16 lanes per block (4 blocks per wavefront; 32 lanes and
+//                     2 blocks when a chain has more than 16 such components).  Predictor::find per nibble, the
+//                     bit-history row in registers, the side table, stretch, the ISSE chains (DPP shift inside the
+//                     block's lanes) -- what spec_kernel.h does on 16 of its 64 lanes, here on all 64.
+//   MIXER wavefronts  two blocks per wavefront as in spec_dual_kernel.h, lane = (block, component): CM, MATCH, MIX2,
+//                     MIX, SSE, AVG, the arithmetic coder and HCOMP; the predictions of the ICM / ISSE components
+//                     arrive through LDS.
+//
+// Why.  One block per wavefront leaves 41 of 64 lanes idle and issues every instruction for all of them; two blocks
+// per wavefront fix half of that but leave ONE wavefront per SIMD with nothing to hide its stalls behind
+// (profiles/r03: 7.9 cycles per instruction, +8 %).  The decoder's true serial chain per bit -- ISSE chain, mixers,
+// SSE, squash, coder -- is ~1 000 cycles; everything else (row probes, side-table and weight updates, candidate
+// fetches) only has to be done by SOMEBODY before the next bit needs it.  Here 8 blocks share a workgroup of 6 (8)
+// wavefronts, a bit is two phases separated by workgroup barriers
+//
+//     rows predict -> [A] -> mixers: chain, squash, decode y -> [B] -> rows update | mixers update    (+ [C] per byte: HCOMP)
+//
+// and while the mixers work the row wavefronts fetch what the next bit may need (both candidates), and vice versa.
+// Per bit the CU issues ~2 x 200 + 4 x 250 instructions for 8 blocks instead of 8 x 415.
+//
+// Chains this kernel takes (the generator checks, the engine falls back to the other decoders otherwise): up to 32
+// components, every ISSE fed by the ICM / ISSE before it (the last one of lower index: true of every chain
+// compressBlock's methods and the legacy models produce), H in LDS (hh <= 10), MIX inputs inside one half, the 8
+// arenas of a workgroup inside a 4 GiB window (the engine lays a batch's arenas out back to back), one segment per block.
+//
+// The per-lane model arithmetic is spec_kernel.h's, statement for statement (bit-exact with Predictor::predict0 /
+// update0, libzpaq.cpp:1854-2066; Decoder::decompress / decode, 2104-2181).  LDS plan: the generated Chain of the
+// 8-blocks-per-workgroup shape; the upper half of a block's 512-byte dummy area carries the exchange words.
+#pragma once
+#ifndef ZPQ_LANE_VM
+#define ZPQ_LANE_VM 1
+#endif
+#include "spec_dual_kernel.h"
+
+namespace zpq {
+
+// Workgroup barrier that waits for this wavefront's LDS traffic only: __syncthreads() also drains vmcnt, i.e. every
+// global fetch and store in flight -- exactly what the phases issue early in order NOT to wait for.
+#ifdef ZPQ_EMU
+#define ZPQ_TEAM_BARRIER() emu::block_barrier()
+#else
+// (the scheduling fences keep the compiler from moving a phase's arithmetic ahead of the barrier that hands the
+// other wavefronts their input: asm volatile orders memory operations only)
+#define ZPQ_TEAM_BARRIER()                                              \
+  do {                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+  } while (0)
+#endif
+
+template <int N>
+struct TeamMap {
+  int nrows;
+  int rc[32];        // chain index of the k-th ICM / ISSE component
+  int depth;         // longest run of ISSEs among them: rounds of (shift, multiply-add, clamp) that resolve every chain
+  bool ok;
+};
+
+template <class Chain>
+constexpr TeamMap<Chain::N> team_map() {
+  TeamMap<Chain::N> m{};
+  m.nrows = 0;
+  m.depth = 0;
+  m.ok = Chain::N <= 32 && Chain::H_LDS >= 0;
+  for (int i = 0; i < 32; ++i) m.rc[i] = 0;
+  int run = 0;
+  for (int i = 0; i < Chain::N; ++i) {
+    const unsigned t = Chain::comp[i].type;
+    if (t == C_ICM || t == C_ISSE) {
+      if (m.nrows < 32) m.rc[m.nrows] = i;
+      ++m.nrows;
+      run = t == C_ISSE ? run + 1 : 0;
+      if (run > m.depth) m.depth = run;
+    }
+    // an ISSE takes its input from the row component before it (its left neighbour among the row lanes)
+    if (t == C_ISSE && (m.nrows < 2 || m.nrows > 32 || Chain::comp[i].a2 != (unsigned)m.rc[m.nrows - 2])) m.ok = false;
+  }
+  return m;
+}
+
+constexpr int kTeamBlocks = 8;                               // blocks per workgroup
+// exchange words in the upper half of a block's dummy area (offsets from the start of the block's LDS region)
+constexpr int kTeamX = spec_wave_lds_bytes(8) - 256;         // X[32]: stretch-domain predictions of the row components, by chain index
+constexpr int kTeamY = kTeamX + 128;                         // the decoded bit
+constexpr int kTeamRun = kTeamX + 132;                       // block still decoding (written once per byte)
+
+template <class Chain>
+constexpr int team_row_lanes() { return team_map<Chain>().nrows <= 16 ? 16 : 32; }
+template <class Chain>
+constexpr int team_threads() { return 64 * (kTeamBlocks / (64 / team_row_lanes<Chain>()) + kTeamBlocks / 2); }
+
+// =====================================================================================================================
+// ROW wavefront
+template <class Chain, class TT>
+__device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const BlockJob* jobs, unsigned nblocks, int wave, int lane) {
+  constexpr auto TM = team_map<Chain>();
+  constexpr int R = TM.nrows;
+  constexpr int RL = team_row_lanes<Chain>();
+  constexpr int BPR = 64 / RL;
+  constexpr int kRegion = spec_wave_lds_bytes(8);
+  const int k = lane % RL, q = lane / RL;
+  const unsigned bw = (unsigned)(wave * BPR + q);            // block of this lane inside the workgroup
+  const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
+  const unsigned b = wg0 + bw;
+  const bool live = b < nblocks && k < R;
+  const BlockJob job0 = jobs[wg0];
+  const BlockJob job = jobs[b < nblocks ? b : wg0];
+  g_u8* const arena = (g_u8*)sp_uni64((unsigned long long)job0.arena);
+  const unsigned long long delta64 = (unsigned long long)job.arena - (unsigned long long)job0.arena;
+  const unsigned hoff = live ? (unsigned)delta64 : 0u;
+  lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
+
+  const unsigned dummy = (unsigned)Chain::OFF_RUN;
+  const unsigned dummy_lds = (unsigned)(kRegion - 512) + (unsigned)(k & 31) * 8u;
+  unsigned mask1 = 63, sizebits = 0, off0 = dummy, off1 = dummy, ctype = 0;
+  int ldsoff = -1, cidx = 0;
+  static_for<0, (R < 32 ? R : 32)>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kc)::value;
+    if (k == kk && live) {
+      constexpr CompK c = Chain::comp[TM.rc[kk]];
+      ctype = c.type;
+      sizebits = c.a1 + 2;
+      off0 = (unsigned)c.t0 + hoff;
+      off1 = (unsigned)c.t1 + hoff;
+      mask1 = c.mask1;
+      ldsoff = c.lds;
+      cidx = TM.rc[kk];
+    }
+  });
+  auto G32 = [&](unsigned off) __attribute__((always_inline)) -> g_u32& { return *(g_u32*)(arena + off); };
+  auto G128 = [&](unsigned off) __attribute__((always_inline)) -> g_u128& { return *(g_u128*)(arena + off); };
+  auto L32 = [&](unsigned off) __attribute__((always_inline)) -> lds_u32& { return *(lds_u32*)(wl + off); };
+
+  const bool is_icm = ctype == C_ICM, is_isse = ctype == C_ISSE;
+  const bool has_row = is_icm || is_isse;
+  const unsigned rmask = has_row ? mask1 : 63u;
+  const unsigned roff = has_row ? off1 : dummy;
+  const unsigned ldsq = (has_row && ldsoff >= 0) ? (unsigned)ldsoff : dummy_lds;
+  const bool side_global = has_row && ldsoff < 0;
+  const unsigned soff = side_global ? off0 : dummy;
+  auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
+    unsigned m = x ? 0xFFFFFFFFu : 0u;
+    ZPQ_OPAQUE(m);
+    return m;
+  };
+  const unsigned m_isse = lane_mask(is_isse), m_icm = lane_mask(is_icm), m_row = lane_mask(has_row);
+  const unsigned m_lds2 = lane_mask(is_isse && !side_global);
+  const unsigned bh_shift = is_isse ? 1u : 0u;
+  const unsigned q1off = is_icm ? 0u : 4u;
+  const unsigned n1base = (is_isse && !side_global) ? ldsq + 4u : dummy_lds + 4u;
+  const unsigned xoff = live ? (unsigned)kTeamX + 4u * (unsigned)cidx : dummy_lds;      // where this lane publishes p
+  constexpr int kIsseDepth = TM.depth;
+
+  unsigned bh = 0, h = 0, v0 = 0, v1 = 0, nspair = 0;
+  int p = 0, sq = 0;
+  unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0, rowoff = 0;
+  unsigned touch_a = 0, touch_b = 0;
+  // side tables that stayed in the arena: both candidates of the next bit are fetched while the mixers work
+  unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
+  unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
+  int c8 = 1, hmap4 = 1, ylast = 0;
+
+  bool any = true;
+  {
+    ZPQ_TEAM_BARRIER();                                      // [S] the mixers have published who runs
+    unsigned r = 0;
+    for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
+    any = r != 0;
+  }
+  while (any) {
+    static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
+      constexpr int B = decltype(bitc)::value;
+      constexpr bool nib = B == 0 || B == 4;
+      constexpr bool last_of_nibble = B == 3;
+      const int slot = hmap4 & 15;
+      const int c8a = c8 * 2, c8b = c8 * 2 + 1;
+      const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+      const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                      : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+      // ---- predict: Predictor::find per nibble, bit history, side table, ISSE chains
+      if constexpr (nib) {
+        ZPQ_KEEP2(touch_a, touch_b);
+        const unsigned cx = h + 16u * (unsigned)c8;
+        const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
+        const unsigned h0 = (cx * 16u) & (rmask - 15u);
+        uint4 r0 = G128(roff + h0);
+        uint4 r1 = G128(roff + (h0 ^ 16u));
+        uint4 r2 = G128(roff + (h0 ^ 32u));
+        const uint4 oldrow = make_uint4(row0, row1, row2, row3);
+        G128(roff + rowoff) = oldrow;
+        if (rowoff == h0) r0 = oldrow;
+        if (rowoff == (h0 ^ 16u)) r1 = oldrow;
+        if (rowoff == (h0 ^ 32u)) r2 = oldrow;
+        const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+        const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+        const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
+        const bool hit = m0 || m1 || m2;
+        const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
+        rowoff = h0 ^ (unsigned)(pick << 4);
+        row0 = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
+        row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
+        row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
+        row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
+      }
+      bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
+      nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
+      const unsigned e0 = (bh << bh_shift) & m_row;
+      const unsigned el = side_global ? 0u : e0;
+      unsigned q0 = L32(ldsq + 4u * el);
+      unsigned q1 = L32(ldsq + 4u * el + q1off);
+      if constexpr (Chain::ANY_GLOBAL_SIDE) {
+        const unsigned sidx = side_global ? e0 : 0u;
+        unsigned g0, g1;
+        if constexpr (nib) {                                  // new row: nothing was fetched ahead
+          g0 = G32(soff + 4u * sidx);
+          g1 = G32(soff + 4u * sidx + 4u);
+        } else {
+          const bool fwd = sidx == le0;
+          g0 = fwd ? ln0 : (ylast ? scb0 : sca0);
+          g1 = fwd ? ln1 : (ylast ? scb1 : sca1);
+        }
+        q0 = side_global ? g0 : q0;
+        q1 = side_global ? g1 : q1;
+      }
+      v0 = q0;
+      v1 = q1;
+      {
+        const int st = sp_stretch(T, (v0 >> 8) & 32767u);
+        p = (int)((unsigned)st & m_icm);
+        const int iw = (int)(v0 & m_isse);
+        const int ia = (int)sp_blend(m_isse, v1 << 6, (unsigned)p << 16);
+#pragma unroll
+        for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
+      }
+      L32(xoff) = (unsigned)p;
+      ZPQ_TEAM_BARRIER();                                    // [A] the mixers take over
+      // ---- while the mixers work: what the update and the next bit will need
+      sq = sp_squash(T, sp_clamp2k(p));
+      const int pj = sp_shr1(p);
+      if constexpr (last_of_nibble) {
+        // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
+        const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
+        touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
+        touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+      }
+      if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {
+        const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
+        const unsigned ea = side_global ? (bha << bh_shift) : 0u, eb = side_global ? (bhb << bh_shift) : 0u;
+        sca0 = G32(soff + 4u * ea); sca1 = G32(soff + 4u * ea + 4u);
+        scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
+      }
+      ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
+      const int y = (int)L32((unsigned)kTeamY);
+      // ---- update (Predictor::update0 cases ICM, ISSE)
+      {
+        const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
+        const int yq = y * 32767;
+        const int err = yq - sq;
+        row_set_nb<(B & 3)>(row0, row1, row2, row3, slot, nsv);
+        const unsigned n0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
+                                  (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
+        const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
+        L32(ldsq + 4u * el) = n0;
+        L32(n1base + ((4u * el) & m_lds2)) = n1;
+        if constexpr (Chain::ANY_GLOBAL_SIDE) {
+          const unsigned sidx = side_global ? e0 : 0u;
+          G32(soff + 4u * sidx) = n0;
+          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = n1;
+          le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
+        }
+        ylast = y;
+      }
+      c8 += c8 + y;
+      if constexpr (B == 7) {
+        ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run: contexts of the next byte, who still runs
+        h = ((lds_u32*)(wl + Chain::H_LDS))[(unsigned)cidx & Chain::HMASK];
+        unsigned r = 0;
+        for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
+        any = r != 0;
+        hmap4 = 1;
+        c8 = 1;
+      } else if constexpr (B == 3) {
+        hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
+      } else {
+        hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + y) & 0xf);
+      }
+    });
+  }
+  // (the last nibble's row is never written back: the block's model state is of no use after its last byte)
+}
+
+// =====================================================================================================================
+// MIXER wavefront: spec_dual_kernel.h without the ICM / ISSE work
+template <class Chain, class TT>
+__device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks,
+                                            int tw, int lane) {
+  constexpr int N = Chain::N;
+  constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
+  constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
+  constexpr int kRegion = spec_wave_lds_bytes(8);
+  const int ci = lane & 31;
+  const bool upper = lane >= 32;
+  const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
+  const unsigned bw = (unsigned)tw * 2u + (upper ? 1u : 0u);
+  const unsigned b = wg0 + bw;
+  const bool live = b < nblocks;
+  const BlockJob job0 = jobs[wg0];
+  const BlockJob job = jobs[live ? b : wg0];
+  g_u8* const arena = (g_u8*)sp_uni64((unsigned long long)job0.arena);
+  const unsigned long long delta64 = (unsigned long long)job.arena - (unsigned long long)job0.arena;
+  const unsigned hoff = live ? (unsigned)delta64 : 0u;
+  const g_u8* const in_ptr = (const g_u8*)job.in;
+  g_u8* const out_ptr = (g_u8*)job.out;
+  const unsigned in_len = job.in_len, out_cap = job.out_cap, rslot = job.res_slot;
+  lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
+
+  const unsigned dummy = (unsigned)Chain::OFF_RUN;
+  unsigned a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63;
+  unsigned off0 = dummy, off1 = dummy;
+  unsigned ctype = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (ci == i && live) {
+      const CompK c = Chain::comp[i];
+      ctype = c.type;
+      a4 = c.a4; a5 = c.a5;
+      limit = c.limit; mask0 = c.mask0;
+      if (c.type != C_ICM && c.type != C_ISSE) {
+        off0 = (unsigned)c.t0 + hoff;
+        if (c.type == C_MATCH) { off1 = (unsigned)c.t1 + hoff; mask1 = c.mask1; }
+      }
+    }
+  }
+  auto G32 = [&](unsigned off) __attribute__((always_inline)) -> g_u32& { return *(g_u32*)(arena + off); };
+  auto G8 = [&](unsigned off) __attribute__((always_inline)) -> g_u8& { return *(g_u8*)(arena + off); };
+  auto L32 = [&](unsigned off) __attribute__((always_inline)) -> lds_u32& { return *(lds_u32*)(wl + off); };
+
+  // HCOMP machine of this half (every lane of the half runs it: identical values, identical stores)
+  unsigned vm_b = 0, vm_c = 0, vm_d = 0, vm_f = 0;
+  g_u8* const vm_M = arena + (unsigned)Chain::OFF_M + hoff;
+  g_u32* const vm_R = (g_u32*)(arena + (unsigned)Chain::OFF_R + hoff);
+  lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
+
+  const bool is_cm = ctype == C_CM, is_match = ctype == C_MATCH, is_mix2 = ctype == C_MIX2;
+  const bool is_rowc = ctype == C_ICM || ctype == C_ISSE;     // predicted by the row wavefronts
+  const bool is_ctx = is_cm || is_match;
+  const bool gl = is_cm || is_mix2;
+  const bool pf_lane = is_cm ? mask0 >= 511u : (is_mix2 && a5 == 255u && mask0 >= 255u);
+  const bool resident = gl && mask0 == 0u;
+  const unsigned goff = gl ? off0 : dummy;
+  const unsigned gmask = gl ? mask0 : 0u;
+  auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
+    unsigned m = x ? 0xFFFFFFFFu : 0u;
+    ZPQ_OPAQUE(m);
+    return m;
+  };
+  const unsigned m_cm = lane_mask(is_cm), m_match = lane_mask(is_match), m_ctx = lane_mask(is_ctx);
+  const unsigned m_res = lane_mask(resident), m_pf = lane_mask(pf_lane), m_rowc = lane_mask(is_rowc);
+  const unsigned xoff = (unsigned)kTeamX + 4u * (unsigned)ci;
+
+  unsigned gidx = 0, h = 0;
+  int p = 0;
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (Chain::comp[i].type == C_CONS) { if (ci == i) p = ((int)Chain::comp[i].a1 - 128) * 4; }
+  });
+  unsigned v0 = 0;
+  unsigned ra = 0, rb = 0, rc = 0, rlimit = 0, mpred = 0, mdd = 0;
+  int mixw[NMIX];
+  unsigned mixrow[NMIX];
+  unsigned ssev[NSSE], ssecx[NSSE];
+  unsigned gwc0 = 0, gwc1 = 0;
+  int mixc0[NMIX], mixc1[NMIX];
+  unsigned ssec0[NSSE], ssec1[NSSE];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; ssec0[k] = 0; ssec1[k] = 0; }
+  unsigned mixbase[NMIX], ssebase[NSSE], mixst[NMIX], mixin[NMIX], ssest[NSSE];
+  int mixsrc[NMIX];
+  unsigned isl[N];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) { mixbase[k] = dummy; mixst[k] = dummy; mixin[k] = 0; mixsrc[k] = lane; }
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) { ssebase[k] = dummy; ssest[k] = dummy; }
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr CompK c = Chain::comp[i];
+    isl[i] = 0;
+    if constexpr (c.type == C_AVG || c.type == C_MIX2 || c.type == C_MIX || c.type == C_SSE)
+      isl[i] = lane_mask(ci == i && live);
+    if constexpr (c.type == C_MIX) {
+      static_assert(c.a2 + c.a3 <= 32, "MIX inputs must sit inside one half");
+      mixbase[c.slot] = (unsigned)c.t0 + hoff + 4u * (unsigned)min(ci, (int)c.a3 - 1);
+      ZPQ_OPAQUE(mixbase[c.slot]);
+      mixin[c.slot] = lane_mask(ci < (int)c.a3 && live);
+      mixst[c.slot] = (ci < (int)c.a3 && live) ? (unsigned)c.t0 + hoff + 4u * (unsigned)ci : dummy;
+      ZPQ_OPAQUE(mixst[c.slot]);
+      mixsrc[c.slot] = (lane & 32) | ((ci + (int)c.a2) & 31);
+    } else if constexpr (c.type == C_SSE) {
+      ssebase[c.slot] = (unsigned)c.t0 + hoff + 4u * (unsigned)ci;
+      ZPQ_OPAQUE(ssebase[c.slot]);
+      ssest[c.slot] = (ci == 0 && live) ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(ssest[c.slot]);
+    }
+  });
+  const unsigned m_lane0 = lane_mask(ci == 0 && live);
+  unsigned rw = G32(goff);
+  unsigned dtv = 0;
+  int sq = 0;
+  unsigned ssetr[NSSE], ssedt[NSSE];
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) { ssetr[k] = 0; ssedt[k] = 0; }
+  unsigned hmix[NMIX], hsse[NSSE];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) hmix[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) hsse[k] = 0;
+  int pdiff = 0;
+  int ylast = 0;
+
+  int c8 = 1, hmap4 = 1;
+  unsigned low = 1, high = 0xFFFFFFFFu;
+  unsigned steps = 0;
+  int status = 0;
+
+  auto g_index = [&](int c8x, int hm4x) __attribute__((always_inline)) -> unsigned {
+    return (is_cm ? (h ^ (unsigned)hm4x) : (h + (unsigned)(c8x & (int)a5))) & gmask;
+  };
+
+  // ---- before [A]: everything of this bit that does not need the row components' predictions
+  auto pre = [&](auto bitc) __attribute__((always_inline)) {
+    constexpr int B = decltype(bitc)::value;
+    constexpr bool pf_now = B > 0;
+    constexpr bool last_of_nibble = B == 3;
+    const int c8a = c8 * 2, c8b = c8 * 2 + 1;
+    const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+    const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                    : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+    unsigned gw;
+    gidx = g_index(c8, hmap4);
+    if constexpr (pf_now) {
+      gw = ylast ? gwc1 : gwc0;
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        if constexpr (c.type == C_MIX && mix_pf(c)) mixw[c.slot] = ylast ? mixc1[c.slot] : mixc0[c.slot];
+        if constexpr (c.type == C_SSE && sse_pf(c)) ssev[c.slot] = ylast ? ssec1[c.slot] : ssec0[c.slot];
+      });
+      if constexpr (Chain::ANY_NONPF_GL) {
+        if (gl && !pf_lane && !resident) gw = G32(goff + 4u * gidx);
+      }
+    } else {
+      gw = G32(goff + 4u * gidx);
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        if constexpr (c.type == C_MIX && mix_pf(c)) {
+          const unsigned r = ((hmix[c.slot] + (unsigned)(c8 & 255)) & c.mask0) * c.stride;
+          mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * r);
+        }
+        if constexpr (c.type == C_SSE && sse_pf(c)) {
+          const unsigned cx0 = ((hsse[c.slot] + (unsigned)c8) * 32u) & c.mask0;
+          ssev[c.slot] = G32(ssebase[c.slot] + 4u * cx0);
+        }
+      });
+    }
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr CompK c = Chain::comp[decltype(ic)::value];
+      if constexpr (c.type == C_MIX) {
+        const unsigned hi = hmix[c.slot];
+        mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.stride;
+        if constexpr (mix_pf(c)) {
+          mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.stride));
+          mixc1[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.stride));
+        } else {
+          mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
+        }
+      } else if constexpr (c.type == C_SSE) {
+        const unsigned hi = hsse[c.slot];
+        ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
+        if constexpr (sse_pf(c)) {
+          ssec0[c.slot] = G32(ssebase[c.slot] + 4u * (((hi + (unsigned)c8a) * 32u) & c.mask0));
+          ssec1[c.slot] = G32(ssebase[c.slot] + 4u * (((hi + (unsigned)c8b) * 32u) & c.mask0));
+        } else {
+          ssev[c.slot] = G32(ssebase[c.slot] + 4u * ssecx[c.slot]);
+        }
+      }
+    });
+    {
+      const unsigned ia = g_index(c8a, hm4a) & m_pf, ib = g_index(c8b, hm4b) & m_pf;
+      gwc0 = G32(goff + 4u * ia);
+      gwc1 = G32(goff + 4u * ib);
+    }
+    gw = sp_blend(m_res, rw, gw);
+    // MATCH
+    const bool m_on = is_match && ra != 0;
+    rc = m_on ? ((mpred >> (7 - B)) & 1u) : rc;
+    const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
+    v0 = gw;
+    const unsigned sx = sp_blend(m_match, msx, v0 >> 17);
+    const int st = sp_stretch(T, sx & 32767u);
+    p = (int)sp_blend(m_ctx, (unsigned)st, (unsigned)p);
+    dtv = (unsigned)T.dt[v0 & 0x3ffu];
+  };
+
+  // ---- after [A]: the dependent components, the final probability
+  auto chain = [&]() __attribute__((always_inline)) -> unsigned {
+    const unsigned px = L32(xoff);
+    p = (int)sp_blend(m_rowc, px, (unsigned)p);
+    DualDep<Chain, 0>::predict(T, upper, isl, mixin, mixsrc, p, (int)v0, 0, mixw, ssev, ssecx, ssetr, ssedt, pdiff);
+    sq = sp_squash(T, sp_clamp2k(p));
+    return dual_bcu((unsigned)sq, N - 1, upper);
+  };
+
+  // ---- after [B]: update of this wavefront's components (Predictor::update0 cases CM, MIX2, MATCH, MIX, SSE)
+  auto update = [&](auto bitc, int y) __attribute__((always_inline)) {
+    constexpr int B = decltype(bitc)::value;
+    constexpr bool byte_done = B == 7;
+    const unsigned count = v0 & 0x3ffu;
+    const int yq = y * 32767;
+    const int err = yq - sq;
+    const int errcm = yq - (int)(v0 >> 17);
+    const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+    const int err2 = __mul24(err, (int)a4) >> 5;
+    const int w2 = min(max((int)v0 + (sp_mad24(err2, pdiff, 1 << 12) >> 13), 0), 65535);
+    const unsigned gnew = sp_blend(m_cm, cm_new, (unsigned)w2);
+    G32(goff + 4u * gidx) = gnew;
+    rw = gnew;
+    ra = (is_match && (int)rc != y) ? 0u : ra;
+    if (byte_done && is_match) {
+      const unsigned mask = mask1;
+      G8(off1 + (rlimit & mask)) = (unsigned char)(c8 * 2 + y);
+      rlimit = (rlimit + 1) & mask;
+      const unsigned eo = off0 + 4u * (h & mask0);
+      if (ra == 0) {
+        rb = rlimit - G32(eo);
+        if (rb & mask)
+          while (ra < 255 && G8(off1 + ((rlimit - ra - 1) & mask)) == G8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+      } else ra += ra < 255;
+      G32(eo) = rlimit;
+      if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
+    }
+    DualDep<Chain, 0>::update(T, arena, upper, mixin, mixst, ssest, m_lane0, mixsrc, y, sq, p, mixw, mixrow, ssecx, ssetr, ssedt);
+    ylast = y;
+  };
+
+  // ---- the coder of this half (Decoder::decode, libzpaq.cpp:2159-2181), on the vector unit
+  unsigned rp = 0, nout = 0, curr = 0;
+  bool run = live;
+  bool eos = false;
+  if (live && (delta64 >> 32) != 0) { status = 8; run = false; }   // arenas of the workgroup not inside a 4 GiB window
+  // in two halves: the bit first -- the row wavefronts wait for it --, the range update and the bytes shifted in behind [B]
+  unsigned dmid = 0;
+  auto decode_bit = [&](unsigned pr) __attribute__((always_inline)) -> int {
+    if (!run) return 0;
+    if (curr < low || curr > high) { status = 2; run = false; return 0; }
+    dmid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
+    return curr <= dmid ? 1 : 0;
+  };
+  auto decode_shift = [&](int y) __attribute__((always_inline)) {
+    if (!run) return;
+    if (y) high = dmid; else low = dmid + 1;
+    while ((high ^ low) < 0x1000000u) {
+      high = high << 8 | 255u;
+      low = low << 8;
+      low += (low == 0);
+      if (rp >= in_len) { status = 6; run = false; break; }
+      curr = curr << 8 | in_ptr[rp++];
+    }
+  };
+  auto decode = [&](unsigned pr) __attribute__((always_inline)) -> int {
+    const int y = decode_bit(pr);
+    decode_shift(y);
+    return y;
+  };
+  auto run_hcomp = [&](unsigned input) __attribute__((always_inline)) -> int {
+#ifndef ZPQ_EMU
+    int e = 0;
+    if (run) e = Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    return e;
+#else
+    int e = 0;
+    if (run && ci == 0) e = Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    return dual_bc(e, 0, upper);
+#endif
+  };
+  auto any_running = [&]() __attribute__((always_inline)) -> bool {
+    unsigned r = 0;
+    for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
+    return r != 0;
+  };
+
+  for (int i = 0; i < 4; ++i) {
+    if (!run) break;
+    if (rp >= in_len) { status = 6; run = false; break; }
+    curr = curr << 8 | in_ptr[rp++];
+  }
+  if (run && nout >= out_cap) run = false;
+  if (ci == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
+  ZPQ_TEAM_BARRIER();                                        // [S]
+  bool any = any_running();
+  while (any) {
+    int ch = 1;
+    const int flag = decode(0);                               // end-of-stream flag, coded with p = 0
+    if (run && flag) { eos = true; if (curr != 0) status = 2; run = false; }
+    static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
+      constexpr int B = decltype(bitc)::value;
+      pre(bitc);
+      ZPQ_TEAM_BARRIER();                                    // [A] the row components' predictions are in LDS
+      const unsigned pr = chain() * 2u + 1u;
+      const int y = decode_bit(pr);
+      if (ci == 0) L32((unsigned)kTeamY) = (unsigned)y;
+      ZPQ_TEAM_BARRIER();                                    // [B]
+      decode_shift(y);
+      ch += ch + y;
+      update(bitc, y);
+      c8 += c8 + y;
+      if constexpr (B == 7) {
+        const int e = run_hcomp((unsigned)(c8 - 256));
+        if (run && e) { status = e; run = false; }
+        if (run) {
+          if (ci == 0) out_ptr[nout] = (unsigned char)(ch - 256);
+          ++nout;
+          ++steps;
+          if (nout >= out_cap) run = false;
+        }
+        if (ci == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
+        ZPQ_TEAM_BARRIER();                                  // [C]
+        any = any_running();
+        h = vm_H[(unsigned)ci & Chain::HMASK];
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          constexpr CompK c = Chain::comp[i];
+          if constexpr (c.type == C_MIX) hmix[c.slot] = dual_bcu(h, i, upper);
+          if constexpr (c.type == C_SSE) hsse[c.slot] = dual_bcu(h, i, upper);
+        });
+        hmap4 = 1;
+        c8 = 1;
+      } else if constexpr (B == 3) {
+        hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
+        if (run) ++steps;
+      } else {
+        hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + y) & 0xf);
+        if (run) ++steps;
+      }
+    });
+  }
+  if (ci == 0 && live) {
+    res[rslot].out_len = nout;
+    res[rslot].consumed = eos ? rp : 0;
+    res[rslot].status = status;
+    res[rslot].steps = steps;
+  }
+}
+
+// =====================================================================================================================
+template <class Chain>
+__device__ __forceinline__ void spec_team_decode_body(const BlockJob* jobs, BlockResult* res, unsigned nblocks,
+                                                      const DeviceTables* tb) {
+  constexpr int N = Chain::N;
+  static_assert(team_map<Chain>().ok, "chain not for the lockstep decoder");
+  static_assert(Chain::WAVES == 8, "the chain's LDS plan must be the one of the 8-blocks-per-workgroup shape");
+  constexpr int kRegion = spec_wave_lds_bytes(8);
+  constexpr int RL = team_row_lanes<Chain>();
+  constexpr int NRW = kTeamBlocks / (64 / RL);                // row wavefronts
+  static_assert((int)sizeof(SpecTables) + kTeamBlocks * kRegion <= kSpecLdsBudget, "LDS budget");
+
+  __shared__ SpecTables T;
+  __shared__ __attribute__((aligned(16))) unsigned char wave_lds[kTeamBlocks][kRegion];
+  for (unsigned i = threadIdx.x; i < 16384u; i += blockDim.x) T.stretch_hi[i] = tb->stretch[16384u + i];
+  for (unsigned i = threadIdx.x; i < 1344u; i += blockDim.x) T.squash_mid[i] = tb->squash[1376u + i];
+  for (unsigned i = threadIdx.x; i < 1024u; i += blockDim.x) { T.dt[i] = tb->dt[i]; T.ns[i] = tb->ns[i]; }
+  for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) T.dt2k[i] = (uint16_t)tb->dt2k[i];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  lds_u8* const lds0 = (lds_u8*)&wave_lds[0][0];
+  const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
+  // side tables -> LDS, H cleared, dummy and exchange words zeroed: the threads of the workgroup, block by block
+  for (int bw = 0; bw < kTeamBlocks; ++bw) {
+    lds_u8* const wl = lds0 + (unsigned)(bw * kRegion);
+    const unsigned b = wg0 + (unsigned)bw;
+    if (b < nblocks) {
+      const g_u8* const arena_b = (const g_u8*)jobs[b].arena;
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        if constexpr (c.lds >= 0 && (c.type == C_ICM || c.type == C_ISSE)) {
+          constexpr unsigned words = c.type == C_ICM ? 256 : 512;
+          const g_u32* src = (const g_u32*)(arena_b + (unsigned)c.t0);
+          lds_u32* dst = (lds_u32*)(wl + c.lds);
+          for (unsigned k = threadIdx.x; k < words; k += blockDim.x) dst[k] = src[k];
+        }
+      });
+      for (unsigned k = threadIdx.x; k <= Chain::HMASK; k += blockDim.x) ((lds_u32*)(wl + Chain::H_LDS))[k] = 0;
+    }
+    for (unsigned k = threadIdx.x; k < 128u; k += blockDim.x) ((lds_u32*)(wl + (kRegion - 512)))[k] = 0;
+  }
+  __syncthreads();
+  if (wave < NRW) team_rows<Chain>(T, lds0, jobs, nblocks, wave, lane);
+  else team_mixers<Chain>(T, lds0, jobs, res, nblocks, wave - NRW, lane);
+}
+
+}  // namespace zpq

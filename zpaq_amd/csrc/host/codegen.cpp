@@ -185,7 +185,15 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with
 
 }  // namespace
 
-bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, bool dual) {
+int team_threads(const zpq_plan& plan) {
+  int rows = 0;
+  for (uint32_t i = 0; i < plan.hdr().n; ++i) rows += plan.comps()[i].type == C_ICM || plan.comps()[i].type == C_ISSE;
+  return rows <= 16 ? 384 : 512;
+}
+
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, int shape) {
+  const bool team = shape == 2;
+  const bool dual = shape == 1 || team;          // (the lockstep decoder's mixer wavefronts are the dual kernel's: same limits)
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
@@ -198,13 +206,25 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
     if (n > 32) { why_not = "more than 32 components"; return false; }
     if (ph.arena_bytes >= (1ull << 31)) { why_not = "model state of 2 GiB or more per block"; return false; }
   }
+  if (team) {
+    if (ph.arena_bytes * 8 >= (1ull << 32)) { why_not = "eight blocks' model state does not fit a 4 GiB window"; return false; }
+    if (4u * (ph.hmask + 1) > 4096u) { why_not = "H does not fit the LDS"; return false; }
+    int prev_row = -1;
+    for (int i = 0; i < n; ++i) {
+      if (comp[i].type == C_ISSE && (prev_row < 0 || comp[i].a2 != (uint32_t)prev_row)) {
+        why_not = "an ISSE that is not fed by the ICM / ISSE before it";
+        return false;
+      }
+      if (comp[i].type == C_ICM || comp[i].type == C_ISSE) prev_row = i;
+    }
+  }
   const int wave_lds = spec_wave_lds_bytes(waves);          // LDS of ONE block
   int lds_used = 0, h_lds = -1;
   const int h_bytes = (int)(4u * (ph.hmask + 1));
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
-       "#include \"" << (dual ? "spec_dual_kernel.h" : "spec_kernel.h") << "\"\n"
+       "#include \"" << (team ? "spec_team_kernel.h" : (dual ? "spec_dual_kernel.h" : "spec_kernel.h")) << "\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
   int nmix = 0, nsse = 0;
@@ -240,6 +260,15 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   const U8* prog = plan.blob.data() + ph.off_prog;
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
   const char* body = "zpq::spec_kernel_body";
+  if (team) {
+    o << "};\n"
+         "}  // namespace zpq_gen\n"
+         "extern \"C\" __global__ __launch_bounds__(" << team_threads(plan) << ") void zpq_spec_decode3(const zpq::BlockJob* jobs, "
+         "zpq::BlockResult* res, unsigned nblocks, const zpq::DeviceTables* tb) {\n"
+         "  zpq::spec_team_decode_body<zpq_gen::Chain>(jobs, res, nblocks, tb);\n}\n";
+    source = o.str();
+    return true;
+  }
   if (dual) {
     o << "};\n"
          "}  // namespace zpq_gen\n"

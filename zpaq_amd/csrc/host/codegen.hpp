@@ -15,8 +15,12 @@ static const int kCodegenVersion = 5;
 // untranslatable HCOMP): such plans run on the generic kernels.
 // `waves` = blocks per workgroup the kernel is laid out for (4: every side table that fits 30 KiB in LDS,
 // one workgroup per CU; 8: half the LDS per block, two wavefronts per SIMD)
-// dual: the decoder with two blocks per wavefront (device/spec_dual_kernel.h; chains of up to 32 components, waves = 8's LDS plan)
-bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, bool dual = false);
+// shape 1 ("dual"): the decoder with two blocks per wavefront (device/spec_dual_kernel.h; chains of up to 32 components, waves = 8's LDS plan)
+// shape 2 ("team"): the decoder with the 8 blocks of a workgroup in lockstep, ICM / ISSE components on row wavefronts and the
+//                   rest on mixer wavefronts (device/spec_team_kernel.h; the same LDS plan; see team_threads for the workgroup size)
+bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, int shape = 0);
+// threads per workgroup of the lockstep decoder for this chain (384: up to 16 ICM / ISSE components, 512: up to 32)
+int team_threads(const zpq_plan& plan);
 
 // ---- pipelined encoder (device/pipe_kernel.h) ----
 // Dataflow plan of a chain: the level of every unit, the stream/state layout of one group of blocks and the

@@ -85,6 +85,21 @@ def dual_source_and_key(header):
     return buf.value.decode(), key.value.decode()
 
 
+def team_source_and_key(header):
+    """The lockstep decoder (device/spec_team_kernel.h): source + cache key, or (None, reason)."""
+    import zpaq_amd as z
+    L = z.lib()
+    L.zpq_plan_spec_team_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p]
+    p = z.Plan(header)
+    buf = C.create_string_buffer(4 << 20)
+    ln = C.c_size_t(0)
+    key = C.create_string_buffer(41)
+    rc = L.zpq_plan_spec_team_source(p._h, buf, len(buf), C.byref(ln), key)
+    if rc != 0:
+        return None, L.zpq_last_error().decode()
+    return buf.value.decode(), key.value.decode()
+
+
 def pipe_source_and_key(header, mode=0):
     """The pipelined encoder of this header (device/pipe_kernel.h) in one of its two shapes (mode 0 throughput, 1 latency):
     source + cache key, or (None, reason)."""
@@ -174,10 +189,11 @@ def main(verbose=True, clean=True):
             if src is not None and key not in seen:
                 seen.add(key)
                 jobs.append((src, key, cache, inc))
-        src, key = dual_source_and_key(h)
-        if src is not None and key not in seen:
-            seen.add(key)
-            jobs.append((src, key, cache, inc))
+        for variant in (dual_source_and_key, team_source_and_key):
+            src, key = variant(h)
+            if src is not None and key not in seen:
+                seen.add(key)
+                jobs.append((src, key, cache, inc))
         for waves in ("4", "8"):
             os.environ["ZPAQ_AMD_SPEC_WAVES"] = waves
             src, key = source_and_key(h)
