@@ -1056,6 +1056,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
       HIP_CHECK(hipEventRecord(sha_done, e.side[0]));
     }
     Timing before = e.last;
+    const auto wave_t0 = std::chrono::steady_clock::now();
     e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
                e.stream, true);
@@ -1070,6 +1071,12 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     }
     HIP_CHECK(hipMemcpyAsync(res.data(), e.results.p, cnt * sizeof(BlockResult), hipMemcpyDeviceToHost, e.stream));
     HIP_CHECK(hipStreamSynchronize(e.stream));
+    if (getenv("ZPAQ_AMD_LOG")) {     // one line per device batch: what a caller-side pool of threads really hands over
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wave_t0).count();
+      fprintf(stderr, "[zpaq_amd] %s batch of %zu blocks (%llu bytes in): %zu launch group(s), kernel kind %d mode %d, init %.1f ms, "
+              "coding %.1f ms, launch-to-results %.1f ms\n", decode ? "decode" : "encode", cnt, (unsigned long long)in_bytes, groups.size(),
+              e.last_kind, groups.empty() ? 0 : groups[0].pick.mode, e.last.init_ms, e.last.code_ms, ms);
+    }
     for (size_t i = 0; i < sh_of.size(); ++i) memcpy(blocks[sh_of[i]].sha1_out, digests.data() + 20 * i, 20);
     if (!segtab.empty()) {
       HIP_CHECK(hipMemcpyAsync(segtab.data(), e.segs.p, segtab.size() * sizeof(SegRange), hipMemcpyDeviceToHost, e.stream));

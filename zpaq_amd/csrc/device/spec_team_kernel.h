@@ -293,13 +293,28 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
 }
 
 // =====================================================================================================================
-// MIXER wavefront: spec_dual_kernel.h without the ICM / ISSE work
+// MIXER wavefront: two blocks per wavefront, lane = (block, component) as in spec_dual_kernel.h, without the ICM / ISSE
+// work -- and with every DEPENDENT component (AVG, MIX2, MIX, SSE) computed redundantly by all 32 lanes of its half:
+// a MIX's dot product ends in a half-wide sum anyway, and what follows it (MIX2, SSE, the final MIX2, squash, the coder)
+// then runs on values every lane of the half already has, with no broadcast (two v_readlane + moves + select each) between
+// its stages.  MIX2 weights are fetched by all lanes of the half from one address (one transaction), both candidates of the
+// next bit like the MIX / SSE rows.
+constexpr bool team_dep_type(unsigned t) { return t == C_AVG || t == C_MIX2 || t == C_MIX || t == C_SSE; }
+template <class Chain>
+constexpr int team_mix2_slot(int i) {
+  int s = 0;
+  for (int k = 0; k < i; ++k) s += Chain::comp[k].type == C_MIX2;
+  return s;
+}
+constexpr bool mix2_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u; }
+
 template <class Chain, class TT>
 __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks,
                                             int tw, int lane) {
   constexpr int N = Chain::N;
   constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
   constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
+  constexpr int NMIX2 = team_mix2_slot<Chain>(N) > 0 ? team_mix2_slot<Chain>(N) : 1;
   constexpr int kRegion = spec_wave_lds_bytes(8);
   const int ci = lane & 31;
   const bool upper = lane >= 32;
@@ -318,7 +333,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
 
   const unsigned dummy = (unsigned)Chain::OFF_RUN;
-  unsigned a4 = 0, a5 = 0, limit = 0, mask0 = 0, mask1 = 63;
+  unsigned limit = 0, mask0 = 0, mask1 = 63;
   unsigned off0 = dummy, off1 = dummy;
   unsigned ctype = 0;
 #pragma unroll
@@ -326,9 +341,8 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     if (ci == i && live) {
       const CompK c = Chain::comp[i];
       ctype = c.type;
-      a4 = c.a4; a5 = c.a5;
       limit = c.limit; mask0 = c.mask0;
-      if (c.type != C_ICM && c.type != C_ISSE) {
+      if (c.type == C_CM || c.type == C_MATCH) {
         off0 = (unsigned)c.t0 + hoff;
         if (c.type == C_MATCH) { off1 = (unsigned)c.t1 + hoff; mask1 = c.mask1; }
       }
@@ -344,21 +358,19 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   g_u32* const vm_R = (g_u32*)(arena + (unsigned)Chain::OFF_R + hoff);
   lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
 
-  const bool is_cm = ctype == C_CM, is_match = ctype == C_MATCH, is_mix2 = ctype == C_MIX2;
+  const bool is_cm = ctype == C_CM, is_match = ctype == C_MATCH;
   const bool is_rowc = ctype == C_ICM || ctype == C_ISSE;     // predicted by the row wavefronts
   const bool is_ctx = is_cm || is_match;
-  const bool gl = is_cm || is_mix2;
-  const bool pf_lane = is_cm ? mask0 >= 511u : (is_mix2 && a5 == 255u && mask0 >= 255u);
-  const bool resident = gl && mask0 == 0u;
-  const unsigned goff = gl ? off0 : dummy;
-  const unsigned gmask = gl ? mask0 : 0u;
+  const bool pf_lane = is_cm && mask0 >= 511u;
+  const unsigned goff = is_cm ? off0 : dummy;
+  const unsigned gmask = is_cm ? mask0 : 0u;
   auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
     unsigned m = x ? 0xFFFFFFFFu : 0u;
     ZPQ_OPAQUE(m);
     return m;
   };
-  const unsigned m_cm = lane_mask(is_cm), m_match = lane_mask(is_match), m_ctx = lane_mask(is_ctx);
-  const unsigned m_res = lane_mask(resident), m_pf = lane_mask(pf_lane), m_rowc = lane_mask(is_rowc);
+  const unsigned m_match = lane_mask(is_match), m_ctx = lane_mask(is_ctx);
+  const unsigned m_pf = lane_mask(pf_lane), m_rowc = lane_mask(is_rowc);
   const unsigned xoff = (unsigned)kTeamX + 4u * (unsigned)ci;
 
   unsigned gidx = 0, h = 0;
@@ -369,29 +381,34 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   });
   unsigned v0 = 0;
   unsigned ra = 0, rb = 0, rc = 0, rlimit = 0, mpred = 0, mdd = 0;
-  int mixw[NMIX];
+  int mixw[NMIX], mixp[NMIX];                                // lane t: weight t of the selected row, the input it multiplies
   unsigned mixrow[NMIX];
   unsigned ssev[NSSE], ssecx[NSSE];
   unsigned gwc0 = 0, gwc1 = 0;
   int mixc0[NMIX], mixc1[NMIX];
   unsigned ssec0[NSSE], ssec1[NSSE];
+  int m2w[NMIX2], m2c0[NMIX2], m2c1[NMIX2], m2d[NMIX2];     // MIX2: weight (every lane of the half), candidates, p[j] - p[k]
+  unsigned m2idx[NMIX2];
 #pragma unroll
-  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
+  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixp[k] = 0; mixrow[k] = 0; mixc0[k] = 0; mixc1[k] = 0; }
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssev[k] = 0; ssecx[k] = 0; ssec0[k] = 0; ssec1[k] = 0; }
-  unsigned mixbase[NMIX], ssebase[NSSE], mixst[NMIX], mixin[NMIX], ssest[NSSE];
+#pragma unroll
+  for (int k = 0; k < NMIX2; ++k) { m2w[k] = 0; m2c0[k] = 0; m2c1[k] = 0; m2d[k] = 0; m2idx[k] = 0; }
+  unsigned mixbase[NMIX], ssebase[NSSE], mixst[NMIX], mixin[NMIX], ssest[NSSE], m2base[NMIX2], m2st[NMIX2];
   int mixsrc[NMIX];
   unsigned isl[N];
 #pragma unroll
   for (int k = 0; k < NMIX; ++k) { mixbase[k] = dummy; mixst[k] = dummy; mixin[k] = 0; mixsrc[k] = lane; }
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssebase[k] = dummy; ssest[k] = dummy; }
+#pragma unroll
+  for (int k = 0; k < NMIX2; ++k) { m2base[k] = dummy; m2st[k] = dummy; }
   static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     constexpr CompK c = Chain::comp[i];
     isl[i] = 0;
-    if constexpr (c.type == C_AVG || c.type == C_MIX2 || c.type == C_MIX || c.type == C_SSE)
-      isl[i] = lane_mask(ci == i && live);
+    if constexpr (team_dep_type(c.type)) isl[i] = lane_mask(ci == i && live);
     if constexpr (c.type == C_MIX) {
       static_assert(c.a2 + c.a3 <= 32, "MIX inputs must sit inside one half");
       mixbase[c.slot] = (unsigned)c.t0 + hoff + 4u * (unsigned)min(ci, (int)c.a3 - 1);
@@ -405,31 +422,36 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       ZPQ_OPAQUE(ssebase[c.slot]);
       ssest[c.slot] = (ci == 0 && live) ? (unsigned)c.t0 + hoff : dummy;
       ZPQ_OPAQUE(ssest[c.slot]);
+    } else if constexpr (c.type == C_MIX2) {
+      constexpr int k2 = team_mix2_slot<Chain>(i);
+      m2base[k2] = live ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(m2base[k2]);
+      m2st[k2] = (ci == 0 && live) ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(m2st[k2]);
+      if constexpr (c.mask0 == 0u) m2w[k2] = (int)G32(m2base[k2]);       // a table of one weight never leaves its register
     }
   });
   const unsigned m_lane0 = lane_mask(ci == 0 && live);
-  unsigned rw = G32(goff);
   unsigned dtv = 0;
-  int sq = 0;
   unsigned ssetr[NSSE], ssedt[NSSE];
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) { ssetr[k] = 0; ssedt[k] = 0; }
-  unsigned hmix[NMIX], hsse[NSSE];
+  unsigned hmix[NMIX], hsse[NSSE], hm2[NMIX2];
 #pragma unroll
   for (int k = 0; k < NMIX; ++k) hmix[k] = 0;
 #pragma unroll
   for (int k = 0; k < NSSE; ++k) hsse[k] = 0;
-  int pdiff = 0;
+#pragma unroll
+  for (int k = 0; k < NMIX2; ++k) hm2[k] = 0;
+  int rep[N], rsq[N];                                         // dependent components: prediction and its squash, in every lane of the half
+#pragma unroll
+  for (int k = 0; k < N; ++k) { rep[k] = 0; rsq[k] = 0; }
   int ylast = 0;
 
   int c8 = 1, hmap4 = 1;
   unsigned low = 1, high = 0xFFFFFFFFu;
   unsigned steps = 0;
   int status = 0;
-
-  auto g_index = [&](int c8x, int hm4x) __attribute__((always_inline)) -> unsigned {
-    return (is_cm ? (h ^ (unsigned)hm4x) : (h + (unsigned)(c8x & (int)a5))) & gmask;
-  };
 
   // ---- before [A]: everything of this bit that does not need the row components' predictions
   auto pre = [&](auto bitc) __attribute__((always_inline)) {
@@ -441,21 +463,27 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
                                     : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
     unsigned gw;
-    gidx = g_index(c8, hmap4);
+    gidx = (h ^ (unsigned)hmap4) & gmask;
     if constexpr (pf_now) {
       gw = ylast ? gwc1 : gwc0;
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) mixw[c.slot] = ylast ? mixc1[c.slot] : mixc0[c.slot];
         if constexpr (c.type == C_SSE && sse_pf(c)) ssev[c.slot] = ylast ? ssec1[c.slot] : ssec0[c.slot];
+        if constexpr (c.type == C_MIX2 && mix2_pf(c)) {
+          constexpr int k2 = team_mix2_slot<Chain>(i);
+          m2w[k2] = ylast ? m2c1[k2] : m2c0[k2];
+        }
       });
       if constexpr (Chain::ANY_NONPF_GL) {
-        if (gl && !pf_lane && !resident) gw = G32(goff + 4u * gidx);
+        if (is_cm && !pf_lane) gw = G32(goff + 4u * gidx);
       }
     } else {
       gw = G32(goff + 4u * gidx);
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-        constexpr CompK c = Chain::comp[decltype(ic)::value];
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
         if constexpr (c.type == C_MIX && mix_pf(c)) {
           const unsigned r = ((hmix[c.slot] + (unsigned)(c8 & 255)) & c.mask0) * c.stride;
           mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * r);
@@ -464,10 +492,15 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
           const unsigned cx0 = ((hsse[c.slot] + (unsigned)c8) * 32u) & c.mask0;
           ssev[c.slot] = G32(ssebase[c.slot] + 4u * cx0);
         }
+        if constexpr (c.type == C_MIX2 && mix2_pf(c)) {
+          constexpr int k2 = team_mix2_slot<Chain>(i);
+          m2w[k2] = (int)G32(m2base[k2] + 4u * ((hm2[k2] + (unsigned)(c8 & 255)) & c.mask0));
+        }
       });
     }
     static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
-      constexpr CompK c = Chain::comp[decltype(ic)::value];
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
       if constexpr (c.type == C_MIX) {
         const unsigned hi = hmix[c.slot];
         mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.stride;
@@ -486,14 +519,23 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
         } else {
           ssev[c.slot] = G32(ssebase[c.slot] + 4u * ssecx[c.slot]);
         }
+      } else if constexpr (c.type == C_MIX2 && c.mask0 != 0u) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const unsigned hi = hm2[k2];
+        m2idx[k2] = (hi + (unsigned)(c8 & (int)c.a5)) & c.mask0;
+        if constexpr (mix2_pf(c)) {
+          m2c0[k2] = (int)G32(m2base[k2] + 4u * ((hi + (unsigned)(c8a & 255)) & c.mask0));
+          m2c1[k2] = (int)G32(m2base[k2] + 4u * ((hi + (unsigned)(c8b & 255)) & c.mask0));
+        } else {
+          m2w[k2] = (int)G32(m2base[k2] + 4u * m2idx[k2]);
+        }
       }
     });
     {
-      const unsigned ia = g_index(c8a, hm4a) & m_pf, ib = g_index(c8b, hm4b) & m_pf;
+      const unsigned ia = ((h ^ (unsigned)hm4a) & gmask) & m_pf, ib = ((h ^ (unsigned)hm4b) & gmask) & m_pf;
       gwc0 = G32(goff + 4u * ia);
       gwc1 = G32(goff + 4u * ib);
     }
-    gw = sp_blend(m_res, rw, gw);
     // MATCH
     const bool m_on = is_match && ra != 0;
     rc = m_on ? ((mpred >> (7 - B)) & 1u) : rc;
@@ -505,29 +547,68 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     dtv = (unsigned)T.dt[v0 & 0x3ffu];
   };
 
+  // prediction of component j for every lane of the half: a dependent component's is there already
+  auto pred_of = [&](auto jc) __attribute__((always_inline)) -> int {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (team_dep_type(Chain::comp[j].type)) return rep[j];
+    else return dual_bc(p, j, upper);
+  };
+
   // ---- after [A]: the dependent components, the final probability
   auto chain = [&]() __attribute__((always_inline)) -> unsigned {
     const unsigned px = L32(xoff);
     p = (int)sp_blend(m_rowc, px, (unsigned)p);
-    DualDep<Chain, 0>::predict(T, upper, isl, mixin, mixsrc, p, (int)v0, 0, mixw, ssev, ssecx, ssetr, ssedt, pdiff);
-    sq = sp_squash(T, sp_clamp2k(p));
-    return dual_bcu((unsigned)sq, N - 1, upper);
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_AVG) {
+        const int pj = pred_of(IC<(int)c.a1>{}), pk = pred_of(IC<(int)c.a2>{});
+        rep[i] = (pj * (int)c.a3 + pk * (256 - (int)c.a3)) >> 8;
+        p = (int)sp_blend(isl[i], (unsigned)rep[i], (unsigned)p);
+      } else if constexpr (c.type == C_MIX2) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const int pj = pred_of(IC<(int)c.a2>{}), pk = pred_of(IC<(int)c.a3>{});
+        m2d[k2] = pj - pk;
+        const int w = m2w[k2];
+        rep[i] = sp_mad24(w, pj, __mul24(65536 - w, pk)) >> 16;              // 17-bit x 12-bit products
+        rsq[i] = sp_squash(T, sp_clamp2k(rep[i]));
+        p = (int)sp_blend(isl[i], (unsigned)rep[i], (unsigned)p);
+      } else if constexpr (c.type == C_MIX) {
+        int pin = p;
+        if constexpr (c.a2 != 0) pin = __shfl(p, mixsrc[c.slot]);
+        mixp[c.slot] = pin;
+        const int x = (int)((unsigned)__mul24(mixw[c.slot] >> 8, pin) & mixin[c.slot]);
+        rep[i] = sp_clamp2k(dual_half_sum<(int)c.a3>(x, upper) >> 8);
+        rsq[i] = sp_squash(T, rep[i]);
+        p = (int)sp_blend(isl[i], (unsigned)rep[i], (unsigned)p);
+      } else if constexpr (c.type == C_SSE) {
+        int pq = pred_of(IC<(int)c.a2>{}) + 992;
+        pq = min(max(pq, 0), 1983);
+        const int wt = pq & 63;
+        pq >>= 6;
+        const int base = upper ? 32 : 0;
+        const unsigned e0 = __shfl(ssev[c.slot], base + pq), e1 = __shfl(ssev[c.slot], base + pq + 1);
+        rep[i] = sp_stretch(T, ((e0 >> 10) * (unsigned)(64 - wt) + (e1 >> 10) * (unsigned)wt) >> 13);
+        p = (int)sp_blend(isl[i], (unsigned)rep[i], (unsigned)p);
+        ssecx[c.slot] += (unsigned)(pq + (wt >> 5));
+        ssetr[c.slot] = (wt >> 5) ? e1 : e0;
+        ssedt[c.slot] = (unsigned)T.dt[ssetr[c.slot] & 0x3ffu];
+      }
+    });
+    constexpr unsigned tlast = Chain::comp[N - 1].type;
+    if constexpr (tlast == C_MIX2 || tlast == C_MIX) return (unsigned)rsq[N - 1];
+    else return (unsigned)sp_squash(T, sp_clamp2k(pred_of(IC<N - 1>{})));
   };
 
-  // ---- after [B]: update of this wavefront's components (Predictor::update0 cases CM, MIX2, MATCH, MIX, SSE)
+  // ---- after [B]: update of this wavefront's components (Predictor::update0 cases CM, MATCH, MIX2, MIX, SSE)
   auto update = [&](auto bitc, int y) __attribute__((always_inline)) {
     constexpr int B = decltype(bitc)::value;
     constexpr bool byte_done = B == 7;
     const unsigned count = v0 & 0x3ffu;
     const int yq = y * 32767;
-    const int err = yq - sq;
     const int errcm = yq - (int)(v0 >> 17);
     const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
-    const int err2 = __mul24(err, (int)a4) >> 5;
-    const int w2 = min(max((int)v0 + (sp_mad24(err2, pdiff, 1 << 12) >> 13), 0), 65535);
-    const unsigned gnew = sp_blend(m_cm, cm_new, (unsigned)w2);
-    G32(goff + 4u * gidx) = gnew;
-    rw = gnew;
+    G32(goff + 4u * gidx) = cm_new;                           // (lanes that are no CM: their dummy)
     ra = (is_match && (int)rc != y) ? 0u : ra;
     if (byte_done && is_match) {
       const unsigned mask = mask1;
@@ -542,7 +623,30 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       G32(eo) = rlimit;
       if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
     }
-    DualDep<Chain, 0>::update(T, arena, upper, mixin, mixst, ssest, m_lane0, mixsrc, y, sq, p, mixw, mixrow, ssecx, ssetr, ssedt);
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_MIX) {
+        const int err = ((yq - rsq[i]) * (int)c.a4) >> 4;
+        const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, mixp[c.slot], 1 << 12) >> 13));
+        const unsigned wo = mixst[c.slot] + ((4u * mixrow[c.slot]) & mixin[c.slot]);
+        *(g_i32*)(arena + wo) = w;
+      } else if constexpr (c.type == C_MIX2) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const int err2 = __mul24(yq - rsq[i], (int)c.a4) >> 5;
+        const int w2 = min(max(m2w[k2] + (sp_mad24(err2, m2d[k2], 1 << 12) >> 13), 0), 65535);   // 19-bit x 13-bit
+        if constexpr (c.mask0 == 0u) m2w[k2] = w2;
+        else *(g_i32*)(arena + m2st[k2] + ((4u * m2idx[k2]) & m_lane0)) = w2;
+      } else if constexpr (c.type == C_SSE) {
+        const unsigned e = ssecx[c.slot];
+        const unsigned v = ssetr[c.slot];
+        const unsigned cnt = v & 0x3ffu;
+        const int err = yq - (int)(v >> 17);
+        const unsigned prod = (unsigned)__mul24(err, (int)ssedt[c.slot]);
+        const unsigned nv = v + (prod & 0xFFFFFC00u) + (cnt < c.limit ? 1u : 0u);
+        *(g_u32*)(arena + ssest[c.slot] + ((4u * (e & c.mask0)) & m_lane0)) = nv;
+      }
+    });
     ylast = y;
   };
 
@@ -635,6 +739,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
           constexpr CompK c = Chain::comp[i];
           if constexpr (c.type == C_MIX) hmix[c.slot] = dual_bcu(h, i, upper);
           if constexpr (c.type == C_SSE) hsse[c.slot] = dual_bcu(h, i, upper);
+          if constexpr (c.type == C_MIX2 && c.mask0 != 0u) hm2[team_mix2_slot<Chain>(i)] = dual_bcu(h, i, upper);
         });
         hmap4 = 1;
         c8 = 1;
