@@ -10,4 +10,4 @@ tail -15 gpurun_out/r04/call2_pytest.txt
 (time timeout 300 python bench.py --mode decode --kernel 6 --cpu-seconds 0 --warmup 0 --steps 1 --verify-blocks 0) > gpurun_out/r04/bench_decode_team.json 2> gpurun_out/r04/bench_decode_team.err
 tail -c 1500 gpurun_out/r04/bench_decode_team.json; tail -5 gpurun_out/r04/bench_decode_team.err
 bash profiles/r04/cli_probe.sh > gpurun_out/r04/cli_probe.txt 2>&1
-tail -45 gpurun_out/r04/cli_probe.txt
+tail -70 gpurun_out/r04/cli_probe.txt

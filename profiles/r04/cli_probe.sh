@@ -9,4 +9,5 @@ for i in range(48):
 PY
 cd $W
 export GPU_MAX_HW_QUEUES=8 ZPAQ_AMD_LOG=1
-( time timeout 170 $GRAFT_REPO_ROOT/oracle/_ref/zpaq_amd_cli add ours.zpaq tree -method 50 -threads 16 ) 2>&1 | tail -40
+( time timeout 170 $GRAFT_REPO_ROOT/oracle/_ref/zpaq_amd_cli add ours.zpaq tree -method 50 -threads 16 ) > add.log 2>&1
+grep -F "[zpaq_amd]" add.log | head -60; grep -E "seconds|real" add.log

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N > 1 path of the framework -- block sharding, scatter of the
+"""CPU, world_size 2 and 3, gloo: the N > 1 path of the framework -- block sharding, scatter of the
 corpus, gather of variable-length archives in block order, max-over-ranks timing.  Every rank runs the PRODUCT's
 compress_blocks on its shard with method "2" (LZ77 without a context model: that path is host-only, so it works
 without a GPU) and rank 0 checks the gathered archives, in block order, against a single-process run, against a round
@@ -11,6 +11,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -69,15 +70,17 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_scatter_gather_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_gather_gloo(tmp_path, world):
+    """world_size 2 and 3 over 7 blocks: 4 + 3 and 3 + 2 + 2 -- uneven splits both ways."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), ZROOT=ROOT, GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))

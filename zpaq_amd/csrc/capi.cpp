@@ -36,7 +36,7 @@ int zpq_device_count(void) { return engine_device_count(); }
 void zpq_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi) { engine_shard_range(n, parts ? parts : 1, k, lo, hi); }
 void zpq_shutdown(void) { try { engine_shutdown(); } catch (...) {} }
 int zpq_set_state_budget(uint64_t bytes) { engine_set_budget(bytes); return ZPQ_OK; }
-int zpq_set_kernel(int which) { if (which < 0 || which > 5) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
+int zpq_set_kernel(int which) { if (which < 0 || which > 6) return ZPQ_E_ARG; engine_set_kernel(which); return ZPQ_OK; }
 
 int zpq_plan_create(const uint8_t* header, size_t hlen, zpq_plan** out) {
   ZPQ_TRY

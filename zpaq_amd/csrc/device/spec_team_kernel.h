@@ -51,6 +51,26 @@ namespace zpq {
   } while (0)
 #endif
 
+// -DZPQ_PROF: wavefront 0 of the row kind and of the mixer kind of workgroup 0 count the cycles of their phases
+// (s_memtime) and print them per coded bit at the end; compiled out otherwise.
+#if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
+#define TEAM_PROF_DECL unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_t_ = __builtin_readcyclecounter(), tp_n_ = 0;
+#define TEAM_PROF(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t_; tp_t_ = n_; } while (0)
+#define TEAM_PROF_BIT() (++tp_n_)
+#else
+#define TEAM_PROF_DECL
+#define TEAM_PROF(k) do {} while (0)
+#define TEAM_PROF_BIT() do {} while (0)
+#endif
+
+// Rows a bit's tables select are fetched one bit ahead (both candidates).  -DZPQ_TOUCH2 (default on): the four rows the
+// bit after that may select are touched as well -- loads whose data nobody reads -- so that the candidate fetch a bit later
+// finds its line in the cache instead of paying the full trip to HBM (page walk included) inside one bit's time.
+#ifndef ZPQ_TOUCH2
+#define ZPQ_TOUCH2 1
+#endif
+constexpr bool team_far_table(unsigned long long bytes) { return bytes > (256u << 10); }   // tables the caches do not hold
+
 template <int N>
 struct TeamMap {
   int nrows;
@@ -162,6 +182,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
   unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
   int c8 = 1, hmap4 = 1, ylast = 0;
+  TEAM_PROF_DECL
 
   bool any = true;
   {
@@ -236,7 +257,9 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
       }
       L32(xoff) = (unsigned)p;
+      TEAM_PROF(0);
       ZPQ_TEAM_BARRIER();                                    // [A] the mixers take over
+      TEAM_PROF(1);
       // ---- while the mixers work: what the update and the next bit will need
       sq = sp_squash(T, sp_clamp2k(p));
       const int pj = sp_shr1(p);
@@ -252,7 +275,10 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         sca0 = G32(soff + 4u * ea); sca1 = G32(soff + 4u * ea + 4u);
         scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
       }
+      TEAM_PROF(2);
       ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
+      TEAM_PROF(3);
+      TEAM_PROF_BIT();
       const int y = (int)L32((unsigned)kTeamY);
       // ---- update (Predictor::update0 cases ICM, ISSE)
       {
@@ -275,7 +301,9 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       }
       c8 += c8 + y;
       if constexpr (B == 7) {
+        TEAM_PROF(0);
         ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run: contexts of the next byte, who still runs
+        TEAM_PROF(4);
         h = ((lds_u32*)(wl + Chain::H_LDS))[(unsigned)cidx & Chain::HMASK];
         unsigned r = 0;
         for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
@@ -290,6 +318,11 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
     });
   }
   // (the last nibble's row is never written back: the block's model state is of no use after its last byte)
+#if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
+  if (blockIdx.x == 0 && wave == 0 && lane == 0 && tp_n_)
+    printf("[zpq team prof] rows   : bits=%llu cycles/bit: update+predict=%.0f wait[A]=%.0f idle-window work=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
+           tp_n_, (double)tp_[0] / tp_n_, (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_);
+#endif
 }
 
 // =====================================================================================================================
@@ -447,6 +480,8 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
 #pragma unroll
   for (int k = 0; k < N; ++k) { rep[k] = 0; rsq[k] = 0; }
   int ylast = 0;
+  unsigned tch = 0;                                           // what the touches loaded (kept alive, never used)
+  TEAM_PROF_DECL
 
   int c8 = 1, hmap4 = 1;
   unsigned low = 1, high = 0xFFFFFFFFu;
@@ -535,6 +570,26 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       const unsigned ia = ((h ^ (unsigned)hm4a) & gmask) & m_pf, ib = ((h ^ (unsigned)hm4b) & gmask) & m_pf;
       gwc0 = G32(goff + 4u * ia);
       gwc1 = G32(goff + 4u * ib);
+    }
+    if constexpr (ZPQ_TOUCH2 != 0 && B <= 5) {
+      // the rows of the bit after next: four per table that is too large for the caches
+      ZPQ_OPAQUE(tch);
+      unsigned t = 0;
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const unsigned c8f = (unsigned)(c8 * 4 + f);
+          if constexpr (c.type == C_MIX && mix_pf(c) && team_far_table(4ull * c.stride * (c.mask0 + 1ull)))
+            t ^= G32(mixbase[c.slot] + 4u * (((hmix[c.slot] + (c8f & 255u)) & c.mask0) * c.stride));
+          if constexpr (c.type == C_SSE && sse_pf(c) && team_far_table(4ull * (c.mask0 + 1ull)))
+            t ^= G32(ssebase[c.slot] + 4u * (((hsse[c.slot] + c8f) * 32u) & c.mask0));
+          if constexpr (c.type == C_MIX2 && mix2_pf(c) && team_far_table(4ull * (c.mask0 + 1ull)))
+            t ^= G32(m2base[team_mix2_slot<Chain>(i)] + 4u * ((hm2[team_mix2_slot<Chain>(i)] + (c8f & 255u)) & c.mask0));
+        }
+      });
+      tch = t;
     }
     // MATCH
     const bool m_on = is_match && ra != 0;
@@ -712,15 +767,21 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
       constexpr int B = decltype(bitc)::value;
       pre(bitc);
+      TEAM_PROF(0);
       ZPQ_TEAM_BARRIER();                                    // [A] the row components' predictions are in LDS
+      TEAM_PROF(1);
       const unsigned pr = chain() * 2u + 1u;
       const int y = decode_bit(pr);
       if (ci == 0) L32((unsigned)kTeamY) = (unsigned)y;
+      TEAM_PROF(2);
       ZPQ_TEAM_BARRIER();                                    // [B]
+      TEAM_PROF(3);
+      TEAM_PROF_BIT();
       decode_shift(y);
       ch += ch + y;
       update(bitc, y);
       c8 += c8 + y;
+      TEAM_PROF(4);
       if constexpr (B == 7) {
         const int e = run_hcomp((unsigned)(c8 - 256));
         if (run && e) { status = e; run = false; }
@@ -731,7 +792,9 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
           if (nout >= out_cap) run = false;
         }
         if (ci == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
+        TEAM_PROF(5);
         ZPQ_TEAM_BARRIER();                                  // [C]
+        TEAM_PROF(6);
         any = any_running();
         h = vm_H[(unsigned)ci & Chain::HMASK];
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
@@ -752,12 +815,19 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       }
     });
   }
+  ZPQ_KEEP2(tch, tch);
   if (ci == 0 && live) {
     res[rslot].out_len = nout;
     res[rslot].consumed = eos ? rp : 0;
     res[rslot].status = status;
     res[rslot].steps = steps;
   }
+#if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
+  if (blockIdx.x == 0 && tw == 0 && lane == 0 && tp_n_)
+    printf("[zpq team prof] mixers : bits=%llu cycles/bit: pre=%.0f wait[A]=%.0f chain+decode=%.0f wait[B]=%.0f update=%.0f hcomp/8=%.0f wait[C]/8=%.0f\n",
+           tp_n_, (double)tp_[0] / tp_n_, (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_,
+           (double)tp_[5] / tp_n_, (double)tp_[6] / tp_n_);
+#endif
 }
 
 // =====================================================================================================================
