@@ -3,7 +3,7 @@
 set -x
 mkdir -p gpurun_out/r04
 export GPU_MAX_HW_QUEUES=8
-for v in default "-DZPQ_TOUCH2=0" "-DZPQ_PROF"; do
+for v in default "-DZPQ_PROF"; do
   if [ "$v" = default ]; then unset ZPAQ_AMD_SPEC_DEFS; else export ZPAQ_AMD_SPEC_DEFS="$v"; fi
   n=$(echo "$v" | tr -c 'A-Za-z0-9\n' '_')
   (time timeout 240 python bench.py --mode decode --kernel 6 --blocks 2048 --block-bytes 262144 --cpu-seconds 0 --warmup 0 --steps 1 --verify-blocks 0 --decode-blocks 0) > gpurun_out/r04/team_$n.json 2> gpurun_out/r04/team_$n.err

@@ -341,6 +341,9 @@ constexpr int team_mix2_slot(int i) {
 }
 constexpr bool mix2_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u; }
 
+typedef unsigned long long __attribute__((aligned(1))) team_u64u;
+typedef __attribute__((address_space(1))) const team_u64u g_u64u;
+
 template <class Chain, class TT>
 __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks,
                                             int tw, int lane) {
@@ -414,6 +417,11 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   });
   unsigned v0 = 0;
   unsigned ra = 0, rb = 0, rc = 0, rlimit = 0, mpred = 0, mdd = 0;
+  // MATCH: what the end of a byte reads -- the index entry of the byte's context, the history behind the candidate it
+  // names, the byte a match predicts next -- has addresses known when the byte starts (pipe_kernel.h::pipe_match): fetched
+  // then (the entry, the continuing match's next byte) and half way (the 8 bytes behind the candidate, the byte at it)
+  unsigned mcmv = 0, mcont = 0, mcand_at = 0;
+  unsigned long long mcand = 0, mhist = 0;
   int mixw[NMIX], mixp[NMIX];                                // lane t: weight t of the selected row, the input it multiplies
   unsigned mixrow[NMIX];
   unsigned ssev[NSSE], ssecx[NSSE];
@@ -592,6 +600,15 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       tch = t;
     }
     // MATCH
+    if constexpr (B == 0) {
+      mcmv = G32(is_match ? off0 + 4u * (h & mask0) : dummy);
+      mcont = G8(is_match ? off1 + ((rlimit + 1u - rb) & mask1) : dummy);
+    } else if constexpr (B == 4) {
+      const unsigned cpos = (mcmv - 8u) & mask1;
+      const bool wraps = cpos + 8u > mask1 + 1u || mask1 < 15u;
+      mcand = *(g_u64u*)(arena + (is_match && !wraps ? off1 + cpos : dummy));
+      mcand_at = G8(is_match ? off1 + (mcmv & mask1) : dummy);
+    }
     const bool m_on = is_match && ra != 0;
     rc = m_on ? ((mpred >> (7 - B)) & 1u) : rc;
     const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
@@ -666,17 +683,42 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     G32(goff + 4u * gidx) = cm_new;                           // (lanes that are no CM: their dummy)
     ra = (is_match && (int)rc != y) ? 0u : ra;
     if (byte_done && is_match) {
+      // Predictor::update0 case MATCH at the end of a byte (libzpaq.cpp:1992-2006), from registers
       const unsigned mask = mask1;
-      G8(off1 + (rlimit & mask)) = (unsigned char)(c8 * 2 + y);
+      const unsigned byte = (unsigned)(c8 * 2 + y) & 255u;
+      const unsigned wpos = rlimit & mask;                     // where this byte goes
+      G8(off1 + wpos) = (unsigned char)byte;
+      mhist = mhist << 8 | byte;
       rlimit = (rlimit + 1) & mask;
       const unsigned eo = off0 + 4u * (h & mask0);
+      bool fresh = false;
       if (ra == 0) {
-        rb = rlimit - G32(eo);
-        if (rb & mask)
-          while (ra < 255 && G8(off1 + ((rlimit - ra - 1) & mask)) == G8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+        rb = rlimit - mcmv;
+        if (rb & mask) {
+          // 8 bytes behind the candidate against the last 8 bytes coded: legal when they do not wrap and were not touched
+          // by this byte's store (before 8 bytes have been coded `mhist` holds zeros where the reference reads the
+          // never-written end of the buffer); longer matches and the special cases take the reference's byte loop
+          const unsigned cpos = (mcmv - 8u) & mask;
+          const bool wraps = cpos + 8u > mask + 1u || mask < 15u;
+          const bool overlap = ((mcmv - 1u - wpos) & mask) < 8u;
+          unsigned m = 0;
+          if (!wraps && !overlap) {
+            const unsigned long long diff = __builtin_bswap64(mcand) ^ mhist;
+            m = diff ? (unsigned)(__builtin_ctzll(diff) >> 3) : 8u;
+          }
+          ra = m;
+          if (wraps || overlap || m == 8u)
+            while (ra < 255 && G8(off1 + ((rlimit - ra - 1) & mask)) == G8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+        }
+        fresh = true;
       } else ra += ra < 255;
       G32(eo) = rlimit;
-      if (ra != 0) { mpred = G8(off1 + ((rlimit - rb) & mask)); mdd = T.dt2k[ra]; }
+      if (ra != 0) {
+        const unsigned ppos = (rlimit - rb) & mask;            // = the candidate for a fresh match, the continuing position otherwise
+        const unsigned early = fresh ? mcand_at : mcont;
+        mpred = ppos == wpos ? byte : early;
+        mdd = T.dt2k[ra];
+      }
     }
     static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
@@ -710,6 +752,41 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   bool run = live;
   bool eos = false;
   if (live && (delta64 >> 32) != 0) { status = 8; run = false; }   // arenas of the workgroup not inside a 4 GiB window
+  // Coded bytes come from a window of 8 in registers, rebuilt once per input byte from a 16-byte fetch issued a byte
+  // earlier: a byte shifted into the coder is then no memory operation.  (Fetched where it is needed, it waits -- vmcnt
+  // counts in order -- for every candidate row requested just before it: a full trip to HBM, and with 8 blocks in lockstep
+  // some block needs a byte at almost every bit.)  Reads stay inside the input rounded up to 64 bytes, which the engine
+  // guarantees to be readable.
+  const unsigned in_lim = (in_len + 63u) & ~63u;
+  unsigned long long iwin = 0, if0 = 0, if1 = 0;
+  unsigned iavail = 0, ifpos = 0;
+  auto in_fetch = [&]() __attribute__((always_inline)) {      // the 16 bytes at the read position (or the last 16 readable ones)
+    ifpos = in_lim >= 16u ? min(rp, in_lim - 16u) : 0u;
+    if0 = *(g_u64u*)(in_ptr + ifpos);
+    if1 = *(g_u64u*)(in_ptr + ifpos + 8u);
+  };
+  auto in_window = [&]() __attribute__((always_inline)) {     // window <- what the last fetch holds from the read position on
+    const unsigned o = rp - ifpos;
+    const unsigned long long b0 = __builtin_bswap64(if0), b1 = __builtin_bswap64(if1);
+    const unsigned sh = (o & 7u) * 8u;
+    const unsigned long long lo = sh ? (b0 << sh) | (b1 >> (64u - sh)) : b0;
+    const unsigned long long hi = b1 << sh;
+    iwin = o < 8u ? lo : hi;
+    iavail = in_lim < 16u ? 0u : (o < 8u ? 8u : (o < 16u ? 16u - o : 0u));
+  };
+  auto in_byte = [&]() __attribute__((always_inline)) -> unsigned {     // the coded byte at rp (rp < in_len)
+    unsigned v;
+    if (iavail) {
+      v = (unsigned)(iwin >> 56);
+      iwin <<= 8;
+      --iavail;
+    } else {
+      v = in_ptr[rp];
+      ZPQ_OPAQUE(v);            // (waited for inside this rarely taken branch, not where the paths join)
+    }
+    ++rp;
+    return v;
+  };
   // in two halves: the bit first -- the row wavefronts wait for it --, the range update and the bytes shifted in behind [B]
   unsigned dmid = 0;
   auto decode_bit = [&](unsigned pr) __attribute__((always_inline)) -> int {
@@ -726,7 +803,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       low = low << 8;
       low += (low == 0);
       if (rp >= in_len) { status = 6; run = false; break; }
-      curr = curr << 8 | in_ptr[rp++];
+      curr = curr << 8 | in_byte();
     }
   };
   auto decode = [&](unsigned pr) __attribute__((always_inline)) -> int {
@@ -751,17 +828,21 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     return r != 0;
   };
 
+  if (run && in_len) { in_fetch(); in_window(); }
   for (int i = 0; i < 4; ++i) {
     if (!run) break;
     if (rp >= in_len) { status = 6; run = false; break; }
-    curr = curr << 8 | in_ptr[rp++];
+    curr = curr << 8 | in_byte();
   }
   if (run && nout >= out_cap) run = false;
   if (ci == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
   ZPQ_TEAM_BARRIER();                                        // [S]
   bool any = any_running();
+  if (run) in_fetch();
   while (any) {
     int ch = 1;
+    // the window for this byte's 9 decoding steps from the fetch of a byte ago, then the fetch for the next byte
+    if (run) { in_window(); in_fetch(); }
     const int flag = decode(0);                               // end-of-stream flag, coded with p = 0
     if (run && flag) { eos = true; if (curr != 0) status = 2; run = false; }
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
