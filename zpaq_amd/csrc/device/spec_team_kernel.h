@@ -63,11 +63,11 @@ namespace zpq {
 #define TEAM_PROF_BIT() do {} while (0)
 #endif
 
-// Rows a bit's tables select are fetched one bit ahead (both candidates).  -DZPQ_TOUCH2 (default on): the four rows the
+// Rows a bit's tables select are fetched one bit ahead (both candidates).  -DZPQ_TOUCH2=1 (off by default: measured -2 % on the MI355X, profiles/r04): the four rows the
 // bit after that may select are touched as well -- loads whose data nobody reads -- so that the candidate fetch a bit later
 // finds its line in the cache instead of paying the full trip to HBM (page walk included) inside one bit's time.
 #ifndef ZPQ_TOUCH2
-#define ZPQ_TOUCH2 1
+#define ZPQ_TOUCH2 0
 #endif
 constexpr bool team_far_table(unsigned long long bytes) { return bytes > (256u << 10); }   // tables the caches do not hold
 
