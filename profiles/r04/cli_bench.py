@@ -24,11 +24,13 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--files", type=int, default=1024)
+    ap.add_argument("--files", type=int, default=256)
     ap.add_argument("--work", default="/tmp/zpq_cli_bench")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04", "cli.json"))
     ap.add_argument("--threads", default="16,64,256")
     ap.add_argument("--ref-threads", default="16")
+    ap.add_argument("--extract-threads", default="64,256", help="ours: a block decodes at ~65 KB/s whatever the batch holds, so few threads crawl")
+    ap.add_argument("--timeout", type=float, default=400.0)
     a = ap.parse_args()
     import torch
     from zpaq_amd import corpus, corpus_torch
@@ -48,15 +50,26 @@ def main():
     total = a.files * bs
     rows = []
 
+    def save():          # after every row: a call that runs out of time keeps what it measured
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump({"files": a.files, "file_bytes": bs, "total_bytes": total, "nproc": os.cpu_count(), "rows": rows}, open(a.out, "w"), indent=1)
+
     def run(exe, args, label, threads):
         t0 = time.perf_counter()
-        r = subprocess.run([exe] + args + ["-threads", str(threads)], cwd=a.work, capture_output=True, text=True)
+        try:
+            r = subprocess.run([exe] + args + ["-threads", str(threads)], cwd=a.work, capture_output=True, text=True, timeout=a.timeout)
+        except subprocess.TimeoutExpired:
+            rows.append({"what": label, "threads": threads, "timeout_s": a.timeout})
+            print(json.dumps(rows[-1]), flush=True)
+            save()
+            return False
         wall = time.perf_counter() - t0
         row = {"what": label, "threads": threads, "wall_s": wall, "MBps": total / 1e6 / wall, "rc": r.returncode}
         if r.returncode:
             row["stderr"] = r.stderr[-600:]
         rows.append(row)
         print(json.dumps(row), flush=True)
+        save()
         return r.returncode == 0
 
     # a first small call of ours so that the one-off costs of a process (code objects, page-locked buffers) show up separately
@@ -70,10 +83,10 @@ def main():
         rows[-1]["archive_bytes"] = os.path.getsize(arc) if os.path.exists(arc) else None
     T0 = int(a.threads.split(",")[0])
     R0 = int(a.ref_threads.split(",")[0])
-    for T in [int(x) for x in a.threads.split(",")]:
+    for T in [int(x) for x in a.extract_threads.split(",")]:
         to = os.path.join(a.work, f"x_ours{T}")
         run(ours, ["extract", os.path.join(a.work, f"ref{R0}.zpaq"), "-to", to], "zpaq_amd_cli extract (the reference's archive)", T)
-        if T == T0:
+        if os.path.isdir(os.path.join(to, "tree")):
             c = filecmp.dircmp(tree, os.path.join(to, "tree"))
             _, mism, errs = filecmp.cmpfiles(tree, os.path.join(to, "tree"), c.common_files, shallow=False)
             rows[-1]["tree_identical"] = not (c.left_only or c.right_only or mism or errs)
@@ -83,8 +96,7 @@ def main():
     c = filecmp.dircmp(tree, os.path.join(to, "tree"))
     _, mism, errs = filecmp.cmpfiles(tree, os.path.join(to, "tree"), c.common_files, shallow=False)
     rows[-1]["tree_identical"] = not (c.left_only or c.right_only or mism or errs)
-    os.makedirs(os.path.dirname(a.out), exist_ok=True)
-    json.dump({"files": a.files, "file_bytes": bs, "total_bytes": total, "nproc": os.cpu_count(), "rows": rows}, open(a.out, "w"), indent=1)
+    save()
     shutil.rmtree(a.work, ignore_errors=True)
 
 

@@ -136,32 +136,6 @@ __device__ __forceinline__ uint4 pipe_settle(uint4 v) {
 
 typedef __attribute__((address_space(1))) uint2 g_u64v;
 
-// Touch: a load nobody waits for.  A lane-per-block unit walks its chunk byte by byte and fetches the table lines of byte
-// k + 1 while it works on byte k; with a trip to HBM at 1 - 2 us under load that lead alone bounds a byte's time from below
-// (2 048 bytes x the round trip = the step time of a small batch; at 1 024 blocks the requests in flight divided by the
-// latency = the transaction rate the round-3 profile measured).  The ENCODER knows every context of the chunk, so the
-// lines of byte k + ZPQ_PIPE_TOUCH can be requested already: the real fetch a few bytes later finds them in the L2.  The
-// destination register is written by the hardware and read by nobody; the load is issued from inline assembly so that the
-// compiler's vmcnt bookkeeping does not know it and never waits FOR it (its in-order waits for older loads are unaffected;
-// a wait for a younger one becomes stricter by the touches between -- they are as old as what is waited for).
-#ifndef ZPQ_PIPE_TOUCH
-#define ZPQ_PIPE_TOUCH 0
-#endif
-__device__ __forceinline__ void pipe_touch(unsigned& sink, const g_u8* p) {
-#ifndef ZPQ_EMU
-  asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
-#else
-  (void)sink; (void)p;
-#endif
-}
-__device__ __forceinline__ void pipe_touch_done(unsigned& sink) {     // before the register is given up
-#ifndef ZPQ_EMU
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
-#else
-  (void)sink;
-#endif
-}
-
 // One lane's view of its block, its chunk and the group's streams.
 template <class Chain>
 struct PipeLane {
@@ -411,19 +385,7 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
   lines(h, byte, ha, hb);
   uint4 a0 = L.A128(ht + ha), a1 = L.A128(ht + (ha ^ 16u)), a2 = L.A128(ht + (ha ^ 32u));
   uint4 b0 = L.A128(ht + hb), b1 = L.A128(ht + (hb ^ 16u)), b2 = L.A128(ht + (hb ^ 32u));
-  // touches: context and byte of position k + T are read one iteration before their lines are requested
-  constexpr unsigned T = ZPQ_PIPE_TOUCH;
-  unsigned sink = 0, hT = 0, bT = 0;
-  if constexpr (T > 0) { const unsigned kt = min(T, L.nb - 1u); hT = L.ctx(ci, kt); bT = L.byte_at(kt); }
   for (unsigned k = 0; k < L.nb; ++k) {
-    if constexpr (T > 0) {
-      unsigned ta, tb;
-      lines(hT, bT, ta, tb);
-      pipe_touch(sink, L.arena + ht + ta);
-      pipe_touch(sink, L.arena + ht + tb);
-      const unsigned kt = min(k + 1u + T, L.nb - 1u);
-      hT = L.ctx(ci, kt); bT = L.byte_at(kt);
-    }
     const unsigned k2 = min(k + 2u, L.nb - 1u);
     const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);          // streams run two bytes ahead ...
     // ... the table one byte ahead: the next byte's six candidates are fetched before this byte's two rows are
@@ -459,7 +421,6 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     ha = han; hb = hbn;
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
-  if constexpr (T > 0) pipe_touch_done(sink);
 }
 
 // CONS: a constant stream, so that consumers need no special case
@@ -552,14 +513,7 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
   const unsigned k1 = L.next(0);
   unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
   unsigned cmv = L.A32(off0 + 4u * (h & c.mask0));
-  constexpr unsigned T = (4ull * (c.mask0 + 1ull) > (256u << 10)) ? ZPQ_PIPE_TOUCH : 0;       // the index entry of byte k + T
-  unsigned sink = 0, hT = 0;
-  if constexpr (T > 0) hT = L.ctx(ci, min(T, L.nb - 1u));
   for (unsigned k = 0; k < L.nb; ++k) {
-    if constexpr (T > 0) {
-      pipe_touch(sink, L.arena + off0 + 4u * (hT & c.mask0));
-      hT = L.ctx(ci, min(k + 1u + T, L.nb - 1u));
-    }
     const unsigned k2 = min(k + 2u, L.nb - 1u);
     const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
     const unsigned eo = off0 + 4u * (h & c.mask0), eon = off0 + 4u * (h1 & c.mask0);
@@ -612,7 +566,6 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
     cmv = eon == eo ? rlimit : cmvn_mem;
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
-  if constexpr (T > 0) pipe_touch_done(sink);
   L.state(sw + 0) = ra; L.state(sw + 1) = rb; L.state(sw + 2) = rlimit;
   L.state(sw + 3) = mpred; L.state(sw + 4) = mdd; L.state(sw + 5) = rc;
   L.state(sw + 6) = (unsigned)hist; L.state(sw + 7) = (unsigned)(hist >> 32);
@@ -1504,17 +1457,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
 #pragma unroll
       for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
     }
-    // touches (tables the caches do not hold): the 8 rows of byte k + T; context and byte read an iteration earlier
-    constexpr unsigned T = (batch && 4ull * c.stride * (c.mask0 + 1ull) > (256u << 10)) ? ZPQ_PIPE_TOUCH : 0;
-    unsigned sink = 0, hT = 0, bT = 0;
-    if constexpr (T > 0) { const unsigned kt = min(T, L.nb - 1u); hT = L.ctx(ci, kt); bT = L.byte_at(kt); }
     for (unsigned k = 0; k < L.nb; ++k) {
-      if constexpr (T > 0) {
-#pragma unroll
-        for (int B = 0; B < 8; ++B) pipe_touch(sink, L.arena + row_of(hT, bT, B));
-        const unsigned kt = min(k + 1u + T, L.nb - 1u);
-        hT = L.ctx(ci, kt); bT = L.byte_at(kt);
-      }
       const unsigned k2 = min(k + 2u, L.nb - 1u);
       const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
       uint4 pv2[4];
@@ -1579,7 +1522,6 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
     }
-    if constexpr (T > 0) pipe_touch_done(sink);
   });
   }
 }
