@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <chrono>
+#include <functional>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -490,6 +491,7 @@ struct PipeRun {
   uint32_t light_threads;    // ... of the light kernel (= threads unless some of its units have a lane per bit position)
   bool consumes[6][6];
   int slack;
+  uint32_t chunk;            // input bytes per step
 };
 
 // ZPAQ_AMD_PIPE_PROFILE=1: run every unit type of every step alone on one stream between two events and print the
@@ -533,9 +535,21 @@ static void launch_pipe_profiled(Engine& e, std::vector<PipeRun>& runs, hipStrea
             kv.second.first / kv.second.second, kv.second.second);
 }
 
-static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
-  if (runs.empty()) return;
-  if (getenv("ZPAQ_AMD_PIPE_PROFILE")) { launch_pipe_profiled(e, runs, st); return; }
+// The tail of a batch's input may still be on its way when the first steps are launched (engine_code_host_on: the units
+// of step s read input bytes below (s + 1) x chunk only): `late` is called once, before the launches of the first step
+// that may read bytes from `from_byte` on; it enqueues the rest of the copy and returns the event the kernels have to wait for.
+struct LateInput {
+  uint32_t from_byte = 0;                       // 0: nothing is late
+  std::function<hipEvent_t()> arrive;
+};
+
+static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, LateInput* late = nullptr) {
+  if (runs.empty()) { if (late && late->from_byte) (void)late->arrive(); return; }
+  if (getenv("ZPAQ_AMD_PIPE_PROFILE")) {
+    if (late && late->from_byte) HIP_CHECK(hipStreamWaitEvent(st, late->arrive(), 0));
+    launch_pipe_profiled(e, runs, st);
+    return;
+  }
   for (auto& ps : e.pstream)
     if (!ps) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   uint32_t nsteps = 0;
@@ -577,7 +591,18 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
   Event fork;
   HIP_CHECK(hipEventRecord(fork, st));
   for (int k = 0; k < 6; ++k) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], fork, 0));
+  uint32_t late_step = 0xFFFFFFFFu;
+  if (late && late->from_byte) {
+    uint32_t maxc = 1;
+    for (auto& r : runs) maxc = std::max(maxc, r.chunk);
+    late_step = late->from_byte / maxc;          // the first step whose units may read a byte at or beyond from_byte
+  }
   for (uint32_t step = 0; step < nsteps; ++step) {
+    if (step == late_step) {
+      hipEvent_t arrived = late->arrive();
+      for (int k = 0; k < 6; ++k) if (used[k]) HIP_CHECK(hipStreamWaitEvent(e.pstream[k], arrived, 0));
+      late_step = 0xFFFFFFFFu;
+    }
     for (int k = 0; k < 6; ++k) {
       if (!used[k]) continue;
       for (int p = 0; p < 6; ++p) {
@@ -600,6 +625,7 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
       HIP_CHECK(hipEventRecord(*ev[k][step % R], e.pstream[k]));
     }
   }
+  if (late_step != 0xFFFFFFFFu) HIP_CHECK(hipStreamWaitEvent(st, late->arrive(), 0));     // (fewer steps than expected)
   for (int k = 0; k < 6; ++k)
     if (used[k] && nsteps) HIP_CHECK(hipStreamWaitEvent(st, *ev[k][(nsteps - 1) % R], 0));
   if (d_trace) {
@@ -619,7 +645,7 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st) {
 // so that each group is one launch (or one launch sequence).
 static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res,
                        const std::vector<LaunchGroup>& groups, uint32_t nb, uint64_t max_arena, hipStream_t st,
-                       bool timed) {
+                       bool timed, LateInput* late = nullptr) {
   Event ev0(true), ev1(true), ev2(true), ev3(true);
   // enough 256-thread groups per block to stream the arena at HBM rate
   uint64_t per = max_arena / (256 * 16 * 8) + 1;
@@ -652,6 +678,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.light_threads = (uint32_t)L.light_threads();
     memcpy(r.consumes, L.consumes, sizeof(r.consumes));
     r.slack = L.slack;
+    r.chunk = (uint32_t)L.C;
     r.grid[0] = (g.count + (uint32_t)L.hcomp_lanes - 1) / (uint32_t)L.hcomp_lanes;
     r.grid[1] = (uint32_t)L.rows.size() * ng;
     r.grid[2] = (uint32_t)L.light.size() * ng;
@@ -686,7 +713,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
     ++gi;
   }
-  launch_pipe(e, runs, st);
+  launch_pipe(e, runs, st, late);
   for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
     Event done;
     HIP_CHECK(hipEventRecord(done, e.side[k]));
@@ -1033,26 +1060,56 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
       i_off += ((uint64_t)hb.in_len + hb.prefix_len + 63) & ~63ull;
       o_off += ((uint64_t)hb.out_cap + 63) & ~63ull;
     }
-    {
-      // the gather is a gigabyte of memcpy for a full batch: one thread per 16 MiB, at most 8 (small batches: this thread alone)
+    // Gather + copy.  The pipelined encoder reads input byte k no earlier than step k / chunk, so for a batch of equally long
+    // blocks (the bulk case: compress() / compressBlocks over a cut-up stream) only the first kHeadBytes of every block are
+    // gathered and copied before the kernels are launched; the rest is gathered by helper threads while the first steps run
+    // and copied -- one strided copy -- when the launch loop reaches the first step that may read it (LateInput).
+    static const uint32_t kHeadBytes = 64u << 10;
+    const uint32_t len0 = cnt ? blocks[order[0]].in_len + blocks[order[0]].prefix_len : 0;
+    bool split = pinned && !decode && cnt >= 64 && len0 >= 8 * kHeadBytes && multi_segment.empty() && !getenv("ZPAQ_AMD_PIPE_PROFILE");
+    if (const char* sc = getenv("ZPAQ_AMD_SPLIT_COPY")) split = split && sc[0] != '0';      // (A/B aid: "0" = one copy up front)
+    for (size_t k = 0; split && k < cnt; ++k)
+      split = blocks[order[k]].in_len + blocks[order[k]].prefix_len == len0 && kind_of_sorted(groups, k) == 4;
+    const uint64_t pitch = ((uint64_t)len0 + 63) & ~63ull;      // (= the distance between two blocks' inputs when all are len0 long)
+    // bytes [from, to) of every block's input (prefix first, then the data) -> staging
+    auto gather_range = [&](size_t t, size_t nt, uint32_t from, uint32_t to) {
+      for (size_t k = t; k < cnt; k += nt) {
+        const HostBlock& hb = blocks[order[k]];
+        const uint32_t total = hb.prefix_len + hb.in_len, hi = std::min(to, total);
+        uint8_t* dst = stage + in_off_of[k];
+        if (from < hb.prefix_len) memcpy(dst + from, hb.prefix + from, std::min(hi, hb.prefix_len) - from);
+        const uint32_t lo = std::max(from, hb.prefix_len);
+        if (hi > lo) memcpy(dst + lo, hb.in + (lo - hb.prefix_len), hi - lo);
+      }
+    };
+    auto gather_all = [&](uint32_t from, uint32_t to, std::vector<std::thread>& pool, bool wait) {
+      // a gigabyte of memcpy for a full batch: one thread per 16 MiB, at most 8 (small batches: this thread alone)
       const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, cnt, (size_t)(in_bytes >> 24) + 1}));
-      auto gather = [&](size_t t) {
-        for (size_t k = t; k < cnt; k += nt) {
-          const HostBlock& hb = blocks[order[k]];
-          if (hb.prefix_len) memcpy(stage + in_off_of[k], hb.prefix, hb.prefix_len);
-          if (hb.in_len) memcpy(stage + in_off_of[k] + hb.prefix_len, hb.in, hb.in_len);
-        }
-      };
-      std::vector<std::thread> pool;
-      size_t started = 1;
+      size_t started = wait ? 1 : 0;
       try {
-        for (; started < nt; ++started) pool.emplace_back(gather, started);
+        for (; started < nt; ++started) pool.emplace_back(gather_range, started, nt, from, to);
       } catch (...) {}                                  // no more threads to be had: this one does the rest
-      gather(0);
-      for (size_t t = started; t < nt; ++t) gather(t);
-      for (auto& th : pool) th.join();
+      if (wait) {
+        gather_range(0, nt, from, to);
+        for (size_t t = started; t < nt; ++t) gather_range(t, nt, from, to);
+        for (auto& th : pool) th.join();
+        pool.clear();
+      } else {
+        for (size_t t = started; t < nt; ++t) gather_range(t, nt, from, to);     // (what no thread could be started for)
+      }
+    };
+    std::vector<std::thread> tail_pool;
+    struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& t : p) if (t.joinable()) t.join(); } } join_tail{tail_pool};
+    if (split) {
+      std::vector<std::thread> pool;
+      gather_all(0, kHeadBytes, pool, true);
+      HIP_CHECK(hipMemcpy2DAsync(e.io_in.p, pitch, stage, pitch, kHeadBytes, cnt, hipMemcpyHostToDevice, e.stream));
+      gather_all(kHeadBytes, 0xFFFFFFFFu, tail_pool, false);        // in the background, joined by LateInput::arrive
+    } else {
+      std::vector<std::thread> pool;
+      gather_all(0, 0xFFFFFFFFu, pool, true);
+      HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, in_bytes, hipMemcpyHostToDevice, e.stream));
     }
-    HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, in_bytes, hipMemcpyHostToDevice, e.stream));
     HIP_CHECK(hipMemcpyAsync(e.jobs.p, jobs.data(), cnt * sizeof(BlockJob), hipMemcpyHostToDevice, e.stream));
     // SHA-1 of the blocks whose caller asked for it: one lane per block, on a side stream beside the coder
     std::vector<Sha1Job> shj;
@@ -1063,23 +1120,49 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
       shj.push_back(Sha1Job{jobs[k].in + hb.prefix_len, hb.in_len, (uint32_t)shj.size()});
       sh_of.push_back(order[k]);
     }
-    Event sha_done;
+    Event sha_done, staged, tail_arrived;
+    if (!shj.empty() || split) {
+      if (e.side.empty()) { hipStream_t s2; HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); e.side.push_back(s2); }
+    }
     if (!shj.empty()) {
       e.sha_jobs.ensure(shj.size() * sizeof(Sha1Job));
       e.sha_out.ensure(shj.size() * 20);
-      if (e.side.empty()) { hipStream_t s2; HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); e.side.push_back(s2); }
-      Event staged;
       HIP_CHECK(hipMemcpyAsync(e.sha_jobs.p, shj.data(), shj.size() * sizeof(Sha1Job), hipMemcpyHostToDevice, e.stream));
-      HIP_CHECK(hipEventRecord(staged, e.stream));
+    }
+    HIP_CHECK(hipEventRecord(staged, e.stream));
+    // hashing needs whole blocks: behind the input's tail when that comes later (same side stream, in order)
+    auto hash_blocks = [&] {
+      if (shj.empty()) return;
       HIP_CHECK(hipStreamWaitEvent(e.side[0], staged, 0));
       HIP_CHECK(launch_sha1((const Sha1Job*)e.sha_jobs.p, (uint32_t)shj.size(), (uint8_t*)e.sha_out.p, e.side[0]));
       HIP_CHECK(hipEventRecord(sha_done, e.side[0]));
+    };
+    LateInput late;
+    bool tail_sent = false;
+    if (split) {
+      late.from_byte = kHeadBytes;
+      late.arrive = [&]() -> hipEvent_t {
+        if (!tail_sent) {
+          for (auto& t : tail_pool) t.join();
+          tail_pool.clear();
+          HIP_CHECK(hipStreamWaitEvent(e.side[0], staged, 0));          // (the buffers are this call's from here on)
+          HIP_CHECK(hipMemcpy2DAsync((uint8_t*)e.io_in.p + kHeadBytes, pitch, stage + kHeadBytes, pitch, pitch - kHeadBytes, cnt,
+                                     hipMemcpyHostToDevice, e.side[0]));
+          HIP_CHECK(hipEventRecord(tail_arrived, e.side[0]));
+          hash_blocks();
+          tail_sent = true;
+        }
+        return tail_arrived;
+      };
+    } else {
+      hash_blocks();
     }
     Timing before = e.last;
     const auto wave_t0 = std::chrono::steady_clock::now();
     e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
-               e.stream, true);
+               e.stream, true, split ? &late : nullptr);
+    if (split && !tail_sent) HIP_CHECK(hipStreamWaitEvent(e.stream, late.arrive(), 0));   // (no pipelined group after all)
     e.last.init_ms += before.init_ms;
     e.last.code_ms += before.code_ms;
     e.last.blocks += before.blocks;
