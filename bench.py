@@ -506,8 +506,10 @@ def main():
                 break
         obj = {"metric": f"decompress MB/s, -m{a.method} over {nd}x{_size_name(bs)} blocks (BASELINE configs[4]: one residency "
                          f"wave of the 8-GPU archive on one GPU)",
-               "value": float(nd) * bs / 1e6 / wall, "unit": "MB/s", "blocks": nd, "block_bytes": bs, "corpus": a.kind,
-               "ms": {"wall": wall * 1e3, "init_arena": tm[0], "code": tm[1]},
+               # like the headline: inputs resident in HBM, state buffers in place -- Predictor::init + the decoding launch; the
+               # wall time of this first decode call of the process also grows the engine's arena pool from 1024 to nd blocks
+               "value": float(nd) * bs / 1e6 / ((tm[0] + tm[1]) / 1e3), "unit": "MB/s", "blocks": nd, "block_bytes": bs, "corpus": a.kind,
+               "ms": {"init_arena": tm[0], "code": tm[1], "wall_first_call": wall * 1e3},
                "every_byte_verified": good,
                "roofline": {"bound": "hbm", "achieved": algo / 1e9 / code_s if code_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (algo / 1e9 / code_s / HBM_PEAK_GBS) if code_s > 0 else 0.0, "traffic": None,
