@@ -100,6 +100,7 @@ struct Engine {
   DevBuf sha_jobs, sha_out;            // SHA-1 of the staged inputs (sha1_blocks_kernel)
   DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
   HostPinned pin_in;                   // page-locked staging of host inputs, kept between calls (ZPAQ_AMD_PINNED_STAGE=0: pageable)
+  HostPinned pin_out;                  // ... and of the outputs of a large batch
   hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
@@ -277,7 +278,7 @@ void engine_shutdown() {
     if (!e.ready) continue;
     (void)hipSetDevice(e.device);
     (void)hipStreamSynchronize(e.stream);
-    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release(); e.pin_in.release();
+    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release(); e.pin_in.release(); e.pin_out.release();
     for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
     for (auto& ss : e.side) (void)hipStreamDestroy(ss);
     e.side.clear();
@@ -989,6 +990,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     }
     if (need > e.budget) fail(ZPQ_E_NOMEM, "Out of memory: one block's model state exceeds the device budget");
     const size_t cnt = end - pos;
+    const auto wave_begin = std::chrono::steady_clock::now();
     uint64_t arena_need = 0;
     for (size_t i = pos; i < end; ++i) arena_need += blocks[i].plan->hdr().arena_bytes;
     e.arena.ensure(arena_need);
@@ -1174,12 +1176,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     }
     HIP_CHECK(hipMemcpyAsync(res.data(), e.results.p, cnt * sizeof(BlockResult), hipMemcpyDeviceToHost, e.stream));
     HIP_CHECK(hipStreamSynchronize(e.stream));
-    if (getenv("ZPAQ_AMD_LOG")) {     // one line per device batch: what a caller-side pool of threads really hands over
-      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wave_t0).count();
-      fprintf(stderr, "[zpaq_amd] %s batch of %zu blocks (%llu bytes in): %zu launch group(s), kernel kind %d mode %d, init %.1f ms, "
-              "coding %.1f ms, launch-to-results %.1f ms\n", decode ? "decode" : "encode", cnt, (unsigned long long)in_bytes, groups.size(),
-              e.last_kind, groups.empty() ? 0 : groups[0].pick.mode, e.last.init_ms, e.last.code_ms, ms);
-    }
+    const auto wave_results = std::chrono::steady_clock::now();
     for (size_t i = 0; i < sh_of.size(); ++i) memcpy(blocks[sh_of[i]].sha1_out, digests.data() + 20 * i, 20);
     if (!segtab.empty()) {
       HIP_CHECK(hipMemcpyAsync(segtab.data(), e.segs.p, segtab.size() * sizeof(SegRange), hipMemcpyDeviceToHost, e.stream));
@@ -1193,14 +1190,54 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
             if (segtab[seg_first[k] + sgi].status) res[k].consumed = 0;      // capacity reached before the last end-of-stream
       }
     }
+    // Outputs.  A copy into the caller's pageable buffer is staged by the runtime and returns when it is done: a thousand of
+    // them cost a few hundred ms however small they are.  A large batch's outputs therefore go -- asynchronously, back to
+    // back -- into a page-locked buffer kept by the engine and are handed out from there by a few threads.
+    uint64_t out_total = 0;
+    std::vector<uint64_t> pin_off(cnt, 0);
     for (size_t k = 0; k < cnt; ++k) {
       const HostBlock& hb = blocks[order[k]];
       results[order[k]] = res[k];
-      uint32_t got = std::min(res[k].out_len, hb.out_cap);
+      pin_off[k] = out_total;
+      if (hb.out) out_total += ((uint64_t)std::min(res[k].out_len, hb.out_cap) + 15) & ~15ull;
+    }
+    const bool pin_outputs = pinned && cnt >= 64 && out_total >= (1u << 20) && e.pin_out.ensure(out_total + 64);
+    for (size_t k = 0; k < cnt; ++k) {
+      const HostBlock& hb = blocks[order[k]];
+      const uint32_t got = std::min(res[k].out_len, hb.out_cap);
       if (got && hb.out)
-        HIP_CHECK(hipMemcpyAsync(hb.out, (const uint8_t*)e.io_out.p + out_off[k], got, hipMemcpyDeviceToHost, e.stream));
+        HIP_CHECK(hipMemcpyAsync(pin_outputs ? (uint8_t*)e.pin_out.p + pin_off[k] : hb.out, (const uint8_t*)e.io_out.p + out_off[k], got,
+                                 hipMemcpyDeviceToHost, e.stream));
     }
     HIP_CHECK(hipStreamSynchronize(e.stream));
+    if (pin_outputs) {
+      const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, cnt, (size_t)(out_total >> 24) + 1}));
+      auto hand_out = [&](size_t t) {
+        for (size_t k = t; k < cnt; k += nt) {
+          const HostBlock& hb = blocks[order[k]];
+          const uint32_t got = std::min(res[k].out_len, hb.out_cap);
+          if (got && hb.out) memcpy(hb.out, (const uint8_t*)e.pin_out.p + pin_off[k], got);
+        }
+      };
+      std::vector<std::thread> pool;
+      size_t started = 1;
+      try {
+        for (; started < nt; ++started) pool.emplace_back(hand_out, started);
+      } catch (...) {}
+      hand_out(0);
+      for (size_t t = started; t < nt; ++t) hand_out(t);
+      for (auto& th : pool) th.join();
+    }
+    if (getenv("ZPAQ_AMD_LOG")) {     // one line per device batch: what a caller-side pool of threads really hands over, and where its time went
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      fprintf(stderr, "[zpaq_amd] %s batch of %zu blocks (%llu bytes in): %zu launch group(s), kernel kind %d mode %d; buffers + gather + "
+              "copy enqueued %.1f ms, launches to results %.1f ms (init %.1f, coding %.1f on the device), outputs %.1f ms%s\n",
+              decode ? "decode" : "encode", cnt, (unsigned long long)in_bytes, groups.size(), e.last_kind,
+              groups.empty() ? 0 : groups[0].pick.mode, ms(wave_begin, wave_t0), ms(wave_t0, wave_results), e.last.init_ms, e.last.code_ms,
+              ms(wave_results, std::chrono::steady_clock::now()), split ? " (input tail copied behind the first steps)" : "");
+    }
     pos = end;
   }
 }
