@@ -107,12 +107,11 @@ constexpr int kTeamX = spec_wave_lds_bytes(8) - 256;         // X[32]: stretch-d
 constexpr int kTeamY = kTeamX + 128;                         // the decoded bit
 constexpr int kTeamRun = kTeamX + 132;                       // block still decoding (written once per byte)
 
-// lanes per block in a row wavefront: 16 (4 blocks per wavefront) when the chain's ICM / ISSE components fit, else 32
-#ifndef ZPQ_TEAM_ROWLANES
-#define ZPQ_TEAM_ROWLANES 0
-#endif
+// lanes per block in a row wavefront: 16 (4 blocks per wavefront) when the chain's ICM / ISSE components fit, else 32.
+// (Measured and dropped, profiles/r04: 32 lanes for every chain -- eight wavefronts, a row and a mixer wavefront on every
+// SIMD -- is 2.5 % slower; a higher priority for the mixer wavefronts changes nothing.)
 template <class Chain>
-constexpr int team_row_lanes() { return ZPQ_TEAM_ROWLANES == 32 ? 32 : (team_map<Chain>().nrows <= 16 ? 16 : 32); }
+constexpr int team_row_lanes() { return team_map<Chain>().nrows <= 16 ? 16 : 32; }
 template <class Chain>
 constexpr int team_threads() { return 64 * (kTeamBlocks / (64 / team_row_lanes<Chain>()) + kTeamBlocks / 2); }
 
@@ -355,9 +354,6 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
   constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
   constexpr int NMIX2 = team_mix2_slot<Chain>(N) > 0 ? team_mix2_slot<Chain>(N) : 1;
-#if defined(ZPQ_TEAM_PRIO) && !defined(ZPQ_EMU)
-  __builtin_amdgcn_s_setprio(ZPQ_TEAM_PRIO);                  // (A/B: the mixers ahead of a row wavefront that shares their SIMD)
-#endif
   constexpr int kRegion = spec_wave_lds_bytes(8);
   const int ci = lane & 31;
   const bool upper = lane >= 32;

@@ -118,8 +118,22 @@ U32 coded_cap(U64 n, bool worst) {
 }
 
 // Runs the encoder for a list of (plan, pp, data) jobs, retrying overflowed ones.
+// Bytes the device writes before anybody reads them: resize() must not fill them first.  (A batch of 1024 x 1 MiB blocks
+// asks for 1.3 GB of output capacity; value-initialising it, block after block on the calling thread, was 200 of the 250 ms
+// the API call spent beside its kernels.)
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+typedef std::vector<U8, DefaultInitAlloc<U8>> RawBytes;
+
 struct EncJob {
-  zpq_plan* plan; const U8* pp; U32 npp; const U8* data; U32 n; std::vector<U8>* coded; U8* sha1_out = nullptr;
+  zpq_plan* plan; const U8* pp; U32 npp; const U8* data; U32 n; RawBytes* coded; U8* sha1_out = nullptr;
   // several segments in one block: lengths of the segments' shares of `data`, and where each one's code ends
   U32 nseg = 0; const U32* seg_len = nullptr; U32* seg_out_end = nullptr;
 };
@@ -184,7 +198,8 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   if (!method || !method[0]) fail(ZPQ_E_ARG, "empty method");
   const size_t nb = in.size();
   struct Work {
-    std::vector<U8> pp, coded, header;
+    std::vector<U8> pp, header;
+    RawBytes coded;
     std::vector<U8> pre;        // LZ77 / BWT stream when the method pre-processes (else the input itself is coded)
     bool use_pre = false;
     bool sha1_on_device = false;
@@ -299,17 +314,18 @@ ApiTiming last_api_timing() {
 
 std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size_t npp, const U8* data, size_t n) {
   PlanCache plans;
-  std::vector<U8> coded;
+  RawBytes coded;
   std::vector<EncJob> jobs(1, EncJob{plan_for(plans, header), pp, (U32)npp, data, (U32)n, &coded, nullptr, 0, nullptr, nullptr});
   if ((U64)n + npp > 0x7FFFF000ull) fail(ZPQ_E_ARG, "segment too large");
   encode_jobs(jobs);
-  return coded;
+  return std::vector<U8>(coded.begin(), coded.end());
 }
 
 // A modelled block of several segments: one device job, the end-of-segment code between them.
 std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& segments) {
   PlanCache plans;
-  std::vector<U8> all, coded;
+  std::vector<U8> all;
+  RawBytes coded;
   std::vector<U32> lens, ends(segments.size(), 0);
   for (const auto& sg : segments) {
     if ((U64)all.size() + sg.size() > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
@@ -321,7 +337,7 @@ std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& head
   if (segments.size() <= 1) jobs[0].nseg = 0;
   encode_jobs(jobs);
   std::vector<std::vector<U8>> out;
-  if (segments.size() <= 1) { out.push_back(coded); return out; }
+  if (segments.size() <= 1) { out.emplace_back(coded.begin(), coded.end()); return out; }
   U32 at = 0;
   for (size_t i = 0; i < segments.size(); ++i) {
     if (ends[i] < at || ends[i] > coded.size()) fail(ZPQ_E_DEVICE, "device coder returned inconsistent segment ends");
@@ -334,7 +350,7 @@ std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& head
 namespace {
 
 struct DecJob {
-  zpq_plan* plan; const U8* payload; U32 len; U64 hint; std::vector<U8>* decoded;
+  zpq_plan* plan; const U8* payload; U32 len; U64 hint; RawBytes* decoded;
   U32 nseg = 0; const U32* seg_len = nullptr; U32* seg_out_end = nullptr;     // several segments: coded lengths / decoded ends
 };
 
@@ -375,18 +391,19 @@ void decode_jobs(std::vector<DecJob>& jobs) {
 
 std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload, size_t len, U64 hint) {
   PlanCache plans;
-  std::vector<U8> decoded;
+  RawBytes decoded;
   if (len > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
   std::vector<DecJob> jobs(1, DecJob{plan_for(plans, header), payload, (U32)len, hint, &decoded, 0, nullptr, nullptr});
   decode_jobs(jobs);
-  return decoded;
+  return std::vector<U8>(decoded.begin(), decoded.end());
 }
 
 // The segments of ONE modelled block decoded together (model and coder state run on from segment to segment):
 // payloads[s] = coded bytes of segment s incl. its terminator; returns the decoded bytes per segment.
 std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& payloads, U64 hint) {
   PlanCache plans;
-  std::vector<U8> all, decoded;
+  std::vector<U8> all;
+  RawBytes decoded;
   std::vector<U32> lens, ends(payloads.size(), 0);
   for (const auto& p : payloads) {
     if ((U64)all.size() + p.size() > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "block too large");
@@ -398,7 +415,7 @@ std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& head
   if (payloads.size() <= 1) jobs[0].nseg = 0;
   decode_jobs(jobs);
   std::vector<std::vector<U8>> out;
-  if (payloads.size() <= 1) { out.push_back(decoded); return out; }
+  if (payloads.size() <= 1) { out.emplace_back(decoded.begin(), decoded.end()); return out; }
   U32 at = 0;
   for (size_t i = 0; i < payloads.size(); ++i) {
     if (ends[i] < at || ends[i] > decoded.size()) fail(ZPQ_E_DEVICE, "device decoder returned inconsistent segment ends");
@@ -414,7 +431,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
     zpq_plan* plan = nullptr;     // null: stored block
     std::vector<U8> header;
     size_t payload_end = 0;
-    std::vector<U8> decoded;      // PP byte(s) + data
+    RawBytes decoded;             // PP byte(s) + data (written by the device: not filled first)
     U64 hint = 0;
     size_t block = 0;             // index of the block the segment belongs to
   };
@@ -452,7 +469,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
   }
   // one device job per modelled block; a block of several segments is ONE job (its model and coder state run on
   // from segment to segment), fed with the segments' payloads back to back
-  struct Multi { std::vector<U8> all, decoded; std::vector<U32> lens, ends; std::vector<size_t> members; };
+  struct Multi { std::vector<U8> all; RawBytes decoded; std::vector<U32> lens, ends; std::vector<size_t> members; };
   std::vector<std::unique_ptr<Multi>> multis;
   std::vector<DecJob> jobs;
   {
@@ -520,7 +537,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
     U64 prog_bytes = 0;
     for (size_t i = 0; i < segs.size() && !force_host; ++i) {
       const Seg& s = *segs[i];
-      const std::vector<U8>& d = s.decoded;
+      const RawBytes& d = s.decoded;
       if (per_block[s.block] != 1 || d.size() < 4 || d[0] != 1) continue;
       const size_t len = d[1] + 256u * d[2];
       if (len < 1 || d.size() < 3 + len) continue;
@@ -571,7 +588,7 @@ void decode_archive(const U8* a, size_t n, const std::function<void(const U8*, s
           done[si].clear();
           pp->segment(s->decoded.data(), s->decoded.size(), done[si]);
         }
-        std::vector<U8>().swap(s->decoded);
+        RawBytes().swap(s->decoded);
         if (s->fs.has_sha1) {
           Sha1 h; h.update(done[si].data(), done[si].size());
           if (memcmp(h.result(), s->fs.sha1, 20) != 0) fail(ZPQ_E_CORRUPT, "segment checksum mismatch");

@@ -185,12 +185,10 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with
 
 }  // namespace
 
-// (ZPAQ_AMD_TEAM_ROWLANES=32: A/B aid -- 32 row lanes per block also for chains that fit 16: eight wavefronts, two per SIMD)
-static bool team_wide_rows() { const char* v = getenv("ZPAQ_AMD_TEAM_ROWLANES"); return v && atoi(v) == 32; }
 int team_threads(const zpq_plan& plan) {
   int rows = 0;
   for (uint32_t i = 0; i < plan.hdr().n; ++i) rows += plan.comps()[i].type == C_ICM || plan.comps()[i].type == C_ISSE;
-  return rows <= 16 && !team_wide_rows() ? 384 : 512;
+  return rows <= 16 ? 384 : 512;
 }
 
 bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, int shape) {
@@ -226,7 +224,6 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
-    << (team && team_wide_rows() ? "#define ZPQ_TEAM_ROWLANES 32\n" : "")
     << "#include \"" << (team ? "spec_team_kernel.h" : (dual ? "spec_dual_kernel.h" : "spec_kernel.h")) << "\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
