@@ -312,6 +312,28 @@ int main(int argc, char** argv) {
       CHECK(bad);
     }
 
+    // A block whose tables exceed this build's limits (an ICM of 2^25 rows: 24 here, 26 in the reference) can still be located
+    // and its memory be asked for -- as the reference's ZPAQL::read allows (libzpaq.cpp:1788); the build's limits apply to decoding
+    {
+      const unsigned char hdr[] = {'z', 'P', 'Q', 2, 1, 10, 0, 0, 0, 0, 0, 1, 3, 25, 0, 56, 0};   // hsize 10: hh hm ph pm n=1, icm 25, END, HALT, END
+      std::string arc((const char*)hdr, sizeof hdr);
+      arc += std::string("\1a\0\0\0", 5);
+      struct R : libzpaq::Reader { const std::string& s; size_t pos = 0; R(const std::string& x) : s(x) {} int get() { return pos < s.size() ? (unsigned char)s[pos++] : -1; } } rd(arc);
+      libzpaq::Decompresser de;
+      de.setInput(&rd);
+      double mem = 0;
+      CHECK(de.findBlock(&mem));
+      CHECK(mem > 64.0 * (1 << 25));
+      const unsigned char big[] = {'z', 'P', 'Q', 2, 1, 10, 0, 0, 0, 0, 0, 1, 3, 27, 0, 56, 0};    // icm 27: refused by the reference as well
+      const std::string arc2((const char*)big, sizeof big);
+      R rd2(arc2);
+      libzpaq::Decompresser de2;
+      de2.setInput(&rd2);
+      bool refused = false;
+      try { de2.findBlock(); } catch (std::runtime_error& e) { refused = std::string(e.what()).find("max size for ICM is 26") != std::string::npos; }
+      CHECK(refused);
+    }
+
     // Decompresser::buffered(): the library reads ahead in 64 KiB pieces; callers recover the true archive offset
     // as (bytes handed out by the Reader) - buffered() (zpaq.cpp:1474, 1631)
     {

@@ -980,7 +980,15 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     while (end < nb) {
       const HostBlock& hb = blocks[end];
       uint64_t a = hb.plan->hdr().arena_bytes;
-      if (!decode && e.kernel_choice != 1 && e.kernel_choice != 2 && e.kernel_choice != 3) a += pipe_bytes(hb.plan, 64, 0) / 64;   // share of a full group
+      // share of a full group's stream buffer, in the largest of the encoder's shapes (which one the wave gets is decided
+      // from its block count further down: the 2048-byte steps of the latency shape need about four times the throughput shape's)
+      if (!decode && e.kernel_choice != 1 && e.kernel_choice != 2 && e.kernel_choice != 3) {
+        // (a wave that outgrows the latency shapes' block count runs the throughput shape: from there on its share is charged)
+        uint64_t share = pipe_bytes(hb.plan, 64, 0) / 64;
+        if (end - pos < kLatencyModeBlocks)
+          for (int m = 1; m < kPipeVariants; ++m) share = std::max(share, pipe_bytes(hb.plan, 64, m) / 64);
+        a += share;
+      }
       if (end > pos && need + a > e.budget) break;
       need += a;
       max_arena = std::max(max_arena, hb.plan->hdr().arena_bytes);

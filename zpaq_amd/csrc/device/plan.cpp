@@ -16,13 +16,17 @@ static const int kCompLen[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};   // libzpaq.cpp
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-zpq_plan* plan_from_header(const U8* h, size_t hlen) {
+// list_only: the caller only locates, lists or skips the block (Decompresser::findBlock): the header is checked with the
+// REFERENCE's limits (sizes up to 32, ZPAQL::read, libzpaq.cpp:887-1006) and only `memory` of the result means anything;
+// the limits of this build -- a block lane's tables live in HBM -- apply where a plan is needed to code or decode.
+zpq_plan* plan_from_header(const U8* h, size_t hlen, bool list_only) {
   if (!h || hlen < 8) fail(ZPQ_E_HEADER, "header too short");
   size_t hsize = h[0] + 256u * h[1];
   if (hsize + 2 != hlen) fail(ZPQ_E_HEADER, "header size field does not match");
   const int hh = h[2], hm = h[3], n = h[6];
-  if (hh > 24) fail(ZPQ_E_HEADER, "H too big");     // reference: >32 (libzpaq.cpp:1018)
-  if (hm > 28) fail(ZPQ_E_HEADER, "M too big");
+  if (hh > (list_only ? 32 : 24)) fail(ZPQ_E_HEADER, "H too big");     // reference: >32 (libzpaq.cpp:1018)
+  if (hm > (list_only ? 32 : 28)) fail(ZPQ_E_HEADER, "M too big");
+  auto too_big = [&](int v, int build_limit) { return v > (list_only ? 32 : build_limit); };
 
   std::vector<CompDesc> comps(n);
   std::vector<Segment> segs;
@@ -61,14 +65,14 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
     switch (type) {
       case C_CONS: break;
       case C_CM:
-        if (cp[1] > 28) fail(ZPQ_E_HEADER, "max size for CM is 28 in this build");
-        c.mask0 = (1u << cp[1]) - 1;
+        if (too_big(cp[1], 28)) fail(ZPQ_E_HEADER, list_only ? "max size for CM is 32" : "max size for CM is 28 in this build");
+        c.mask0 = (uint32_t)((1ull << cp[1]) - 1);
         c.limit = cp[2] * 4u;
         c.t0 = seg(4ull << cp[1], F_U32, 0x80000000u);
         mem += 4 * size; algo += 64;
         break;
       case C_ICM:
-        if (cp[1] > 24) fail(ZPQ_E_HEADER, "max size for ICM is 24 in this build");
+        if (cp[1] > (list_only ? 26 : 24)) fail(ZPQ_E_HEADER, list_only ? "max size for ICM is 26" : "max size for ICM is 24 in this build");
         c.limit = 1023;
         c.t0 = seg(1024, F_ICM, 0);
         c.mask1 = (uint32_t)((64ull << cp[1]) - 1);
@@ -76,9 +80,9 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         mem += 64 * size + 1024; algo += 64;
         break;
       case C_MATCH:
-        if (cp[1] > 28 || cp[2] > 30) fail(ZPQ_E_HEADER, "max size for MATCH is 28 30 in this build");
-        c.mask0 = (1u << cp[1]) - 1;
-        c.mask1 = (1u << cp[2]) - 1;
+        if (too_big(cp[1], 28) || too_big(cp[2], 30)) fail(ZPQ_E_HEADER, list_only ? "max size for MATCH is 32 32" : "max size for MATCH is 28 30 in this build");
+        c.mask0 = (uint32_t)((1ull << cp[1]) - 1);
+        c.mask1 = (uint32_t)((1ull << cp[2]) - 1);
         c.t0 = seg(4ull << cp[1], F_ZERO, 0);
         c.t1 = seg(align_up(1ull << cp[2], 16), F_MATCHBUF, 0);
         mem += 4 * size + std::ldexp(1.0, cp[2]); algo += 10;
@@ -89,10 +93,10 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         dep_mask |= 1ull << (i & 63);
         break;
       case C_MIX2:
-        if (cp[1] > 29) fail(ZPQ_E_HEADER, "max size for MIX2 is 29 in this build");
+        if (too_big(cp[1], 29)) fail(ZPQ_E_HEADER, list_only ? "max size for MIX2 is 32" : "max size for MIX2 is 29 in this build");
         if (cp[3] >= i) fail(ZPQ_E_HEADER, "MIX2 k >= i");
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "MIX2 j >= i");
-        c.mask0 = (1u << cp[1]) - 1;
+        c.mask0 = (uint32_t)((1ull << cp[1]) - 1);
         // device layout: one dword per weight (the reference packs U16) so that CM and MIX2
         // words are fetched, prefetched and written back by the same dword instructions
         c.t0 = seg(align_up(4ull << cp[1], 16), F_U32, 32768u);
@@ -100,10 +104,10 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         dep_mask |= 1ull << (i & 63);
         break;
       case C_MIX:
-        if (cp[1] > 24) fail(ZPQ_E_HEADER, "max size for MIX is 24 in this build");
+        if (too_big(cp[1], 24)) fail(ZPQ_E_HEADER, list_only ? "max size for MIX is 32" : "max size for MIX is 24 in this build");
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "MIX j >= i");
         if (cp[3] < 1 || cp[3] > i - cp[2]) fail(ZPQ_E_HEADER, "MIX m not in 1..i-j");
-        c.mask0 = (1u << cp[1]) - 1;
+        c.mask0 = (uint32_t)((1ull << cp[1]) - 1);
         c.stride = mix_row_stride(cp[3]);              // padded rows: one 128-byte line per row (layout.h)
         c.t0 = seg(align_up((4ull * c.stride) << cp[1], 16), F_U32, (uint32_t)(65536 / cp[3]));
         mem += 4 * size * cp[3]; algo += 64.0 * cp[3];
@@ -111,7 +115,7 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         mix_mask |= 1ull << (i & 63);
         break;
       case C_ISSE:
-        if (cp[1] > 24) fail(ZPQ_E_HEADER, "max size for ISSE is 24 in this build");
+        if (too_big(cp[1], 24)) fail(ZPQ_E_HEADER, list_only ? "max size for ISSE is 32" : "max size for ISSE is 24 in this build");
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "ISSE j >= i");
         c.t0 = seg(2048, F_ISSE, 0);
         c.mask1 = (uint32_t)((64ull << cp[1]) - 1);
@@ -120,7 +124,7 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen) {
         dep_mask |= 1ull << (i & 63);
         break;
       case C_SSE:
-        if (cp[1] > 24) fail(ZPQ_E_HEADER, "max size for SSE is 24 in this build");
+        if (too_big(cp[1], 24)) fail(ZPQ_E_HEADER, list_only ? "max size for SSE is 32" : "max size for SSE is 24 in this build");
         if (cp[2] >= i) fail(ZPQ_E_HEADER, "SSE j >= i");
         if (cp[3] > cp[4] * 4) fail(ZPQ_E_HEADER, "SSE start > limit*4");
         c.mask0 = (uint32_t)((32ull << cp[1]) - 1);

@@ -39,7 +39,7 @@ namespace zpq {
 int plan_device_index();
 void set_plan_device_index(int dev);
 // Parses a stored block header into a plan; throws Failure(ZPQ_E_HEADER/...).
-zpq_plan* plan_from_header(const U8* header, size_t hlen);
+zpq_plan* plan_from_header(const U8* header, size_t hlen, bool list_only = false);
 }
 
 inline zpq_plan::OnDevice& zpq_plan::cur() { return dev[zpq::plan_device_index()]; }

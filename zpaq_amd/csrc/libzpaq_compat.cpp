@@ -284,9 +284,10 @@ bool Decompresser::findBlock(double* memptr) {
   }
   if (hsize < 6) error("header too short");
   if (level == 1 && header_[6] == 0) error("ZPAQ level 1 requires at least 1 component");
-  // ZPAQL::read's checks and ZPAQL::memory() for every block, modelled or not (libzpaq.cpp:1145-1216, 1228-1270)
+  // ZPAQL::read's checks and ZPAQL::memory() for every block, modelled or not (libzpaq.cpp:1145-1216, 1228-1270) -- with the
+  // reference's limits: locating, listing or skipping a block needs no plan; this build's size limits apply when it is decoded
   guarded([&] {
-    zpq_plan* p = zpq::plan_from_header(header_.data(), header_.size());
+    zpq_plan* p = zpq::plan_from_header(header_.data(), header_.size(), /*list_only=*/true);
     if (memptr) *memptr = p->memory;
     delete p;
   });
