@@ -243,8 +243,15 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     std::vector<size_t> sorting;
     U64 sort_bytes = 0;
     for (size_t b = 0; b < nb; ++b) if (front[b].sorts) { sorting.push_back(b); sort_bytes += in[b].n; }
-    if (sorting.size() >= 4 && sort_bytes >= (1u << 20) && engine_device_count() > 0) {
-      for (size_t b : sorting) if (front[b].args[1] > 4) e8e9_forward(in[b].data, in[b].n);
+    // the device sorter's range is known up front (blocks below 16 MiB, 2 GiB per batch, 65535 blocks): a batch outside it
+    // is left to the host sorter before anything is touched
+    bool in_range = sorting.size() <= 65535 && sort_bytes < (1ull << 31);
+    for (size_t b : sorting) in_range = in_range && in[b].n < (1u << 24);
+    if (in_range && sorting.size() >= 4 && sort_bytes >= (1u << 20) && engine_device_count() > 0) {
+      parallel_blocks(sorting.size(), [&](size_t k) {        // E8E9 first where the method has it: it changes the bytes that are sorted
+        const size_t b = sorting[k];
+        if (front[b].args[1] > 4) e8e9_forward(in[b].data, in[b].n);
+      });
       std::vector<std::pair<const U8*, U32>> blk;
       for (size_t b : sorting) blk.push_back({in[b].data, in[b].n});
       std::vector<std::vector<U32>> sa;
