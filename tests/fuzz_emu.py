@@ -106,6 +106,16 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
                 dec2 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), dual=True)
                 for i, (plain, status, consumed) in zip(inputs, dec2):
                     assert status == 0 and plain == i, ("dual decode", status, len(plain), len(i))
+            # the lockstep decoder (chains whose ISSEs are fed by the ICM / ISSE before them)
+            try:
+                emu.team_source(header)
+                has_team = True
+            except RuntimeError:
+                has_team = False
+            if has_team:
+                dec3 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), team=True)
+                for i, (plain, status, consumed) in zip(inputs, dec3):
+                    assert status == 0 and plain == i, ("lockstep decode", status, len(plain), len(i))
             for mode in ((1, 2) if big else (0, 1)):
                 out = emu.pipe_run(header, inputs, mode=mode, group=rng.choice([None, None, None, 8, 16]))
                 for w, (coded, status, _consumed), i in zip(want, out, inputs):
