@@ -347,41 +347,6 @@ constexpr bool mix2_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u;
 typedef unsigned long long __attribute__((aligned(1))) team_u64u;
 typedef __attribute__((address_space(1))) const team_u64u g_u64u;
 
-// HCOMP's M array behind a register window.  The context programs compressBlock's methods generate use M as a history
-// buffer: push the new byte below the last one (c = c - 1; M[c] = a), then read M[c], M[c + 1], ... a few bytes up -- twenty
-// dependent loads of one cache line per input byte, ~150 cycles each: most of the 3 500 cycles HCOMP cost per byte, all of it
-// serial between a byte's last bit and the next byte's first.  The window holds the 8 bytes at `base` and above; a store just
-// below `base` moves it down, any other store inside it patches it, every store also goes to memory, a load outside it comes
-// from memory: exact for every program, a few ALU instructions per access for those that behave like the standard ones.
-template <unsigned MMASK>
-struct TeamVmMem {
-  g_u8* mem;
-  unsigned long long& win;      // byte k (bits 8k .. 8k + 7) = M[(base + k) & MMASK]
-  unsigned& base;
-  struct Ref {
-    const TeamVmMem& m;
-    unsigned i;
-    __device__ __forceinline__ operator unsigned() const {
-      if constexpr (MMASK < 15u) return m.mem[i];
-      const unsigned o = (i - m.base) & MMASK;
-      unsigned v;
-      if (o < 8u) v = (unsigned)(m.win >> (8u * o)) & 255u;
-      else { v = m.mem[i]; ZPQ_OPAQUE(v); }
-      return v;
-    }
-    __device__ __forceinline__ const Ref& operator=(unsigned char x) const {
-      m.mem[i] = x;
-      if constexpr (MMASK >= 15u) {
-        const unsigned o = (i - m.base) & MMASK;
-        if (o < 8u) m.win = (m.win & ~(255ull << (8u * o))) | ((unsigned long long)x << (8u * o));
-        else if (((m.base - 1u - i) & MMASK) == 0u) { m.win = m.win << 8 | x; m.base = i; }
-      }
-      return *this;
-    }
-  };
-  __device__ __forceinline__ Ref operator[](unsigned i) const { return Ref{*this, i}; }
-};
-
 template <class Chain, class TT>
 __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks,
                                             int tw, int lane) {
@@ -428,9 +393,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
 
   // HCOMP machine of this half (every lane of the half runs it: identical values, identical stores)
   unsigned vm_b = 0, vm_c = 0, vm_d = 0, vm_f = 0;
-  unsigned long long vm_mwin = 0;
-  unsigned vm_mbase = 0;
-  const TeamVmMem<Chain::MMASK> vm_M{arena + (unsigned)Chain::OFF_M + hoff, vm_mwin, vm_mbase};
+  g_u8* const vm_M = arena + (unsigned)Chain::OFF_M + hoff;
   g_u32* const vm_R = (g_u32*)(arena + (unsigned)Chain::OFF_R + hoff);
   lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
 
