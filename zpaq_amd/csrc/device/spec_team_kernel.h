@@ -103,12 +103,9 @@ constexpr TeamMap<Chain::N> team_map() {
 
 constexpr int kTeamBlocks = 8;                               // blocks per workgroup
 // exchange words in the upper half of a block's dummy area (offsets from the start of the block's LDS region)
-// X[parity of the bit's position][value of the bit before it][chain index], 16 bits each: the stretch-domain predictions of
-// the row components for a bit, published once per possible value of the pending bit (nibble starts: under index 0 only)
-constexpr int kTeamX = spec_wave_lds_bytes(8) - 256;
-constexpr int kTeamY = spec_wave_lds_bytes(8) - 384;         // the decoded bit
-constexpr int kTeamRun = kTeamY + 4;                         // block still decoding (written once per byte)
-typedef __attribute__((address_space(3))) short lds_i16;
+constexpr int kTeamX = spec_wave_lds_bytes(8) - 256;         // X[32]: stretch-domain predictions of the row components, by chain index
+constexpr int kTeamY = kTeamX + 128;                         // the decoded bit
+constexpr int kTeamRun = kTeamX + 132;                       // block still decoding (written once per byte)
 
 // lanes per block in a row wavefront: 16 (4 blocks per wavefront) when the chain's ICM / ISSE components fit, else 32.
 // (Measured and dropped, profiles/r04: 32 lanes for every chain -- eight wavefronts, a row and a mixer wavefront on every
@@ -140,7 +137,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
 
   const unsigned dummy = (unsigned)Chain::OFF_RUN;
-  const unsigned dummy_lds = (unsigned)(kRegion - 512) + (unsigned)(k & 15) * 8u;      // (idle lanes share 16 slots: nobody reads them)
+  const unsigned dummy_lds = (unsigned)(kRegion - 512) + (unsigned)(k & 31) * 8u;
   unsigned mask1 = 63, sizebits = 0, off0 = dummy, off1 = dummy, ctype = 0;
   int ldsoff = -1, cidx = 0;
   static_for<0, (R < 32 ? R : 32)>([&](auto kc) __attribute__((always_inline)) {
@@ -177,44 +174,18 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   const unsigned bh_shift = is_isse ? 1u : 0u;
   const unsigned q1off = is_icm ? 0u : 4u;
   const unsigned n1base = (is_isse && !side_global) ? ldsq + 4u : dummy_lds + 4u;
-  // where this lane publishes its prediction: + 128 x (parity of the bit's position) + 64 x (value of the bit before it)
-  const unsigned xoff = live ? (unsigned)kTeamX + 2u * (unsigned)cidx : dummy_lds;
-  const unsigned xpar = live ? 128u : 0u, xy = live ? 64u : 0u;
+  const unsigned xoff = live ? (unsigned)kTeamX + 4u * (unsigned)cidx : dummy_lds;      // where this lane publishes p
   constexpr int kIsseDepth = TM.depth;
 
-  // the bit being resolved: bit history, side-table entry (index and words), prediction, what update will need
-  unsigned bh = 0, e_cur = 0, v0 = 0, v1 = 0, nspair = 0;
-  int p = 0, sq = 0, pj = 0;
-  unsigned h = 0;
+  unsigned bh = 0, h = 0, v0 = 0, v1 = 0, nspair = 0;
+  int p = 0, sq = 0;
   unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0, rowoff = 0;
   unsigned touch_a = 0, touch_b = 0;
-  int c8 = 1, hmap4 = 1;
+  // side tables that stayed in the arena: both candidates of the next bit are fetched while the mixers work
+  unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
+  unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
+  int c8 = 1, hmap4 = 1, ylast = 0;
   TEAM_PROF_DECL
-
-  // side-table entry e: LDS or, for the tables that did not fit, the arena (a store to the same entry by this lane earlier
-  // in program order is seen: same wavefront, same address)
-  auto side_read = [&](unsigned e, unsigned& q0, unsigned& q1) __attribute__((always_inline)) {
-    const unsigned el = side_global ? 0u : e;
-    q0 = L32(ldsq + 4u * el);
-    q1 = L32(ldsq + 4u * el + q1off);
-    if constexpr (Chain::ANY_GLOBAL_SIDE) {
-      const unsigned sidx = side_global ? e : 0u;
-      const unsigned g0 = G32(soff + 4u * sidx), g1 = G32(soff + 4u * sidx + 4u);
-      q0 = side_global ? g0 : q0;
-      q1 = side_global ? g1 : q1;
-    }
-  };
-  // prediction of every row component from its side-table words (ICM: stretch; ISSE: the chains, resolved together by
-  // `depth` rounds of shift / multiply-add / clamp inside the block's lanes)
-  auto predict_rows = [&](unsigned q0, unsigned q1) __attribute__((always_inline)) -> int {
-    const int st = sp_stretch(T, (q0 >> 8) & 32767u);
-    int pp = (int)((unsigned)st & m_icm);
-    const int iw = (int)(q0 & m_isse);
-    const int ia = (int)sp_blend(m_isse, q1 << 6, (unsigned)pp << 16);
-#pragma unroll
-    for (int it = 0; it < kIsseDepth; ++it) pp = sp_clamp2k(sp_mad24(iw, sp_shr1(pp), ia) >> 16);
-    return pp;
-  };
 
   bool any = true;
   {
@@ -227,13 +198,14 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
       constexpr int B = decltype(bitc)::value;
       constexpr bool nib = B == 0 || B == 4;
-      constexpr bool ahead = B != 3 && B != 7;               // the next bit lives in the same row: predicted now, for both values of this one
+      constexpr bool last_of_nibble = B == 3;
       const int slot = hmap4 & 15;
       const int c8a = c8 * 2, c8b = c8 * 2 + 1;
-      const int hm4a = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf);
-      const int hm4b = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf);
+      const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+      const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                      : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+      // ---- predict: Predictor::find per nibble, bit history, side table, ISSE chains
       if constexpr (nib) {
-        // ---- a nibble's first bit: Predictor::find, then the prediction the ordinary way; the mixers wait for it at [A]
         ZPQ_KEEP2(touch_a, touch_b);
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
@@ -256,85 +228,81 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
         row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
         row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
-        bh = row_get_nb<0>(row0, row1, row2, row3, slot);
-        nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
-        e_cur = (bh << bh_shift) & m_row;
-        side_read(e_cur, v0, v1);
-        p = predict_rows(v0, v1);
-        sq = sp_squash(T, sp_clamp2k(p));
-        pj = sp_shr1(p);
-        *(lds_i16*)(wl + xoff + (unsigned)(B & 1) * xpar) = (short)p;
-        TEAM_PROF(0);
-        ZPQ_TEAM_BARRIER();                                  // [A] the mixers take over
-        TEAM_PROF(1);
       }
-      // ---- while the mixers work on this bit: its update for both outcomes (Predictor::update0 cases ICM, ISSE) ...
-      unsigned n0[2], n1[2];
-#pragma unroll
-      for (int yy = 0; yy < 2; ++yy) {
-        const int yq = yy * 32767;
-        const int err = yq - sq;
-        n0[yy] = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
-                          (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
-        n1[yy] = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-      }
-      // ... and, inside a nibble, the NEXT bit's prediction for both outcomes: its slot of the row is not the one this
-      // bit's update writes; its side-table entry is read as it is now, or is this bit's entry, whose new words are above
-      unsigned sbh[2] = {0, 0}, sv0[2] = {0, 0}, sv1[2] = {0, 0}, snsp[2] = {0, 0};
-      int sp[2] = {0, 0}, ssq[2] = {0, 0};
-      if constexpr (ahead) {
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-          const int slotn = (yy ? hm4b : hm4a) & 15;
-          sbh[yy] = row_get_nb<((B + 1) & 3)>(row0, row1, row2, row3, slotn);
-          snsp[yy] = *(const unsigned short*)&T.ns[(sbh[yy] & 255u) * 4u];
-          const unsigned en = (sbh[yy] << bh_shift) & m_row;
-          unsigned q0, q1;
-          side_read(en, q0, q1);
-          const bool same = en == e_cur;
-          sv0[yy] = same ? n0[yy] : q0;
-          sv1[yy] = same ? n1[yy] : q1;
-          sp[yy] = predict_rows(sv0[yy], sv1[yy]);
-          ssq[yy] = sp_squash(T, sp_clamp2k(sp[yy]));
-          *(lds_i16*)(wl + xoff + (unsigned)((B + 1) & 1) * xpar + (unsigned)yy * xy) = (short)sp[yy];
+      bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
+      nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
+      const unsigned e0 = (bh << bh_shift) & m_row;
+      const unsigned el = side_global ? 0u : e0;
+      unsigned q0 = L32(ldsq + 4u * el);
+      unsigned q1 = L32(ldsq + 4u * el + q1off);
+      if constexpr (Chain::ANY_GLOBAL_SIDE) {
+        const unsigned sidx = side_global ? e0 : 0u;
+        unsigned g0, g1;
+        if constexpr (nib) {                                  // new row: nothing was fetched ahead
+          g0 = G32(soff + 4u * sidx);
+          g1 = G32(soff + 4u * sidx + 4u);
+        } else {
+          const bool fwd = sidx == le0;
+          g0 = fwd ? ln0 : (ylast ? scb0 : sca0);
+          g1 = fwd ? ln1 : (ylast ? scb1 : sca1);
         }
+        q0 = side_global ? g0 : q0;
+        q1 = side_global ? g1 : q1;
       }
-      if constexpr (B == 3) {
+      v0 = q0;
+      v1 = q1;
+      {
+        const int st = sp_stretch(T, (v0 >> 8) & 32767u);
+        p = (int)((unsigned)st & m_icm);
+        const int iw = (int)(v0 & m_isse);
+        const int ia = (int)sp_blend(m_isse, v1 << 6, (unsigned)p << 16);
+#pragma unroll
+        for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
+      }
+      L32(xoff) = (unsigned)p;
+      TEAM_PROF(0);
+      ZPQ_TEAM_BARRIER();                                    // [A] the mixers take over
+      TEAM_PROF(1);
+      // ---- while the mixers work: what the update and the next bit will need
+      sq = sp_squash(T, sp_clamp2k(p));
+      const int pj = sp_shr1(p);
+      if constexpr (last_of_nibble) {
         // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
         const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
         touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
         touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+      }
+      if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {
+        const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
+        const unsigned ea = side_global ? (bha << bh_shift) : 0u, eb = side_global ? (bhb << bh_shift) : 0u;
+        sca0 = G32(soff + 4u * ea); sca1 = G32(soff + 4u * ea + 4u);
+        scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
       }
       TEAM_PROF(2);
       ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
       TEAM_PROF(3);
       TEAM_PROF_BIT();
       const int y = (int)L32((unsigned)kTeamY);
-      // ---- commit: the bit history and the side-table entry of this bit, the state of the next one
+      // ---- update (Predictor::update0 cases ICM, ISSE)
       {
         const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
+        const int yq = y * 32767;
+        const int err = yq - sq;
         row_set_nb<(B & 3)>(row0, row1, row2, row3, slot, nsv);
-        const unsigned w0 = y ? n0[1] : n0[0], w1 = y ? n1[1] : n1[0];
-        const unsigned el = side_global ? 0u : e_cur;
-        L32(ldsq + 4u * el) = w0;
-        L32(n1base + ((4u * el) & m_lds2)) = w1;
+        const unsigned n0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
+                                  (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
+        const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
+        L32(ldsq + 4u * el) = n0;
+        L32(n1base + ((4u * el) & m_lds2)) = n1;
         if constexpr (Chain::ANY_GLOBAL_SIDE) {
-          const unsigned sidx = side_global ? e_cur : 0u;
-          G32(soff + 4u * sidx) = w0;
-          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = w1;
+          const unsigned sidx = side_global ? e0 : 0u;
+          G32(soff + 4u * sidx) = n0;
+          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = n1;
+          le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
         }
+        ylast = y;
       }
       c8 += c8 + y;
-      if constexpr (ahead) {
-        bh = y ? sbh[1] : sbh[0];
-        v0 = y ? sv0[1] : sv0[0];
-        v1 = y ? sv1[1] : sv1[0];
-        nspair = y ? snsp[1] : snsp[0];
-        p = y ? sp[1] : sp[0];
-        sq = y ? ssq[1] : ssq[0];
-        e_cur = (bh << bh_shift) & m_row;
-        pj = sp_shr1(p);
-      }
       if constexpr (B == 7) {
         TEAM_PROF(0);
         ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run: contexts of the next byte, who still runs
@@ -355,7 +323,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   // (the last nibble's row is never written back: the block's model state is of no use after its last byte)
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
   if (blockIdx.x == 0 && wave == 0 && lane == 0 && tp_n_)
-    printf("[zpq team prof] rows   : bits=%llu cycles/bit: commit + a nibble's first bit=%.0f wait[A]=%.0f both outcomes one bit ahead=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
+    printf("[zpq team prof] rows   : bits=%llu cycles/bit: update+predict=%.0f wait[A]=%.0f idle-window work=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
            tp_n_, (double)tp_[0] / tp_n_, (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_);
 #endif
 }
@@ -442,7 +410,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   };
   const unsigned m_match = lane_mask(is_match), m_ctx = lane_mask(is_ctx);
   const unsigned m_pf = lane_mask(pf_lane), m_rowc = lane_mask(is_rowc);
-  const unsigned xoff = (unsigned)kTeamX + 2u * (unsigned)ci;     // + 128 x (parity of the bit's position) + 64 x (value of the bit before it)
+  const unsigned xoff = (unsigned)kTeamX + 4u * (unsigned)ci;
 
   unsigned gidx = 0, h = 0;
   int p = 0;
@@ -662,12 +630,8 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   };
 
   // ---- after [A]: the dependent components, the final probability
-  auto chain = [&](auto bitc) __attribute__((always_inline)) -> unsigned {
-    constexpr int B = decltype(bitc)::value;
-    constexpr bool nib = B == 0 || B == 4;
-    // a nibble's first bit has one prediction per row component; the other bits' were computed a bit ahead for both values of
-    // the bit before them
-    const unsigned px = (unsigned)(int)*(const lds_i16*)(wl + xoff + (unsigned)(B & 1) * 128u + (nib ? 0u : (unsigned)ylast * 64u));
+  auto chain = [&]() __attribute__((always_inline)) -> unsigned {
+    const unsigned px = L32(xoff);
     p = (int)sp_blend(m_rowc, px, (unsigned)p);
     static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
@@ -888,9 +852,9 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       constexpr int B = decltype(bitc)::value;
       pre(bitc);
       TEAM_PROF(0);
-      if constexpr (B == 0 || B == 4) ZPQ_TEAM_BARRIER();    // [A] a nibble's first bit: the row components' predictions are in LDS now
+      ZPQ_TEAM_BARRIER();                                    // [A] the row components' predictions are in LDS
       TEAM_PROF(1);
-      const unsigned pr = chain(bitc) * 2u + 1u;
+      const unsigned pr = chain() * 2u + 1u;
       const int y = decode_bit(pr);
       if (ci == 0) L32((unsigned)kTeamY) = (unsigned)y;
       TEAM_PROF(2);
