@@ -639,7 +639,6 @@ def main():
         entries = entries if isinstance(entries, list) else [entries]       # one entry per code object that was profiled
         obj_sha = None
         if origin.startswith("cache:"):          # the code object that ran: same machine code as the profiled one also counts
-            import hashlib
             obj = os.path.join(ROOT, "zpaq_amd", "spec_cache", origin[6:].split()[0] + ".hsaco")
             if os.path.exists(obj):
                 obj_sha = hashlib.sha256(open(obj, "rb").read()).hexdigest()

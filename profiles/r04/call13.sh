@@ -18,4 +18,4 @@ PY
 }
 run configs1 --method 3 --blocks 256 --block-bytes 262144 --kind lcg --decode-blocks 0 --steps 3
 run mixed --kind mixed --decode-blocks 0
-run dense --blocks 2048 --decode-blocks 0 --api-blocks 0
+
