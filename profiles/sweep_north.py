@@ -7,8 +7,8 @@ every line (a work queue over the usable cores, one block each).
     python profiles/sweep_north.py out.jsonl [--quick]
 
 Each line: MB/s of the device-resident call, roofline fraction on algorithmic bytes, CPU reference MB/s, whether every
-status is 0, whether a few blocks decode back (first 32 KiB through the device decoder) and, for the zeros lines, whether
-block 0's coded payload is the one inside the reference's archive of the same block.
+status is 0, whether a few blocks decode back (first 32 KiB through the device decoder) and how many of the blocks the
+reference coded as well (one per usable core) have the coded payload that sits inside the reference's archive.
 """
 from __future__ import annotations
 
@@ -125,11 +125,12 @@ def main():
                     r2h = r2.cpu().numpy()
                     line["decoded_back"] = int(sum(int(r2h[k, 2] == 0 and r2h[k, 0] == vb and bool((back[k, :vb] == d_in[k, :vb]).all()))
                                                    for k in range(nv))) if rc == 0 else 0
-                    payload0 = d_out[0, :int(out_len[0])].cpu().numpy().tobytes()
+                    # coded payloads of the blocks the reference will code as well (one per usable core)
+                    payloads = [d_out[k, :int(out_len[k])].cpu().numpy().tobytes() for k in range(min(cores, nb))]
                     del coded, back
                 except Exception as ex:
                     line["error"] = str(ex)[:300]
-                    payload0 = None
+                    payloads = None
                 del d_out, d_res
                 # the reference on the host cores: one block per thread from a work queue
                 if ref is not None:
@@ -139,9 +140,13 @@ def main():
                     line["cpu_MBps"] = ncpu * bs / 1e6 / wall_c
                     line["cpu_cores"] = ncpu
                     line["cpu_build"] = ref.build_flags()
-                    if payload0 is not None:
-                        ps = parse_block(arch[0])["payload_start"]
-                        line["block0_identical_to_reference"] = arch[0][ps:ps + len(payload0) + 4] == payload0 + b"\0\0\0\0"
+                    if payloads is not None:
+                        same = 0
+                        for k in range(ncpu):
+                            ps = parse_block(arch[k])["payload_start"]
+                            same += arch[k][ps:ps + len(payloads[k]) + 4] == payloads[k] + b"\0\0\0\0"
+                        line["blocks_compared_with_reference"] = ncpu
+                        line["blocks_identical_to_reference"] = int(same)
                     if "MBps" in line:
                         line["vs_cpu"] = line["MBps"] / line["cpu_MBps"]
                 del d_in
