@@ -177,37 +177,15 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   const unsigned xoff = live ? (unsigned)kTeamX + 4u * (unsigned)cidx : dummy_lds;      // where this lane publishes p
   constexpr int kIsseDepth = TM.depth;
 
-  // the bit being resolved: bit history, side-table entry (index and words), prediction, what its update needs
-  unsigned bh = 0, e_cur = 0, h = 0, v0 = 0, v1 = 0, nspair = 0;
-  int p = 0, sq = 0, pj = 0;
+  unsigned bh = 0, h = 0, v0 = 0, v1 = 0, nspair = 0;
+  int p = 0, sq = 0;
   unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0, rowoff = 0;
   unsigned touch_a = 0, touch_b = 0;
-  int c8 = 1, hmap4 = 1;
+  // side tables that stayed in the arena: both candidates of the next bit are fetched while the mixers work
+  unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
+  unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
+  int c8 = 1, hmap4 = 1, ylast = 0;
   TEAM_PROF_DECL
-
-  // side-table entry e: LDS or, for the tables that did not fit, the arena (a store to the same entry by this lane earlier
-  // in program order is seen: same wavefront, same address)
-  auto side_read = [&](unsigned e, unsigned& q0, unsigned& q1) __attribute__((always_inline)) {
-    const unsigned el = side_global ? 0u : e;
-    q0 = L32(ldsq + 4u * el);
-    q1 = L32(ldsq + 4u * el + q1off);
-    if constexpr (Chain::ANY_GLOBAL_SIDE) {
-      const unsigned sidx = side_global ? e : 0u;
-      const unsigned g0 = G32(soff + 4u * sidx), g1 = G32(soff + 4u * sidx + 4u);
-      q0 = side_global ? g0 : q0;
-      q1 = side_global ? g1 : q1;
-    }
-  };
-  // the ISSE chains, resolved together by `depth` rounds of shift / multiply-add / clamp inside a block's lanes; st = the
-  // ICM lanes' stretch(cm >> 8)
-  auto chains = [&](int st, unsigned q0, unsigned q1) __attribute__((always_inline)) -> int {
-    int pp = (int)((unsigned)st & m_icm);
-    const int iw = (int)(q0 & m_isse);
-    const int ia = (int)sp_blend(m_isse, q1 << 6, (unsigned)pp << 16);
-#pragma unroll
-    for (int it = 0; it < kIsseDepth; ++it) pp = sp_clamp2k(sp_mad24(iw, sp_shr1(pp), ia) >> 16);
-    return pp;
-  };
 
   bool any = true;
   {
@@ -216,22 +194,18 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
     for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
     any = r != 0;
   }
-  // what the idle window prepared for the next bit, per value of the pending one: bit history, its successors, side-table
-  // words (the pending bit's entry forwarded with ITS two possible new values), stretch of the ICM word
-  unsigned sbh[2] = {0, 0}, sv0[2] = {0, 0}, sv1[2] = {0, 0}, snsp[2] = {0, 0};
-  int sst[2] = {0, 0};
   while (any) {
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
       constexpr int B = decltype(bitc)::value;
       constexpr bool nib = B == 0 || B == 4;
-      constexpr bool ahead = B != 3 && B != 7;               // the next bit lives in the same row
+      constexpr bool last_of_nibble = B == 3;
       const int slot = hmap4 & 15;
       const int c8a = c8 * 2, c8b = c8 * 2 + 1;
-      const int hm4a = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf);
-      const int hm4b = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf);
-      // ---- predict
+      const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+      const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                      : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+      // ---- predict: Predictor::find per nibble, bit history, side table, ISSE chains
       if constexpr (nib) {
-        // a nibble's first bit: Predictor::find, then bit history, side table, stretch
         ZPQ_KEEP2(touch_a, touch_b);
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
@@ -254,82 +228,81 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         row1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
         row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
         row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
-        bh = row_get_nb<0>(row0, row1, row2, row3, slot);
-        nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
-        e_cur = (bh << bh_shift) & m_row;
-        side_read(e_cur, v0, v1);
-        p = chains(sp_stretch(T, (v0 >> 8) & 32767u), v0, v1);
       }
-      // (the other bits: bh, v0, v1, nspair and the stretch were prepared for both values of the bit before; the commit
-      //  below selected them and ran the chains)
+      bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
+      nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
+      const unsigned e0 = (bh << bh_shift) & m_row;
+      const unsigned el = side_global ? 0u : e0;
+      unsigned q0 = L32(ldsq + 4u * el);
+      unsigned q1 = L32(ldsq + 4u * el + q1off);
+      if constexpr (Chain::ANY_GLOBAL_SIDE) {
+        const unsigned sidx = side_global ? e0 : 0u;
+        unsigned g0, g1;
+        if constexpr (nib) {                                  // new row: nothing was fetched ahead
+          g0 = G32(soff + 4u * sidx);
+          g1 = G32(soff + 4u * sidx + 4u);
+        } else {
+          const bool fwd = sidx == le0;
+          g0 = fwd ? ln0 : (ylast ? scb0 : sca0);
+          g1 = fwd ? ln1 : (ylast ? scb1 : sca1);
+        }
+        q0 = side_global ? g0 : q0;
+        q1 = side_global ? g1 : q1;
+      }
+      v0 = q0;
+      v1 = q1;
+      {
+        const int st = sp_stretch(T, (v0 >> 8) & 32767u);
+        p = (int)((unsigned)st & m_icm);
+        const int iw = (int)(v0 & m_isse);
+        const int ia = (int)sp_blend(m_isse, v1 << 6, (unsigned)p << 16);
+#pragma unroll
+        for (int it = 0; it < kIsseDepth; ++it) p = sp_clamp2k(sp_mad24(iw, sp_shr1(p), ia) >> 16);
+      }
       L32(xoff) = (unsigned)p;
-      TEAM_PROF(0);
+      TEAM_PROF((B == 0 ? 5 : (B == 4 ? 6 : 0)));
       ZPQ_TEAM_BARRIER();                                    // [A] the mixers take over
       TEAM_PROF(1);
-      // ---- while the mixers work: this bit's update for both outcomes (Predictor::update0 cases ICM, ISSE) ...
+      // ---- while the mixers work: what the update and the next bit will need
       sq = sp_squash(T, sp_clamp2k(p));
-      pj = sp_shr1(p);
-      unsigned n0[2], n1[2];
-#pragma unroll
-      for (int yy = 0; yy < 2; ++yy) {
-        const int yq = yy * 32767;
-        const int err = yq - sq;
-        n0[yy] = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
-                          (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
-        n1[yy] = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-      }
-      // ... and, inside a nibble, everything of the next bit's prediction that is a table lookup, for both outcomes: its slot
-      // of the row is not the one this bit's update writes; its side-table entry is read as it is now, or it is this bit's
-      // entry, whose new words are above
-      if constexpr (ahead) {
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-          const int slotn = (yy ? hm4b : hm4a) & 15;
-          sbh[yy] = row_get_nb<((B + 1) & 3)>(row0, row1, row2, row3, slotn);
-          snsp[yy] = *(const unsigned short*)&T.ns[(sbh[yy] & 255u) * 4u];
-          const unsigned en = (sbh[yy] << bh_shift) & m_row;
-          unsigned q0, q1;
-          side_read(en, q0, q1);
-          const bool same = en == e_cur;
-          sv0[yy] = same ? n0[yy] : q0;
-          sv1[yy] = same ? n1[yy] : q1;
-          sst[yy] = sp_stretch(T, (sv0[yy] >> 8) & 32767u);
-        }
-      }
-      if constexpr (B == 3) {
+      const int pj = sp_shr1(p);
+      if constexpr (last_of_nibble) {
         // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
         const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
         touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
         touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+      }
+      if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {
+        const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
+        const unsigned ea = side_global ? (bha << bh_shift) : 0u, eb = side_global ? (bhb << bh_shift) : 0u;
+        sca0 = G32(soff + 4u * ea); sca1 = G32(soff + 4u * ea + 4u);
+        scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
       }
       TEAM_PROF(2);
       ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
       TEAM_PROF(3);
       TEAM_PROF_BIT();
       const int y = (int)L32((unsigned)kTeamY);
-      // ---- commit this bit; inside a nibble: select what was prepared and run the chains for the next one
+      // ---- update (Predictor::update0 cases ICM, ISSE)
       {
         const unsigned nsv = y ? nspair >> 8 : nspair & 255u;
+        const int yq = y * 32767;
+        const int err = yq - sq;
         row_set_nb<(B & 3)>(row0, row1, row2, row3, slot, nsv);
-        const unsigned w0 = y ? n0[1] : n0[0], w1 = y ? n1[1] : n1[0];
-        const unsigned el = side_global ? 0u : e_cur;
-        L32(ldsq + 4u * el) = w0;
-        L32(n1base + ((4u * el) & m_lds2)) = w1;
+        const unsigned n0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
+                                  (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
+        const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
+        L32(ldsq + 4u * el) = n0;
+        L32(n1base + ((4u * el) & m_lds2)) = n1;
         if constexpr (Chain::ANY_GLOBAL_SIDE) {
-          const unsigned sidx = side_global ? e_cur : 0u;
-          G32(soff + 4u * sidx) = w0;
-          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = w1;
+          const unsigned sidx = side_global ? e0 : 0u;
+          G32(soff + 4u * sidx) = n0;
+          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = n1;
+          le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
         }
+        ylast = y;
       }
       c8 += c8 + y;
-      if constexpr (ahead) {
-        bh = y ? sbh[1] : sbh[0];
-        v0 = y ? sv0[1] : sv0[0];
-        v1 = y ? sv1[1] : sv1[0];
-        nspair = y ? snsp[1] : snsp[0];
-        e_cur = (bh << bh_shift) & m_row;
-        p = chains(y ? sst[1] : sst[0], v0, v1);
-      }
       if constexpr (B == 7) {
         TEAM_PROF(0);
         ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run: contexts of the next byte, who still runs
@@ -350,8 +323,10 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   // (the last nibble's row is never written back: the block's model state is of no use after its last byte)
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
   if (blockIdx.x == 0 && wave == 0 && lane == 0 && tp_n_)
-    printf("[zpq team prof] rows   : bits=%llu cycles/bit: update+predict=%.0f wait[A]=%.0f idle-window work=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
-           tp_n_, (double)tp_[0] / tp_n_, (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_);
+    printf("[zpq team prof] rows   : bits=%llu cycles: update+predict per bit inside a nibble=%.0f, per first bit of a byte=%.0f, per first bit of the "
+           "second nibble=%.0f; per bit: wait[A]=%.0f idle-window work=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
+           tp_n_, (double)tp_[0] / (tp_n_ * 0.75), (double)tp_[5] / (tp_n_ * 0.125), (double)tp_[6] / (tp_n_ * 0.125), (double)tp_[1] / tp_n_,
+           (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_);
 #endif
 }
 
@@ -878,7 +853,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
       constexpr int B = decltype(bitc)::value;
       pre(bitc);
-      TEAM_PROF(0);
+      TEAM_PROF((B == 0 ? 7 : 0));
       ZPQ_TEAM_BARRIER();                                    // [A] the row components' predictions are in LDS
       TEAM_PROF(1);
       const unsigned pr = chain() * 2u + 1u;
@@ -935,9 +910,10 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   }
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
   if (blockIdx.x == 0 && tw == 0 && lane == 0 && tp_n_)
-    printf("[zpq team prof] mixers : bits=%llu cycles/bit: pre=%.0f wait[A]=%.0f chain+decode=%.0f wait[B]=%.0f update=%.0f hcomp/8=%.0f wait[C]/8=%.0f\n",
-           tp_n_, (double)tp_[0] / tp_n_, (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_,
-           (double)tp_[5] / tp_n_, (double)tp_[6] / tp_n_);
+    printf("[zpq team prof] mixers : bits=%llu cycles: pre per bit but a byte's first=%.0f, per first bit of a byte=%.0f; per bit: wait[A]=%.0f chain+decode=%.0f "
+           "wait[B]=%.0f update=%.0f hcomp/8=%.0f wait[C]/8=%.0f\n",
+           tp_n_, (double)tp_[0] / (tp_n_ * 0.875), (double)tp_[7] / (tp_n_ * 0.125), (double)tp_[1] / tp_n_, (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_,
+           (double)tp_[4] / tp_n_, (double)tp_[5] / tp_n_, (double)tp_[6] / tp_n_);
 #endif
 }
 
