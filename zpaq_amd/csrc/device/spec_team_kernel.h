@@ -187,14 +187,6 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   int c8 = 1, hmap4 = 1, ylast = 0;
   TEAM_PROF_DECL
 
-  // The second nibble's row is looked up while bit 3 is being decoded, for both of its values (Predictor::find on both candidate
-  // lines, then the bit history's side-table words): two dependent trips to memory -- 5 800 cycles measured for the nibble's
-  // first bit, with the mixers idle -- leave the critical path.  What bit 3's commit installs:
-  unsigned nb_row0[2], nb_row1[2], nb_row2[2], nb_row3[2], nb_off[2], nb_bh[2], nb_nsp[2], nb_q0[2], nb_q1[2];
-  unsigned s_bh = 0, s_nsp = 0, s_q0 = 0, s_q1 = 0;         // ... and the first bit of the second nibble starts from
-  unsigned t4a = 0, t4b = 0, t4c = 0, t4d = 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { nb_row0[i] = nb_row1[i] = nb_row2[i] = nb_row3[i] = nb_off[i] = nb_bh[i] = nb_nsp[i] = nb_q0[i] = nb_q1[i] = 0; }
   bool any = true;
   {
     ZPQ_TEAM_BARRIER();                                      // [S] the mixers have published who runs
@@ -205,7 +197,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   while (any) {
     static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
       constexpr int B = decltype(bitc)::value;
-      constexpr bool nib = B == 0;                           // (the second nibble's find runs ahead, see above)
+      constexpr bool nib = B == 0 || B == 4;
       constexpr bool last_of_nibble = B == 3;
       const int slot = hmap4 & 15;
       const int c8a = c8 * 2, c8b = c8 * 2 + 1;
@@ -237,19 +229,13 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         row2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
         row3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
       }
-      if constexpr (B == 4) { bh = s_bh; nspair = s_nsp; }
-      else {
-        bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
-        nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
-      }
+      bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
+      nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
       const unsigned e0 = (bh << bh_shift) & m_row;
       const unsigned el = side_global ? 0u : e0;
-      unsigned q0 = s_q0, q1 = s_q1;
-      if constexpr (B != 4) {
-        q0 = L32(ldsq + 4u * el);
-        q1 = L32(ldsq + 4u * el + q1off);
-      }
-      if constexpr (Chain::ANY_GLOBAL_SIDE && B != 4) {
+      unsigned q0 = L32(ldsq + 4u * el);
+      unsigned q1 = L32(ldsq + 4u * el + q1off);
+      if constexpr (Chain::ANY_GLOBAL_SIDE) {
         const unsigned sidx = side_global ? e0 : 0u;
         unsigned g0, g1;
         if constexpr (nib) {                                  // new row: nothing was fetched ahead
@@ -280,68 +266,11 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       // ---- while the mixers work: what the update and the next bit will need
       sq = sp_squash(T, sp_clamp2k(p));
       const int pj = sp_shr1(p);
-      if constexpr (B == 2) {
-        // the second nibble's row will be one of four lines: pull them towards this XCD's L2 now
-        ZPQ_KEEP4(t4a, t4b, t4c, t4d);
-        t4a = G32(roff + (((h + 16u * (unsigned)(c8 * 4 + 0)) * 16u) & (rmask - 15u)));
-        t4b = G32(roff + (((h + 16u * (unsigned)(c8 * 4 + 1)) * 16u) & (rmask - 15u)));
-        t4c = G32(roff + (((h + 16u * (unsigned)(c8 * 4 + 2)) * 16u) & (rmask - 15u)));
-        t4d = G32(roff + (((h + 16u * (unsigned)(c8 * 4 + 3)) * 16u) & (rmask - 15u)));
-      }
       if constexpr (last_of_nibble) {
-        // Predictor::find for the second nibble under both values of this bit; the row being left is forwarded with this
-        // bit's update applied (its new bit history depends on the value), and so is this bit's side-table entry
-        uint4 c0[2], c1[2], c2[2];
-        unsigned hh0[2], chk2[2];
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-          const unsigned cx = h + 16u * (unsigned)(c8 * 2 + yy);
-          chk2[yy] = (cx >> (sizebits & 31u)) & 255u;
-          hh0[yy] = (cx * 16u) & (rmask - 15u);
-          c0[yy] = G128(roff + hh0[yy]);
-          c1[yy] = G128(roff + (hh0[yy] ^ 16u));
-          c2[yy] = G128(roff + (hh0[yy] ^ 32u));
-        }
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-          const int yq = yy * 32767;
-          const int err = yq - sq;
-          const unsigned un0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
-                                        (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
-          const unsigned un1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-          unsigned o0 = row0, o1 = row1, o2 = row2, o3 = row3;
-          row_set_nb<3>(o0, o1, o2, o3, slot, yy ? nspair >> 8 : nspair & 255u);
-          const uint4 oldrow = make_uint4(o0, o1, o2, o3);
-          uint4 r0 = c0[yy], r1 = c1[yy], r2 = c2[yy];
-          const unsigned h0 = hh0[yy], chk = chk2[yy];
-          if (rowoff == h0) r0 = oldrow;
-          if (rowoff == (h0 ^ 16u)) r1 = oldrow;
-          if (rowoff == (h0 ^ 32u)) r2 = oldrow;
-          const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
-          const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
-          const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
-          const bool hit = m0 || m1 || m2;
-          const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
-          nb_off[yy] = h0 ^ (unsigned)(pick << 4);
-          nb_row0[yy] = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
-          nb_row1[yy] = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
-          nb_row2[yy] = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
-          nb_row3[yy] = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
-          nb_bh[yy] = (nb_row0[yy] >> 8) & 255u;                  // slot 1: the nibble's first bit
-          nb_nsp[yy] = *(const unsigned short*)&T.ns[(nb_bh[yy] & 255u) * 4u];
-          const unsigned en = (nb_bh[yy] << bh_shift) & m_row;
-          const unsigned enl = side_global ? 0u : en;
-          unsigned a0 = L32(ldsq + 4u * enl), a1 = L32(ldsq + 4u * enl + q1off);
-          if constexpr (Chain::ANY_GLOBAL_SIDE) {
-            const unsigned sidx = side_global ? en : 0u;
-            const unsigned g0 = G32(soff + 4u * sidx), g1 = G32(soff + 4u * sidx + 4u);
-            a0 = side_global ? g0 : a0;
-            a1 = side_global ? g1 : a1;
-          }
-          const bool same = en == e0;                              // this bit's entry: its words as this value leaves them
-          nb_q0[yy] = same ? un0 : a0;
-          nb_q1[yy] = same ? un1 : a1;
-        }
+        // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
+        const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
+        touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
+        touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
       }
       if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {
         const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
@@ -374,18 +303,6 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         ylast = y;
       }
       c8 += c8 + y;
-      if constexpr (B == 3) {
-        G128(roff + rowoff) = make_uint4(row0, row1, row2, row3);
-        rowoff = y ? nb_off[1] : nb_off[0];
-        row0 = y ? nb_row0[1] : nb_row0[0];
-        row1 = y ? nb_row1[1] : nb_row1[0];
-        row2 = y ? nb_row2[1] : nb_row2[0];
-        row3 = y ? nb_row3[1] : nb_row3[0];
-        s_bh = y ? nb_bh[1] : nb_bh[0];
-        s_nsp = y ? nb_nsp[1] : nb_nsp[0];
-        s_q0 = y ? nb_q0[1] : nb_q0[0];
-        s_q1 = y ? nb_q1[1] : nb_q1[0];
-      }
       if constexpr (B == 7) {
         TEAM_PROF(0);
         ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run: contexts of the next byte, who still runs
