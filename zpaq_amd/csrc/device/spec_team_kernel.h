@@ -51,6 +51,35 @@ namespace zpq {
   } while (0)
 #endif
 
+// The workgroup's shared tables: stretch in the encoder's compact form (groups of 8 as start value + seven 1-bit increments
+// for x in [16384, 32512), the steep top end direct, the lower half by stretch(x) = -stretch(32767 - x): exact, checked
+// exhaustively on the host), the non-trivial part of squash, dt, dt2k, the state table.
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+
+struct TeamTables {
+  unsigned stretch_cb[2016];
+  short stretch_top[256];
+  uint16_t squash_mid[1344];
+  int32_t dt[1024];
+  uint16_t dt2k[256];
+  uint8_t ns[1024];
+};
+static_assert(sizeof(TeamTables) == kTeamTablesBytes, "host codegen and device disagree on the lockstep decoder's LDS tables");
+__device__ __forceinline__ int sp_stretch(const TeamTables& T, unsigned x) {   // x in 0..32767
+  const bool lo = x < 16384u;
+  const unsigned y = lo ? 32767u - x : x;
+  const unsigned e = T.stretch_cb[min((y - 16384u) >> 3, 2015u)];
+  const int mid = (int)(short)(unsigned short)e + __builtin_popcount((e >> 16) & ((1u << (y & 7u)) - 1u));
+  const int hi = T.stretch_top[y >= 32512u ? y - 32512u : 0u];
+  const int v = y >= 32512u ? hi : mid;
+  return lo ? -v : v;
+}
+__device__ __forceinline__ int sp_squash(const TeamTables& T, int p) {         // p in -2048..2047
+  const int i = p + 2048 - 1376;
+  const int v = T.squash_mid[min(max(i, 0), 1343)];
+  return i < 0 ? 0 : (i > 1343 ? 32767 : v);
+}
+
 // -DZPQ_PROF: wavefront 0 of the row kind and of the mixer kind of workgroup 0 count the cycles of their phases
 // (s_memtime) and print them per coded bit at the end; compiled out otherwise.
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
@@ -103,7 +132,7 @@ constexpr TeamMap<Chain::N> team_map() {
 
 constexpr int kTeamBlocks = 8;                               // blocks per workgroup
 // exchange words in the upper half of a block's dummy area (offsets from the start of the block's LDS region)
-constexpr int kTeamX = spec_wave_lds_bytes(8) - 256;         // X[32]: stretch-domain predictions of the row components, by chain index
+constexpr int kTeamX = team_block_lds_bytes() - 256;         // X[32]: stretch-domain predictions of the row components, by chain index
 constexpr int kTeamY = kTeamX + 128;                         // the decoded bit
 constexpr int kTeamRun = kTeamX + 132;                       // block still decoding (written once per byte)
 
@@ -123,7 +152,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   constexpr int R = TM.nrows;
   constexpr int RL = team_row_lanes<Chain>();
   constexpr int BPR = 64 / RL;
-  constexpr int kRegion = spec_wave_lds_bytes(8);
+  constexpr int kRegion = team_block_lds_bytes();
   const int k = lane % RL, q = lane / RL;
   const unsigned bw = (unsigned)(wave * BPR + q);            // block of this lane inside the workgroup
   const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
@@ -170,10 +199,32 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
     return m;
   };
   const unsigned m_isse = lane_mask(is_isse), m_icm = lane_mask(is_icm), m_row = lane_mask(has_row);
-  const unsigned m_lds2 = lane_mask(is_isse && !side_global);
   const unsigned bh_shift = is_isse ? 1u : 0u;
-  const unsigned q1off = is_icm ? 0u : 4u;
-  const unsigned n1base = (is_isse && !side_global) ? ldsq + 4u : dummy_lds + 4u;
+  // packed side table in LDS (layout.h kTeamIcmLds / kTeamIsseLds): 16-bit array(s) at the table's start -- ICM: cm's low half,
+  // 2 bytes per entry; ISSE: the two weights' low halves, 4 bytes per entry --, then one byte per entry with the bits above.
+  // Lanes without such a table (idle, or the table stayed in the arena) work on their 8-byte dummy slot.
+  const bool in_lds = has_row && ldsoff >= 0;
+  const unsigned pk_sh = is_isse ? 2u : 1u;
+  const unsigned pk_hi = in_lds ? ldsq + (is_isse ? 1024u : 512u) : dummy_lds + 4u;
+  const unsigned m_inlds = lane_mask(in_lds), m_lds2 = lane_mask(is_isse && in_lds);
+  auto side_lds_get = [&](unsigned bhv, unsigned& q0, unsigned& q1) __attribute__((always_inline)) {
+    const unsigned i = bhv & m_inlds;
+    const unsigned a1 = ldsq + (i << pk_sh);
+    const unsigned lo = *(const lds_u16*)(wl + a1), hi16 = *(const lds_u16*)(wl + a1 + 2u), h8 = *(const lds_u8*)(wl + pk_hi + i);
+    const unsigned cm = lo | h8 << 16;
+    const unsigned w0 = (unsigned)((int)((lo | (h8 & 15u) << 16) << 12) >> 12);
+    const unsigned w1 = (unsigned)((int)((hi16 | (h8 >> 4) << 16) << 12) >> 12);
+    q0 = sp_blend(m_icm, cm, w0);
+    q1 = w1;
+  };
+  auto side_lds_put = [&](unsigned bhv, unsigned n0, unsigned n1) __attribute__((always_inline)) {
+    const unsigned i = bhv & m_inlds;
+    const unsigned a1 = ldsq + (i << pk_sh);
+    const unsigned a2 = sp_blend(m_lds2, a1 + 2u, dummy_lds + 2u);
+    *(lds_u16*)(wl + a1) = (unsigned short)n0;
+    *(lds_u16*)(wl + a2) = (unsigned short)n1;
+    *(lds_u8*)(wl + pk_hi + i) = (unsigned char)sp_blend(m_icm, n0 >> 16, ((n0 >> 16) & 15u) | ((n1 >> 16) & 15u) << 4);
+  };
   const unsigned xoff = live ? (unsigned)kTeamX + 4u * (unsigned)cidx : dummy_lds;      // where this lane publishes p
   constexpr int kIsseDepth = TM.depth;
 
@@ -232,9 +283,8 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       bh = row_get_nb<(B & 3)>(row0, row1, row2, row3, slot);
       nspair = *(const unsigned short*)&T.ns[(bh & 255u) * 4u];
       const unsigned e0 = (bh << bh_shift) & m_row;
-      const unsigned el = side_global ? 0u : e0;
-      unsigned q0 = L32(ldsq + 4u * el);
-      unsigned q1 = L32(ldsq + 4u * el + q1off);
+      unsigned q0, q1;
+      side_lds_get(bh, q0, q1);
       if constexpr (Chain::ANY_GLOBAL_SIDE) {
         const unsigned sidx = side_global ? e0 : 0u;
         unsigned g0, g1;
@@ -292,8 +342,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         const unsigned n0 = sp_blend(m_icm, v0 + (unsigned)((int)((unsigned)yq - (v0 >> 8)) >> 2),
                                   (unsigned)sp_clamp512k((int)v0 + (sp_mad24(err, pj, 1 << 12) >> 13)));
         const unsigned n1 = (unsigned)sp_clamp512k((int)v1 + ((err + 16) >> 5));
-        L32(ldsq + 4u * el) = n0;
-        L32(n1base + ((4u * el) & m_lds2)) = n1;
+        side_lds_put(bh, n0, n1);
         if constexpr (Chain::ANY_GLOBAL_SIDE) {
           const unsigned sidx = side_global ? e0 : 0u;
           G32(soff + 4u * sidx) = n0;
@@ -356,7 +405,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
   constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
   constexpr int NMIX2 = team_mix2_slot<Chain>(N) > 0 ? team_mix2_slot<Chain>(N) : 1;
-  constexpr int kRegion = spec_wave_lds_bytes(8);
+  constexpr int kRegion = team_block_lds_bytes();
   const int ci = lane & 31;
   const bool upper = lane >= 32;
   const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
@@ -924,14 +973,15 @@ __device__ __forceinline__ void spec_team_decode_body(const BlockJob* jobs, Bloc
   constexpr int N = Chain::N;
   static_assert(team_map<Chain>().ok, "chain not for the lockstep decoder");
   static_assert(Chain::WAVES == 8, "the chain's LDS plan must be the one of the 8-blocks-per-workgroup shape");
-  constexpr int kRegion = spec_wave_lds_bytes(8);
+  constexpr int kRegion = team_block_lds_bytes();
   constexpr int RL = team_row_lanes<Chain>();
   constexpr int NRW = kTeamBlocks / (64 / RL);                // row wavefronts
-  static_assert((int)sizeof(SpecTables) + kTeamBlocks * kRegion <= kSpecLdsBudget, "LDS budget");
+  static_assert((int)sizeof(TeamTables) + kTeamBlocks * kRegion <= kSpecLdsBudget, "LDS budget");
 
-  __shared__ SpecTables T;
+  __shared__ TeamTables T;
   __shared__ __attribute__((aligned(16))) unsigned char wave_lds[kTeamBlocks][kRegion];
-  for (unsigned i = threadIdx.x; i < 16384u; i += blockDim.x) T.stretch_hi[i] = tb->stretch[16384u + i];
+  for (unsigned i = threadIdx.x; i < 2016u; i += blockDim.x) T.stretch_cb[i] = tb->stretch_cb[i];
+  for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) T.stretch_top[i] = tb->stretch_top[i];
   for (unsigned i = threadIdx.x; i < 1344u; i += blockDim.x) T.squash_mid[i] = tb->squash[1376u + i];
   for (unsigned i = threadIdx.x; i < 1024u; i += blockDim.x) { T.dt[i] = tb->dt[i]; T.ns[i] = tb->ns[i]; }
   for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) T.dt2k[i] = (uint16_t)tb->dt2k[i];
@@ -949,10 +999,20 @@ __device__ __forceinline__ void spec_team_decode_body(const BlockJob* jobs, Bloc
       static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
         constexpr CompK c = Chain::comp[decltype(ic)::value];
         if constexpr (c.lds >= 0 && (c.type == C_ICM || c.type == C_ISSE)) {
-          constexpr unsigned words = c.type == C_ICM ? 256 : 512;
+          // packed: ICM  u16 lo[256] | u8 hi[256];  ISSE  (u16 w0 lo, u16 w1 lo)[256] | u8 (w0 hi nibble | w1 hi nibble << 4)[256]
           const g_u32* src = (const g_u32*)(arena_b + (unsigned)c.t0);
-          lds_u32* dst = (lds_u32*)(wl + c.lds);
-          for (unsigned k = threadIdx.x; k < words; k += blockDim.x) dst[k] = src[k];
+          lds_u8* const tab = wl + c.lds;
+          for (unsigned k = threadIdx.x; k < 256u; k += blockDim.x) {
+            if constexpr (c.type == C_ICM) {
+              const unsigned v = src[k];
+              *(lds_u16*)(tab + 2u * k) = (unsigned short)v;
+              tab[512u + k] = (unsigned char)(v >> 16);
+            } else {
+              const unsigned w0 = src[2u * k], w1 = src[2u * k + 1u];
+              *(lds_u32*)(tab + 4u * k) = (w0 & 0xFFFFu) | (w1 << 16);
+              tab[1024u + k] = (unsigned char)(((w0 >> 16) & 15u) | (((w1 >> 16) & 15u) << 4));
+            }
+          }
         }
       });
       for (unsigned k = threadIdx.x; k <= Chain::HMASK; k += blockDim.x) ((lds_u32*)(wl + Chain::H_LDS))[k] = 0;

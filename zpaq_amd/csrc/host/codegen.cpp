@@ -218,7 +218,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
       if (comp[i].type == C_ICM || comp[i].type == C_ISSE) prev_row = i;
     }
   }
-  const int wave_lds = spec_wave_lds_bytes(waves);          // LDS of ONE block
+  const int wave_lds = team ? team_block_lds_bytes() : spec_wave_lds_bytes(waves);          // LDS of ONE block
   int lds_used = 0, h_lds = -1;
   const int h_bytes = (int)(4u * (ph.hmask + 1));
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
@@ -234,7 +234,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
     const CompDesc& c = comp[i];
     int lds = -1, slot = -1;
     if (c.type == C_ICM || c.type == C_ISSE) {
-      const int bytes = c.type == C_ICM ? 1024 : 2048;
+      const int bytes = team ? (c.type == C_ICM ? kTeamIcmLds : kTeamIsseLds) : (c.type == C_ICM ? 1024 : 2048);   // (the lockstep decoder packs its entries)
       if (lds_used + bytes <= wave_lds - 512) { lds = lds_used; lds_used += bytes; }   // last 512 B: dummy slots
       else any_global_side = true;
     }
