@@ -32,6 +32,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import hashlib
+import struct
 import json
 import os
 import re
@@ -229,6 +230,42 @@ def in_library_bench(a, torch, z):
         line["vs_cpu"] = value / base["value"] if base["value"] else None
     print(json.dumps(line))
 
+
+
+def machine_code_sha256(path):
+    """sha256 over the .text and .rodata bytes of the gfx950 code object inside a clang offload bundle (or a bare ELF):
+    what the GPU executes, without the bundle's ids and the notes that change with the name of the source file."""
+    b = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    if b.startswith(magic):
+        n = struct.unpack_from("<Q", b, len(magic))[0]
+        p = len(magic) + 8
+        elf = None
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", b, p)
+            triple = b[p + 24:p + 24 + tl]
+            p += 24 + tl
+            if b"amdgcn" in triple:
+                elf = b[off:off + size]
+        if elf is None:
+            return None
+        b = elf
+    if b[:4] != b"\x7fELF":
+        return None
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    strtab = b[stroff:stroff + strsize]
+    h = hashlib.sha256()
+    for i in range(shnum):
+        name, off, size = sh(i)
+        nm = strtab[name:strtab.index(b"\0", name)]
+        if nm in (b".text", b".rodata"):
+            h.update(nm); h.update(b[off:off + size])
+    return h.hexdigest()
 
 def main():
     ap = argparse.ArgumentParser()
@@ -637,12 +674,14 @@ def main():
         key = f"method {a.method} x {nb} x {bs} {a.kind} {a.mode}"
         entries = tj.get(key, [])
         entries = entries if isinstance(entries, list) else [entries]       # one entry per code object that was profiled
-        obj_sha = None
+        obj_sha = code_sha = None
         if origin.startswith("cache:"):          # the code object that ran: same machine code as the profiled one also counts
             obj = os.path.join(ROOT, "zpaq_amd", "spec_cache", origin[6:].split()[0] + ".hsaco")
             if os.path.exists(obj):
                 obj_sha = hashlib.sha256(open(obj, "rb").read()).hexdigest()
-        hit = [e for e in entries if e.get("kernel_origin") == origin or (obj_sha and e.get("code_object_sha256") == obj_sha)]
+                code_sha = machine_code_sha256(obj)
+        hit = [e for e in entries if e.get("kernel_origin") == origin or (obj_sha and e.get("code_object_sha256") == obj_sha)
+               or (code_sha and e.get("machine_code_sha256") == code_sha)]
         if hit:
             tj = {key: hit[0]}
             traffic = tj[key]["traffic_bytes"]

@@ -144,7 +144,18 @@ static std::vector<std::string> jit_options() {
   std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + spec_include_dir(), "-Wno-unused-label",
                                 "-mllvm", "-simplifycfg-sink-common=false"};
   const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS");
-  if (defs && defs[0]) o.push_back(defs);      // a single extra option, e.g. -DZPQ_PROF
+  if (defs && defs[0]) {                       // extra options separated by blanks, e.g. "-DZPQ_PROF -DZPQ_TEAM_EARLY2=0"
+    std::string cur;
+    for (const char* c = defs;; ++c) {
+      if (*c == ' ' || *c == 0) {
+        if (!cur.empty()) o.push_back(cur);
+        cur.clear();
+        if (*c == 0) break;
+      } else {
+        cur.push_back(*c);
+      }
+    }
+  }
   return o;
 }
 

@@ -82,6 +82,15 @@ __device__ __forceinline__ int sp_squash(const TeamTables& T, int p) {         /
 
 // -DZPQ_PROF: wavefront 0 of the row kind and of the mixer kind of workgroup 0 count the cycles of their phases
 // (s_memtime) and print them per coded bit at the end; compiled out otherwise.
+// ZPQ_TEAM_EARLY2: the second nibble's three candidate rows are LOADED for both values of bit 3 while that bit is decoded
+// (24 registers per lane) instead of only pulled towards the L2
+#ifndef ZPQ_TEAM_EARLY2
+#define ZPQ_TEAM_EARLY2 1
+#endif
+// ZPQ_TEAM_LATE_UPDATE7: the mixers train a byte's last bit after HCOMP and [C] instead of before
+#ifndef ZPQ_TEAM_LATE_UPDATE7
+#define ZPQ_TEAM_LATE_UPDATE7 1
+#endif
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
 #define TEAM_PROF_DECL unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_t_ = __builtin_readcyclecounter(), tp_n_ = 0;
 #define TEAM_PROF(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t_; tp_t_ = n_; } while (0)
@@ -193,6 +202,11 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   const unsigned ldsq = (has_row && ldsoff >= 0) ? (unsigned)ldsoff : dummy_lds;
   const bool side_global = has_row && ldsoff < 0;
   const unsigned soff = side_global ? off0 : dummy;
+  // the ISSE's second word: one store at a per-lane offset (written as a choice between two addresses it compiles to a
+  // ladder of branches on the path every bit takes)
+  unsigned s1base = (side_global && is_isse) ? soff + 4u : dummy + 4u, s1mask = (side_global && is_isse) ? ~0u : 0u;
+  ZPQ_OPAQUE(s1base);
+  ZPQ_OPAQUE(s1mask);
   auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
     unsigned m = x ? 0xFFFFFFFFu : 0u;
     ZPQ_OPAQUE(m);
@@ -232,6 +246,9 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   int p = 0, sq = 0;
   unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0, rowoff = 0;
   unsigned touch_a = 0, touch_b = 0;
+#if ZPQ_TEAM_EARLY2
+  uint4 ea0 = make_uint4(0, 0, 0, 0), ea1 = ea0, ea2 = ea0, eb0 = ea0, eb1 = ea0, eb2 = ea0;
+#endif
   // side tables that stayed in the arena: both candidates of the next bit are fetched while the mixers work
   unsigned sca0 = 0, sca1 = 0, scb0 = 0, scb1 = 0;
   unsigned le0 = 0xFFFFFFFFu, ln0 = 0, ln1 = 0;
@@ -261,9 +278,22 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
         const unsigned h0 = (cx * 16u) & (rmask - 15u);
+#if ZPQ_TEAM_EARLY2
+        uint4 r0, r1, r2;
+        if constexpr (B == 4) {                               // both candidate lines have been on their way since bit 3's [A]
+          r0 = ylast ? eb0 : ea0;
+          r1 = ylast ? eb1 : ea1;
+          r2 = ylast ? eb2 : ea2;
+        } else {
+          r0 = G128(roff + h0);
+          r1 = G128(roff + (h0 ^ 16u));
+          r2 = G128(roff + (h0 ^ 32u));
+        }
+#else
         uint4 r0 = G128(roff + h0);
         uint4 r1 = G128(roff + (h0 ^ 16u));
         uint4 r2 = G128(roff + (h0 ^ 32u));
+#endif
         const uint4 oldrow = make_uint4(row0, row1, row2, row3);
         G128(roff + rowoff) = oldrow;
         if (rowoff == h0) r0 = oldrow;
@@ -319,8 +349,14 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       if constexpr (last_of_nibble) {
         // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
         const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
+#if ZPQ_TEAM_EARLY2
+        const unsigned ha = (cxa * 16u) & (rmask - 15u), hb = (cxb * 16u) & (rmask - 15u);
+        ea0 = G128(roff + ha); ea1 = G128(roff + (ha ^ 16u)); ea2 = G128(roff + (ha ^ 32u));
+        eb0 = G128(roff + hb); eb1 = G128(roff + (hb ^ 16u)); eb2 = G128(roff + (hb ^ 32u));
+#else
         touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
         touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+#endif
       }
       if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {
         const unsigned bha = row_get(row0, row1, row2, row3, hm4a & 15), bhb = row_get(row0, row1, row2, row3, hm4b & 15);
@@ -346,7 +382,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         if constexpr (Chain::ANY_GLOBAL_SIDE) {
           const unsigned sidx = side_global ? e0 : 0u;
           G32(soff + 4u * sidx) = n0;
-          G32((side_global && is_isse) ? soff + 4u * sidx + 4u : dummy + 4u) = n1;
+          G32(s1base + 4u * (sidx & s1mask)) = n1;
           le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
         }
         ylast = y;
@@ -843,11 +879,12 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
   };
   // in two halves: the bit first -- the row wavefronts wait for it --, the range update and the bytes shifted in behind [B]
   unsigned dmid = 0;
-  auto decode_bit = [&](unsigned pr) __attribute__((always_inline)) -> int {
-    if (!run) return 0;
-    if (curr < low || curr > high) { status = 2; run = false; return 0; }
+  auto decode_bit = [&](unsigned pr) __attribute__((always_inline)) -> int {     // (selects, no branches: every bit passes here)
+    const bool bad = run && (curr < low || curr > high);
+    status = bad ? 2 : status;
+    run = run && !bad;
     dmid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
-    return curr <= dmid ? 1 : 0;
+    return (run && curr <= dmid) ? 1 : 0;
   };
   auto decode_shift = [&](int y) __attribute__((always_inline)) {
     if (!run) return;
@@ -914,11 +951,16 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
       TEAM_PROF_BIT();
       decode_shift(y);
       ch += ch + y;
-      update(bitc, y);
-      c8 += c8 + y;
-      TEAM_PROF(4);
+      if constexpr (B != 7 || !ZPQ_TEAM_LATE_UPDATE7) {
+        update(bitc, y);
+        c8 += c8 + y;
+        TEAM_PROF(4);
+      }
       if constexpr (B == 7) {
-        const int e = run_hcomp((unsigned)(c8 - 256));
+        // HCOMP needs the byte, not the trained components: it runs first, and the last bit's update behind [C], while the
+        // row wavefronts are out for the next byte's rows (it reads h, c8 and the contexts of the byte that ends: they
+        // change only below)
+        const int e = run_hcomp((unsigned)((ZPQ_TEAM_LATE_UPDATE7 ? c8 + c8 + y : c8) - 256));
         if (run && e) { status = e; run = false; }
         if (run) {
           if (ci == 0) out_ptr[nout] = (unsigned char)(ch - 256);
@@ -930,6 +972,10 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
         TEAM_PROF(5);
         ZPQ_TEAM_BARRIER();                                  // [C]
         TEAM_PROF(6);
+        if constexpr (ZPQ_TEAM_LATE_UPDATE7) {
+          update(bitc, y);
+          TEAM_PROF(4);
+        }
         any = any_running();
         h = vm_H[(unsigned)ci & Chain::HMASK];
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {

@@ -160,8 +160,8 @@ def compile_one(args):
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label",
            "-mllvm", "-simplifycfg-sink-common=false",     # keeps the kernel's register state out of scratch
            "-I", inc, "--genco", tmp, "-o", out + ".tmp"]
-    if os.environ.get("ZPAQ_AMD_SPEC_DEFS"):
-        cmd.insert(1, os.environ["ZPAQ_AMD_SPEC_DEFS"])
+    if os.environ.get("ZPAQ_AMD_SPEC_DEFS"):      # extra options separated by blanks (the cache key covers them: spec_loader.cpp)
+        cmd[1:1] = os.environ["ZPAQ_AMD_SPEC_DEFS"].split()
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     os.remove(tmp)
     if r.returncode != 0:
