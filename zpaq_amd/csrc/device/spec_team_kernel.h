@@ -91,6 +91,12 @@ __device__ __forceinline__ int sp_squash(const TeamTables& T, int p) {         /
 #ifndef ZPQ_TEAM_LATE_UPDATE7
 #define ZPQ_TEAM_LATE_UPDATE7 1
 #endif
+// ZPQ_TEAM_LATE_STORES: the row wavefronts' global stores (the row that is left, the entry trained in a side table that
+// stayed in the arena) are issued behind [A] instead of in front of the next prediction's dependent loads -- vmcnt counts
+// in order, so a load issued after a store is not there before the store has been acknowledged
+#ifndef ZPQ_TEAM_LATE_STORES
+#define ZPQ_TEAM_LATE_STORES 1
+#endif
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
 #define TEAM_PROF_DECL unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_t_ = __builtin_readcyclecounter(), tp_n_ = 0;
 #define TEAM_PROF(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t_; tp_t_ = n_; } while (0)
@@ -246,6 +252,8 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
   int p = 0, sq = 0;
   unsigned row0 = 0, row1 = 0, row2 = 0, row3 = 0, rowoff = 0;
   unsigned touch_a = 0, touch_b = 0;
+  uint4 wb = make_uint4(0, 0, 0, 0);
+  unsigned wboff = 0;
 #if ZPQ_TEAM_EARLY2
   uint4 ea0 = make_uint4(0, 0, 0, 0), ea1 = ea0, ea2 = ea0, eb0 = ea0, eb1 = ea0, eb2 = ea0;
 #endif
@@ -295,7 +303,12 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         uint4 r2 = G128(roff + (h0 ^ 32u));
 #endif
         const uint4 oldrow = make_uint4(row0, row1, row2, row3);
+#if ZPQ_TEAM_LATE_STORES
+        wb = oldrow;
+        wboff = rowoff;
+#else
         G128(roff + rowoff) = oldrow;
+#endif
         if (rowoff == h0) r0 = oldrow;
         if (rowoff == (h0 ^ 16u)) r1 = oldrow;
         if (rowoff == (h0 ^ 32u)) r2 = oldrow;
@@ -321,6 +334,11 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         if constexpr (nib) {                                  // new row: nothing was fetched ahead
           g0 = G32(soff + 4u * sidx);
           g1 = G32(soff + 4u * sidx + 4u);
+#if ZPQ_TEAM_LATE_STORES
+          const bool fwd = sidx == le0;                       // (the entry trained a bit ago is not in memory yet)
+          g0 = fwd ? ln0 : g0;
+          g1 = fwd ? ln1 : g1;
+#endif
         } else {
           const bool fwd = sidx == le0;
           g0 = fwd ? ln0 : (ylast ? scb0 : sca0);
@@ -346,6 +364,17 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       // ---- while the mixers work: what the update and the next bit will need
       sq = sp_squash(T, sp_clamp2k(p));
       const int pj = sp_shr1(p);
+#if ZPQ_TEAM_LATE_STORES
+      if constexpr (nib) G128(roff + wboff) = wb;
+      if constexpr (Chain::ANY_GLOBAL_SIDE) {
+        const bool pend = le0 != 0xFFFFFFFFu;
+        unsigned so0 = pend ? soff + 4u * le0 : dummy, so1 = pend ? s1base + 4u * (le0 & s1mask) : dummy + 4u;
+        ZPQ_OPAQUE(so0);
+        ZPQ_OPAQUE(so1);
+        G32(so0) = ln0;
+        G32(so1) = ln1;
+      }
+#endif
       if constexpr (last_of_nibble) {
         // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
         const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
@@ -381,8 +410,10 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         side_lds_put(bh, n0, n1);
         if constexpr (Chain::ANY_GLOBAL_SIDE) {
           const unsigned sidx = side_global ? e0 : 0u;
+#if !ZPQ_TEAM_LATE_STORES
           G32(soff + 4u * sidx) = n0;
           G32(s1base + 4u * (sidx & s1mask)) = n1;
+#endif
           le0 = sidx; ln0 = n0; ln1 = is_isse ? n1 : v1;
         }
         ylast = y;
