@@ -98,13 +98,19 @@ __device__ __forceinline__ int sp_squash(const TeamTables& T, int p) {         /
 #define ZPQ_TEAM_LATE_STORES 1
 #endif
 #if defined(ZPQ_PROF) && !defined(ZPQ_EMU)
-#define TEAM_PROF_DECL unsigned long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_t_ = __builtin_readcyclecounter(), tp_n_ = 0;
+#define TEAM_PROF_DECL unsigned long long tp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t_ = __builtin_readcyclecounter(), tp_n_ = 0;
 #define TEAM_PROF(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t_; tp_t_ = n_; } while (0)
 #define TEAM_PROF_BIT() (++tp_n_)
+#ifdef ZPQ_PROF2       // (profile build only) every memory operation of the wavefront has landed; then the phase counter
+#define TEAM_PROF_VM(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TEAM_PROF(k); } while (0)
+#else
+#define TEAM_PROF_VM(k) do {} while (0)
+#endif
 #else
 #define TEAM_PROF_DECL
 #define TEAM_PROF(k) do {} while (0)
 #define TEAM_PROF_BIT() do {} while (0)
+#define TEAM_PROF_VM(k) do {} while (0)
 #endif
 
 // Rows a bit's tables select are fetched one bit ahead (both candidates).  -DZPQ_TOUCH2=1 (off by default: measured -2 % on the MI355X, profiles/r04): the four rows the
@@ -283,6 +289,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
       // ---- predict: Predictor::find per nibble, bit history, side table, ISSE chains
       if constexpr (nib) {
         ZPQ_KEEP2(touch_a, touch_b);
+        TEAM_PROF_VM((B == 0 ? 8 : 11));                      // what is still in flight from before (B = 4: the early rows)
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
         const unsigned h0 = (cx * 16u) & (rmask - 15u);
@@ -302,6 +309,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         uint4 r1 = G128(roff + (h0 ^ 16u));
         uint4 r2 = G128(roff + (h0 ^ 32u));
 #endif
+        TEAM_PROF_VM((B == 0 ? 9 : 12));                      // (B = 0: the rows)
         const uint4 oldrow = make_uint4(row0, row1, row2, row3);
 #if ZPQ_TEAM_LATE_STORES
         wb = oldrow;
@@ -346,6 +354,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         }
         q0 = side_global ? g0 : q0;
         q1 = side_global ? g1 : q1;
+        if constexpr (nib) TEAM_PROF_VM((B == 0 ? 10 : 13));  // the entries of the side tables that stayed in the arena
       }
       v0 = q0;
       v1 = q1;
@@ -443,6 +452,13 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
            "second nibble=%.0f; per bit: wait[A]=%.0f idle-window work=%.0f wait[B]=%.0f wait[C]/8=%.0f\n",
            tp_n_, (double)tp_[0] / (tp_n_ * 0.75), (double)tp_[5] / (tp_n_ * 0.125), (double)tp_[6] / (tp_n_ * 0.125), (double)tp_[1] / tp_n_,
            (double)tp_[2] / tp_n_, (double)tp_[3] / tp_n_, (double)tp_[4] / tp_n_);
+#ifdef ZPQ_PROF2
+  if (blockIdx.x == 0 && wave == 0 && lane == 0 && tp_n_)
+    printf("[zpq team prof] rows, a byte's first bit: in flight from before=%.0f rows=%.0f side entries in the arena=%.0f rest=%.0f; second nibble's "
+           "first bit: update + early rows=%.0f (rows)=%.0f side entries=%.0f rest=%.0f\n",
+           (double)tp_[8] / (tp_n_ * 0.125), (double)tp_[9] / (tp_n_ * 0.125), (double)tp_[10] / (tp_n_ * 0.125), (double)tp_[5] / (tp_n_ * 0.125),
+           (double)tp_[11] / (tp_n_ * 0.125), (double)tp_[12] / (tp_n_ * 0.125), (double)tp_[13] / (tp_n_ * 0.125), (double)tp_[6] / (tp_n_ * 0.125));
+#endif
 #endif
 }
 
