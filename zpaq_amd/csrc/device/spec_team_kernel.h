@@ -481,67 +481,6 @@ constexpr bool mix2_pf(const CompK& c) { return c.a5 == 255u && c.mask0 >= 255u;
 typedef unsigned long long __attribute__((aligned(1))) team_u64u;
 typedef __attribute__((address_space(1))) const team_u64u g_u64u;
 
-// HCOMP's M array behind a register window (ZPQ_TEAM_MWIN).  The context programs compressBlock's methods generate use M as a
-// history buffer: push the new byte below the last one (c = c - 1; M[c] = a), then read M[c], M[c + 1], ... a few bytes up.
-// The window holds the 8 bytes at `base` and above; a store just below `base` moves it down, any other store inside it
-// patches it, every store also goes to memory, a load outside it comes from memory: exact for every program, a few ALU
-// instructions per access for those that behave like the standard ones -- and HCOMP, which runs between a byte's last bit
-// and [C] with every other wavefront waiting, does not wait for memory.  (Measured without gain while the last bit's update
-// still ran in front of HCOMP: the loads then waited for that update's stores either way.)
-#ifndef ZPQ_TEAM_MWIN
-#define ZPQ_TEAM_MWIN 1
-#endif
-// HCOMP's H array (ZPQ_TEAM_HWRITE1): every lane of a half runs the program on identical values; only one of them stores
-// into H, the others into a word of their own -- 32 lanes storing to ONE LDS address are 32 passes through the bank.
-#ifndef ZPQ_TEAM_HWRITE1
-#define ZPQ_TEAM_HWRITE1 1
-#endif
-struct TeamVmH {
-  lds_u32* h;
-  lds_u32* sink;                // this lane's own word when it is not the writer, h otherwise
-  unsigned keep;                // ~0u for the writer, 0 for the others
-  struct Ref {
-    const TeamVmH& m;
-    unsigned i;
-    __device__ __forceinline__ operator unsigned() const { return m.h[i]; }
-    __device__ __forceinline__ const Ref& operator=(unsigned x) const {
-      m.sink[i & m.keep] = x;
-      return *this;
-    }
-    __device__ __forceinline__ const Ref& operator=(const Ref& o) const { return *this = (unsigned)o; }
-  };
-  __device__ __forceinline__ Ref operator[](unsigned i) const { return Ref{*this, i}; }
-};
-
-template <unsigned MMASK>
-struct TeamVmMem {
-  g_u8* mem;
-  unsigned long long& win;      // byte k (bits 8k .. 8k + 7) = M[(base + k) & MMASK]
-  unsigned& base;
-  struct Ref {
-    const TeamVmMem& m;
-    unsigned i;
-    __device__ __forceinline__ operator unsigned() const {
-      if constexpr (MMASK < 15u) return m.mem[i];
-      const unsigned o = (i - m.base) & MMASK;
-      unsigned v;
-      if (o < 8u) v = (unsigned)(m.win >> (8u * o)) & 255u;
-      else { v = m.mem[i]; ZPQ_OPAQUE(v); }
-      return v;
-    }
-    __device__ __forceinline__ const Ref& operator=(unsigned char x) const {
-      m.mem[i] = x;
-      if constexpr (MMASK >= 15u) {
-        const unsigned o = (i - m.base) & MMASK;
-        if (o < 8u) m.win = (m.win & ~(255ull << (8u * o))) | ((unsigned long long)x << (8u * o));
-        else if (((m.base - 1u - i) & MMASK) == 0u) { m.win = m.win << 8 | x; m.base = i; }
-      }
-      return *this;
-    }
-  };
-  __device__ __forceinline__ Ref operator[](unsigned i) const { return Ref{*this, i}; }
-};
-
 template <class Chain, class TT>
 __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks,
                                             int tw, int lane) {
@@ -588,20 +527,9 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
 
   // HCOMP machine of this half (every lane of the half runs it: identical values, identical stores)
   unsigned vm_b = 0, vm_c = 0, vm_d = 0, vm_f = 0;
-#if ZPQ_TEAM_MWIN
-  unsigned long long vm_mwin = 0;
-  unsigned vm_mbase = 0;
-  const TeamVmMem<Chain::MMASK> vm_M{arena + (unsigned)Chain::OFF_M + hoff, vm_mwin, vm_mbase};
-#else
   g_u8* const vm_M = arena + (unsigned)Chain::OFF_M + hoff;
-#endif
   g_u32* const vm_R = (g_u32*)(arena + (unsigned)Chain::OFF_R + hoff);
-#if ZPQ_TEAM_HWRITE1
-  const TeamVmH vm_H{(lds_u32*)(wl + Chain::H_LDS),
-                     ci == 0 ? (lds_u32*)(wl + Chain::H_LDS) : (lds_u32*)(wl + (unsigned)(kRegion - 512) + (unsigned)ci * 8u), ci == 0 ? ~0u : 0u};
-#else
   lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
-#endif
 
   const bool is_cm = ctype == C_CM, is_match = ctype == C_MATCH;
   const bool is_rowc = ctype == C_ICM || ctype == C_ISSE;     // predicted by the row wavefronts
@@ -1096,7 +1024,7 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
           TEAM_PROF(4);
         }
         any = any_running();
-        h = ((lds_u32*)(wl + Chain::H_LDS))[(unsigned)ci & Chain::HMASK];
+        h = vm_H[(unsigned)ci & Chain::HMASK];
         static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(ic)::value;
           constexpr CompK c = Chain::comp[i];
