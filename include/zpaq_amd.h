@@ -271,6 +271,15 @@ int zpq_preprocess_block(const char* xmethod, uint8_t* data, uint32_t n, uint8_t
  * zpq_compress_blocks does for a batch.  For a method with E8E9 (x.,5 / x.,6 / x.,7) the caller filters first with
  * zpq_e8e9 -- the suffixes sorted are those of the filtered bytes -- and this call then does not filter again. */
 int zpq_preprocess_block_sa(const char* xmethod, uint8_t* data, uint32_t n, const uint32_t* sa, uint8_t* out, size_t cap, size_t* len);
+/* The pre-processors behind the sort for n buffers in one device call: the suffix sort, the LZ77 parse (LZBuffer::fill with a
+   suffix array, libzpaq.cpp:6693-6757) and the BWT's last column run on the GPU (device/lz77_kernel.h), the parse comes back
+   as a list of matches (4 x uint32: position of the search, offset, length, literals in front) and the host writes LZBuffer's
+   codes from it (6759-6883).  zpq_preprocess_blocks_device returns what zpq_preprocess_block does, buffer by buffer;
+   zpq_lz77_tokens_host is the host's list, zpq_lz77_serialize the coder. */
+int zpq_preprocess_blocks_device(const char* xmethod, uint8_t* const* data, const uint32_t* len, uint32_t n, uint8_t* const* out, const size_t* cap,
+                                 size_t* outlen);
+int zpq_lz77_tokens_host(const char* xmethod, uint8_t* data, uint32_t n, uint32_t* tokens4, size_t cap, size_t* count);
+int zpq_lz77_serialize(const char* xmethod, const uint8_t* data, uint32_t n, const uint32_t* tokens4, size_t ntok, uint8_t* out, size_t cap, size_t* len);
 void zpq_e8e9(uint8_t* data, uint32_t n);      /* e8e9 (libzpaq.cpp:6450-6459), in place */
 /* Compiler alone (libzpaq.cpp:2698): ZPAQL source text -> header / PCOMP bytes. */
 int zpq_assemble(const char* config, const int* args9, uint8_t* hcomp, size_t hcap,

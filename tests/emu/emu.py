@@ -290,3 +290,44 @@ def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, out
             status, consumed = int(line[3]), int(line[7])
             res.append((open(os.path.join(td, f"out.{i}"), "rb").read(), status, consumed))
         return res
+
+
+def build_lz77() -> str:
+    """The emulator executable of the pre-processor kernels behind the suffix sort (device/lz77_kernel.h)."""
+    import zpaq_amd as z
+    dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
+    srcs = (os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "lz77_emu_main.cpp"),
+            os.path.join(dev, "lz77_kernel.h"), os.path.join(dev, "layout.h"))
+    flags = _sanitize_flags()
+    key = hashlib.sha1(b"".join(open(p, "rb").read() for p in srcs) + " ".join(flags).encode()).hexdigest()[:20]
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, f"lz77_{key}")
+    if os.path.exists(exe):
+        return exe
+    libdir = os.path.dirname(z.library_path())
+    cmd = ["g++", "-O1", "-std=c++17", "-w", *flags, "-I", EMU, "-I", dev, "-I", os.path.join(ROOT, "include"),
+           os.path.join(EMU, "lz77_emu_main.cpp"), os.path.join(EMU, "wave_emu.cpp"), "-L", libdir, "-lzpaq_amd", f"-Wl,-rpath,{libdir}", "-o", exe + ".tmp"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("lz77 emulator build failed:\n" + r.stdout[-6000:])
+    os.replace(exe + ".tmp", exe)
+    return exe
+
+
+def lz77_run(kind: int, min_match: int, lookahead: int, bucket: int, checkbits: int, inputs: Sequence[bytes]):
+    """device/lz77_kernel.h on the emulator: per input the token list (kind 1 / 2: 16 bytes per match) or the BWT stream
+    (kind 3: n + 5 bytes) the device would hand back."""
+    exe = build_lz77()
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for k, data in enumerate(inputs):
+            pth = os.path.join(td, f"in{k}")
+            with open(pth, "wb") as fh:
+                fh.write(bytes(data))
+            paths.append(pth)
+        prefix = os.path.join(td, "out")
+        r = subprocess.run([exe, str(kind), str(min_match), str(lookahead), str(bucket), str(checkbits), prefix, *paths],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"lz77 emulator failed ({r.returncode}):\n" + r.stdout[-4000:])
+        return [open(f"{prefix}.{k}", "rb").read() for k in range(len(inputs))]

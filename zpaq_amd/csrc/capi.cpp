@@ -435,6 +435,76 @@ int zpq_preprocess_block_sa(const char* xmethod, uint8_t* data, uint32_t n, cons
   ZPQ_CATCH
 }
 
+// ---- the LZ77 parse through a suffix array as a token list (host/common.hpp LzToken: i, off, len, blit) ----
+static void lz_args(const char* xmethod, int args[9]) {
+  if (!xmethod) fail(ZPQ_E_ARG, "null argument");
+  (void)make_config(xmethod, args);
+  const int level = args[1] & 3;
+  if (args[1] < 1 || args[1] > 7 || level < 1 || level > 2 || args[5] - args[0] < 21) fail(ZPQ_E_ARG, "not an LZ77 method that searches a suffix array");
+}
+
+// The host's parse of one block (data is E8E9-filtered in place first when the method says so).
+int zpq_lz77_tokens_host(const char* xmethod, uint8_t* data, uint32_t n, uint32_t* tokens4, size_t cap, size_t* count) {
+  ZPQ_TRY
+  if ((!data && n) || !count) fail(ZPQ_E_ARG, "null argument");
+  int args[9];
+  lz_args(xmethod, args);
+  if (args[1] > 4) e8e9_forward(data, n);
+  std::vector<LzToken> toks;
+  lz77_host_tokens(data, n, args, nullptr, toks);
+  *count = toks.size();
+  if (toks.size() > cap) fail(ZPQ_E_OVERFLOW, "token buffer too small");
+  if (!toks.empty()) memcpy(tokens4, toks.data(), toks.size() * sizeof(LzToken));
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+// The coded stream of a token list (what zpq_preprocess_block returns for the same block and the host's list); `data` as the
+// parse saw it (E8E9 already applied).
+int zpq_lz77_serialize(const char* xmethod, const uint8_t* data, uint32_t n, const uint32_t* tokens4, size_t ntok, uint8_t* out, size_t cap, size_t* len) {
+  ZPQ_TRY
+  if ((!data && n) || (!tokens4 && ntok) || !len) fail(ZPQ_E_ARG, "null argument");
+  int args[9];
+  lz_args(xmethod, args);
+  std::vector<U8> pre;
+  lz77_serialize(data, n, args, (const LzToken*)tokens4, ntok, pre);
+  *len = pre.size();
+  if (pre.size() > cap) fail(ZPQ_E_OVERFLOW, "output buffer too small");
+  if (!pre.empty()) memcpy(out, pre.data(), pre.size());
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
+// What zpq_preprocess_block makes, for n host buffers in one call with the sort, the LZ77 parse and the BWT on the device
+// (device/sa_kernels.hip, device/lz77_kernel.h); only for methods whose pre-processor sorts.  E8E9 is applied in place.
+int zpq_preprocess_blocks_device(const char* xmethod, uint8_t* const* data, const uint32_t* len, uint32_t n, uint8_t* const* out, const size_t* cap,
+                                 size_t* outlen) {
+  ZPQ_TRY
+  if (!xmethod || (n && (!data || !len || !out || !cap || !outlen))) fail(ZPQ_E_ARG, "null argument");
+  int args[9];
+  (void)make_config(xmethod, args);
+  if (!preprocess_needs_suffix_array(args)) fail(ZPQ_E_ARG, "the method's pre-processor does not sort");
+  std::vector<SortJob> jobs;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (args[1] > 4) e8e9_forward(data[i], len[i]);
+    jobs.push_back(sort_job(data[i], len[i], args));
+  }
+  std::vector<SortOut> outs;
+  std::string note;
+  if (!engine_sort_preprocess(jobs, outs, note)) fail(ZPQ_E_UNSUPPORTED, "pre-processing on the device unavailable: " + note);
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<U8> pre;
+    if (len[i] == 0) (void)preprocess_block(data[i], 0, args, pre, nullptr, true);
+    else if (jobs[i].kind == 3) pre.swap(outs[i].bwt);
+    else lz77_serialize(data[i], len[i], args, outs[i].toks.data(), outs[i].toks.size(), pre);
+    outlen[i] = pre.size();
+    if (pre.size() > cap[i]) fail(ZPQ_E_OVERFLOW, "output buffer too small");
+    if (!pre.empty()) memcpy(out[i], pre.data(), pre.size());
+  }
+  return ZPQ_OK;
+  ZPQ_CATCH
+}
+
 int zpq_sha1_batch_device(const uint8_t* const* in, const uint32_t* len, uint32_t n, uint8_t* out20n) {
   ZPQ_TRY
   if (n && (!in || !len || !out20n)) fail(ZPQ_E_ARG, "null argument");

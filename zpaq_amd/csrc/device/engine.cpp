@@ -1454,6 +1454,103 @@ bool engine_suffix_arrays(const std::vector<std::pair<const U8*, U32>>& blocks, 
   return true;
 }
 
+bool engine_sort_preprocess(const std::vector<SortJob>& jobs, std::vector<SortOut>& out, std::string& note) {
+  const size_t n = jobs.size();
+  out.assign(n, SortOut());
+  uint64_t total = 0, ntok = 0, bwt_bytes = 0;
+  uint32_t max_len = 0;
+  bool any_lz = false, any_bwt = false;
+  std::vector<LzBlock> blk(n);
+  for (size_t i = 0; i < n; ++i) {
+    const SortJob& j = jobs[i];
+    LzBlock& B = blk[i];
+    memset(&B, 0, sizeof(B));
+    B.off = total;
+    B.n = j.n;
+    B.kind = j.n ? j.kind : 0u;
+    B.min_match = j.min_match; B.lookahead = j.lookahead; B.bucket = j.bucket; B.checkbits = j.checkbits;
+    if (B.kind == 1 || B.kind == 2) {
+      if (j.min_match < 1 || j.lookahead > 255 || j.checkbits < 1 || j.checkbits > 31) { note = "LZ77 parameters outside the device parser's range"; return false; }
+      B.tok_off = ntok;
+      B.tok_cap = j.n / j.min_match + 2;
+      ntok += B.tok_cap;
+      any_lz = true;
+    } else if (B.kind == 3) {
+      any_bwt = true;
+    } else if (B.kind != 0) { note = "unknown pre-processor kind"; return false; }
+    total += j.n;
+    max_len = std::max(max_len, j.n);
+  }
+  if (!total) return true;
+  bwt_bytes = any_bwt ? total + n : 0;
+  if (n > 65535 || max_len >= (1u << 24) || total >= (1ull << 31)) { note = "batch outside the device sorter's range"; return false; }
+  Engine& e = eng();
+  std::lock_guard<std::mutex> g(e.mu);
+  require_ready(e);
+  bind_device(e);
+  wait_in_flight(e);
+  const size_t ws = sa_workspace_bytes(total, (uint32_t)n);
+  const uint64_t in_bytes = (total + 255) & ~255ull;
+  // behind the arrays in io_out: decisions (16 B per element), tokens, BWT bytes, counts and indices, the block table
+  const uint64_t o_res = (4 * total + 255) & ~255ull;
+  const uint64_t o_tok = o_res + (any_lz ? 16 * total : 0);
+  const uint64_t o_bwt = o_tok + 16 * ntok;
+  const uint64_t o_cnt = (o_bwt + bwt_bytes + 255) & ~255ull;
+  const uint64_t o_idx = o_cnt + 4 * n;
+  const uint64_t o_blk = (o_idx + 4 * n + 255) & ~255ull;
+  const uint64_t out_bytes = o_blk + n * sizeof(LzBlock) + 256;
+  if (ws + in_bytes + out_bytes + (1u << 20) > e.budget) { note = "sort + parse workspace exceeds the device budget"; return false; }
+  e.io_in.ensure(in_bytes + 64);
+  e.io_out.ensure(out_bytes);
+  e.arena.ensure(ws);
+  e.jobs.ensure((n + 2) * 16 + 64);
+  std::vector<const uint8_t*> ptrs(n);
+  std::vector<uint64_t> off(n + 1, 0);
+  const bool pinned = in_bytes >= (1u << 20) && e.pin_in.ensure(in_bytes + 64);
+  std::unique_ptr<uint8_t[]> pageable;
+  uint8_t* stage = pinned ? (uint8_t*)e.pin_in.p : (pageable.reset(new uint8_t[in_bytes + 64]), pageable.get());
+  for (size_t i = 0; i < n; ++i) {
+    ptrs[i] = (const uint8_t*)e.io_in.p + off[i];
+    if (jobs[i].n) memcpy(stage + off[i], jobs[i].data, jobs[i].n);
+    off[i + 1] = off[i] + jobs[i].n;
+  }
+  uint8_t* meta = (uint8_t*)e.jobs.p;
+  uint8_t* const ob = (uint8_t*)e.io_out.p;
+  HIP_CHECK(hipMemcpyAsync(e.io_in.p, stage, total, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(meta, ptrs.data(), n * 8, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(meta + ((n * 8 + 15) & ~15ull), off.data(), (n + 1) * 8, hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemcpyAsync(ob + o_blk, blk.data(), n * sizeof(LzBlock), hipMemcpyHostToDevice, e.stream));
+  HIP_CHECK(hipMemsetAsync(ob + o_cnt, 0, 8 * n, e.stream));
+  uint32_t rounds = 0;
+  SaSideArrays side;
+  hipError_t rc = build_suffix_arrays((const uint8_t* const*)meta, (const uint64_t*)(meta + ((n * 8 + 15) & ~15ull)), (uint32_t)n, total, max_len,
+                                      (uint32_t*)ob, e.arena.p, e.arena.cap, e.stream, &rounds, &side);
+  if (rc == hipSuccess)
+    rc = launch_sort_preprocessors((const uint8_t*)e.io_in.p, (const uint32_t*)ob, side, (const LzBlock*)(ob + o_blk), (uint32_t)n, total, any_lz, any_bwt,
+                                   ob + o_res, (LzTok*)(ob + o_tok), (uint32_t*)(ob + o_cnt), ob + o_bwt, (uint32_t*)(ob + o_idx), e.stream);
+  if (rc != hipSuccess) { (void)hipGetLastError(); note = std::string("device sort / parse failed: ") + hipGetErrorString(rc); return false; }
+  std::vector<uint32_t> cnt(2 * n);
+  HIP_CHECK(hipMemcpyAsync(cnt.data(), ob + o_cnt, 8 * n, hipMemcpyDeviceToHost, e.stream));
+  HIP_CHECK(hipStreamSynchronize(e.stream));
+  static_assert(sizeof(LzTok) == sizeof(LzToken) && sizeof(LzTok) == 16, "token layouts");
+  for (size_t i = 0; i < n; ++i) {
+    const LzBlock& B = blk[i];
+    if (B.kind == 1 || B.kind == 2) {
+      if (cnt[i] > B.tok_cap) { note = "LZ77 token list overflowed"; return false; }
+      out[i].toks.resize(cnt[i]);
+      if (cnt[i]) HIP_CHECK(hipMemcpyAsync(out[i].toks.data(), ob + o_tok + 16 * B.tok_off, 16ull * cnt[i], hipMemcpyDeviceToHost, e.stream));
+    } else if (B.kind == 3) {
+      out[i].bwt.resize((size_t)B.n + 5);
+      HIP_CHECK(hipMemcpyAsync(out[i].bwt.data(), ob + o_bwt + B.off + i, (size_t)B.n + 1, hipMemcpyDeviceToHost, e.stream));
+      uint32_t idx = cnt[n + i];
+      for (int k = 0; k < 4; ++k) { out[i].bwt[(size_t)B.n + 1 + k] = (U8)idx; idx >>= 8; }
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(e.stream));
+  note = "device, " + std::to_string(rounds) + " doubling rounds";
+  return true;
+}
+
 int engine_jit_threads() { return jit_threads(); }
 
 int engine_selftest(int32_t out[8]) {

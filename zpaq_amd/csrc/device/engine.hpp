@@ -67,6 +67,18 @@ void engine_sha1_host(const uint8_t* const* in, const uint32_t* len, uint32_t n,
 // Suffix arrays of host buffers, all in one device call (device/sa_kernels.hip: prefix doubling over the whole batch).
 // false + note when the device declines (then the host sorts): a buffer of 2^24 bytes or more, too many buffers, memory.
 bool engine_suffix_arrays(const std::vector<std::pair<const U8*, U32>>& blocks, std::vector<std::vector<U32>>& sa, std::string& note);
+// The pre-processors behind the sort for a whole batch on the device (device/lz77_kernel.h): blocks of kind 1 / 2 come back as
+// the LZ77 parse's list of matches (host/preproc.cpp lz77_serialize codes it), blocks of kind 3 as the BWT stream
+// preprocess_block would make (n + 5 bytes).  false + note when the device declines (then the host does it all).
+struct SortJob { const U8* data; U32 n; U32 kind, min_match, lookahead, bucket, checkbits; };
+struct SortOut { std::vector<LzToken> toks; std::vector<U8> bwt; };
+bool engine_sort_preprocess(const std::vector<SortJob>& jobs, std::vector<SortOut>& out, std::string& note);
+// the job of a block whose method has these args (LZBuffer's parameters: libzpaq.cpp:6647-6692)
+inline SortJob sort_job(const U8* data, U32 n, const int args[9]) {
+  const U32 level = (U32)(args[1] & 3);
+  if (level == 3) return SortJob{data, n, 3u, 0u, 0u, 0u, 0u};
+  return SortJob{data, n, level, (U32)args[2], (U32)args[6], args[4] >= 0 && args[4] < 31 ? (1u << args[4]) - 1u : 0x7FFFFFFFu, (U32)(17 + args[0])};
+}
 int engine_selftest(int32_t out[8]);
 int engine_jit_threads();      // host threads spec_precompile() uses by default (the host cores the process may use, at most 16)
 

@@ -171,6 +171,18 @@ static const int kTeamTablesBytes = 2016 * 4 + 256 * 2 + 2688 + 4096 + 512 + 102
 static inline constexpr int team_block_lds_bytes() { return ((kSpecLdsBudget - kTeamTablesBytes) / 8) & ~15; }   // 18336
 static const int kTeamIcmLds = 256 * 2 + 256, kTeamIsseLds = 256 * 4 + 256;                  // 768, 1280 bytes per table
 
+// The pre-processors behind the suffix sort (device/lz77_kernel.h, device/sa_kernels.hip)
+struct LzBlock {            // one per block of the batch
+  uint64_t off;             // its first element in the batch's arrays (bytes, suffix array, ranks, decisions)
+  uint64_t tok_off;         // its first slot in the token array
+  uint32_t n;
+  uint32_t tok_cap;
+  uint32_t kind;            // 1 / 2: LZ77 with bit-packed / byte-aligned codes; 3: BWT; 0: nothing to do here
+  uint32_t min_match, lookahead, bucket, checkbits;     // LZBuffer's parameters (args[2], args[6], 2^args[4] - 1, 17 + args[0])
+  uint32_t pad;
+};
+struct LzTok { uint32_t i, off, len, blit; };            // = host/common.hpp LzToken
+
 // Cap on HCOMP instructions per input byte: the reference has no limit (a
 // hostile header can loop forever); a device kernel must not hang.
 static const uint32_t kMaxVmSteps = 1u << 20;

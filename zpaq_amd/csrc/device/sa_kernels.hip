@@ -20,6 +20,7 @@
 
 #include <cstdint>
 
+#include "lz77_kernel.h"
 #include "sa_kernels.h"
 
 namespace zpq {
@@ -76,6 +77,18 @@ __global__ __launch_bounds__(256) void sa_invert_kernel(const uint32_t* rank, co
 
 inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
+__global__ __launch_bounds__(256) void lz77_search_kernel(const uint8_t* in_all, const uint32_t* sa_all, const uint32_t* rank_all, const uint16_t* blk,
+                                                          const LzBlock* blocks, uint64_t total, uint4* res) {
+  lz77_search_body(in_all, sa_all, rank_all, blk, blocks, total, res);
+}
+__global__ __launch_bounds__(64) void lz77_walk_kernel(const LzBlock* blocks, const uint4* res, LzTok* toks, uint32_t* counts) {
+  lz77_walk_body(blocks, res, toks, counts);
+}
+__global__ __launch_bounds__(256) void bwt_emit_kernel(const uint8_t* in_all, const uint32_t* sa_all, const uint16_t* blk, const LzBlock* blocks,
+                                                       uint64_t total, uint8_t* out_all, uint32_t* idx) {
+  bwt_emit_body(in_all, sa_all, blk, blocks, total, out_all, idx);
+}
+
 }  // namespace
 
 size_t sa_workspace_bytes(uint64_t total, uint32_t nblocks) {
@@ -90,7 +103,7 @@ size_t sa_workspace_bytes(uint64_t total, uint32_t nblocks) {
 // d_in[b] -> bytes of block b ON THE DEVICE, d_off[0..nblocks] = exclusive prefix sums of the lengths (device), total = d_off[nblocks];
 // d_sa receives the suffix arrays back to back (d_sa + off[b] = block b's).  `ws` = sa_workspace_bytes(total, nblocks) bytes of device memory.
 hipError_t build_suffix_arrays(const uint8_t* const* d_in, const uint64_t* d_off, uint32_t nblocks, uint64_t total, uint32_t max_len,
-                               uint32_t* d_sa, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* rounds_out) {
+                               uint32_t* d_sa, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* rounds_out, SaSideArrays* side) {
   if (!total) return hipSuccess;
   if (nblocks > 65535u || max_len >= (1u << 24) || total >= (1ull << 32)) return hipErrorInvalidValue;
   const size_t a = (size_t)((total + 63) & ~63ull);
@@ -132,6 +145,21 @@ hipError_t build_suffix_arrays(const uint8_t* const* d_in, const uint64_t* d_off
   }
   hipLaunchKernelGGL(sa_invert_kernel, dim3(g), dim3(256), 0, st, rank, blk, d_off, total, d_sa);
   if (rounds_out) *rounds_out = rounds;
+  if (side) { side->rank = rank; side->blk = blk; }
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_preprocessors(const uint8_t* in_all, const uint32_t* sa_all, const SaSideArrays& side, const LzBlock* blocks, uint32_t nblocks,
+                                     uint64_t total, bool any_lz, bool any_bwt, void* res, LzTok* toks, uint32_t* counts, uint8_t* bwt_out,
+                                     uint32_t* bwt_idx, hipStream_t st) {
+  if (!total || !nblocks) return hipSuccess;
+  const unsigned g = grid_for(total);
+  if (any_lz) {
+    hipLaunchKernelGGL(lz77_search_kernel, dim3(g), dim3(256), 0, st, in_all, sa_all, (const uint32_t*)side.rank, (const uint16_t*)side.blk, blocks, total, (uint4*)res);
+    hipLaunchKernelGGL(lz77_walk_kernel, dim3(nblocks), dim3(64), 0, st, blocks, (const uint4*)res, toks, counts);
+  }
+  if (any_bwt)
+    hipLaunchKernelGGL(bwt_emit_kernel, dim3(g), dim3(256), 0, st, in_all, sa_all, (const uint16_t*)side.blk, blocks, total, bwt_out, bwt_idx);
   return hipGetLastError();
 }
 

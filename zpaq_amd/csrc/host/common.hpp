@@ -92,5 +92,12 @@ std::vector<U32> suffix_array(const U8* in, U32 n);
 bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out, const U32* sa = nullptr, bool e8e9_done = false);
 // does this method's pre-processor sort the block's suffixes (BWT, or LZ77 searching through a suffix array)?
 bool preprocess_needs_suffix_array(const int args[9]);
+// The LZ77 parse through a suffix array as a list of matches, in order: the search stood at `i`, `blit` literals in front of
+// the match belong to it (a look-ahead match), then `len` bytes from `off` back.  Every position the list does not cover is
+// a literal.  lz77_host_tokens: the host's parse; lz77_serialize: the coded stream (LZBuffer's byte-aligned or bit-packed
+// codes, libzpaq.cpp:6647-6883) from a list -- the host's or the one device/lz77_kernel.h made for a whole batch.
+struct LzToken { U32 i, off, len, blit; };
+void lz77_host_tokens(const U8* data, U32 n, const int args[9], const U32* sa, std::vector<LzToken>& toks);
+void lz77_serialize(const U8* data, U32 n, const int args[9], const LzToken* toks, size_t ntok, std::vector<U8>& out);
 
 }  // namespace zpq

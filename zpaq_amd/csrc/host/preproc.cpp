@@ -178,7 +178,7 @@ namespace {
 // One block through LZ77 (level 1: bit-packed codes, level 2: byte-aligned codes).
 class Lz77 {
  public:
-  Lz77(const U8* in, U32 n, const int args[9], std::vector<U8>& out, const U32* sa = nullptr)
+  Lz77(const U8* in, U32 n, const int args[9], std::vector<U8>& out, const U32* sa = nullptr, bool emit_only = false)
       : in_(in), n_(n), out_(out), level_(args[1] & 3),
         use_sa_(args[5] - args[0] >= 21),
         checkbits_(use_sa_ ? 17 + args[0] : 12 - args[0]),
@@ -189,6 +189,7 @@ class Lz77 {
         min_both_((int)std::max<unsigned>(min_match_, min_match2_ + lookahead_) + 4),
         rb_(args[0] > 4 ? (unsigned)(args[0] - 4) : 0u) {
     if ((min_match_ < 4 && level_ == 1) || (min_match_ < 1 && level_ == 2)) fail(ZPQ_E_ARG, "match length $3 too small");
+    if (emit_only) return;                            // (emit_tokens only: nothing is searched)
     if (use_sa_) {
       if (sa) sa_.assign(sa, sa + n);                 // built on the device for the whole batch (device/sa_kernels.hip)
       else sa_ = suffix_array(in, n);
@@ -200,6 +201,36 @@ class Lz77 {
       if (args[5] < 1 || args[5] > 30) fail(ZPQ_E_ARG, "LZ77 hash table size out of range");
       ht_.assign((size_t)1 << args[5], 0);
     }
+  }
+
+  // The parse through a suffix array as a list of matches (what device/lz77_kernel.h produces for a whole batch): the
+  // position the search stood at, the literals in front of the match that belong to it, its length and offset.
+  void tokens(std::vector<LzToken>& toks) { toks_ = &toks; run(); toks_ = nullptr; }
+
+  // The coded stream from such a list: literal runs between the matches, flushed after kMaxLiteral of them as run() does.
+  void emit_tokens(const LzToken* toks, size_t ntok) {
+    static const unsigned kMaxLiteral = (1u << 14) / 4;
+    unsigned pos = 0, lit = 0;
+    for (size_t t = 0; t <= ntok; ++t) {
+      const unsigned stop = t < ntok ? toks[t].i : n_;
+      if (stop < pos || stop > n_) fail(ZPQ_E_DEVICE, "LZ77 token list out of order");
+      while (pos < stop) {                                       // literal steps: one byte each
+        const unsigned take = std::min(stop - pos, kMaxLiteral - lit);
+        lit += take;
+        pos += take;
+        if (lit >= kMaxLiteral) literals(pos, lit);
+      }
+      if (t == ntok) break;
+      const LzToken& k = toks[t];
+      if (k.off == 0 || k.off > k.i || k.len == 0 || (U64)k.i + k.blit + k.len > n_) fail(ZPQ_E_DEVICE, "LZ77 token out of range");
+      lit += k.blit;
+      literals(k.i + k.blit, lit);
+      match(k.len, k.off);
+      pos = k.i + k.blit + k.len;
+    }
+    literals(n_, lit);
+    if (nbits_ > 0) out_.push_back((U8)bits_);
+    bits_ = nbits_ = 0;
   }
 
   void run() {
@@ -293,9 +324,12 @@ class Lz77 {
       const unsigned off = i - bp;
       if (off > 0 && bscore > 0 &&
           blen - blit >= min_match_ + (level_ == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)))) {
-        lit += blit;
-        literals(i + blit, lit);
-        match(blen - blit, off);
+        if (toks_) { toks_->push_back(LzToken{i, off, blen - blit, blit}); lit = 0; }
+        else {
+          lit += blit;
+          literals(i + blit, lit);
+          match(blen - blit, off);
+        }
       } else {
         blen = 1;
         ++lit;
@@ -316,8 +350,9 @@ class Lz77 {
           ++i;
         }
       }
-      if (lit >= kMaxLiteral) literals(i, lit);
+      if (lit >= kMaxLiteral) { if (toks_) lit = 0; else literals(i, lit); }
     }
+    if (toks_) return;
     literals(n_, lit);
     if (nbits_ > 0) out_.push_back((U8)bits_);
     bits_ = nbits_ = 0;
@@ -411,6 +446,7 @@ class Lz77 {
   unsigned bits_ = 0, nbits_ = 0;
   std::vector<U32> ht_, sa_, isa_;
   unsigned isa_window_ = 0xFFFFFFFFu;     // first position of the window isa_ holds
+  std::vector<LzToken>* toks_ = nullptr;  // tokens(): matches are listed instead of coded
 };
 
 }  // namespace
@@ -448,8 +484,28 @@ bool preprocess_block(U8* data, U32 n, const int args[9], std::vector<U8>& out, 
   }
   out.reserve((size_t)n / 2 + 64);
   Lz77 lz(data, n, args, out, sa_in);
-  lz.run();
+  if (args[5] - args[0] >= 21) {                     // through a suffix array: the parse as a token list, then the coder --
+    std::vector<LzToken> toks;                       // the same coder takes the device's list (lz77_serialize)
+    lz.tokens(toks);
+    lz.emit_tokens(toks.data(), toks.size());
+  } else lz.run();
   return true;
+}
+
+void lz77_host_tokens(const U8* data, U32 n, const int args[9], const U32* sa, std::vector<LzToken>& toks) {
+  toks.clear();
+  if ((args[1] & 3) < 1 || (args[1] & 3) > 2 || args[5] - args[0] < 21) fail(ZPQ_E_ARG, "not an LZ77 method that searches a suffix array");
+  std::vector<U8> unused;
+  Lz77 lz(data, n, args, unused, sa);
+  lz.tokens(toks);
+}
+
+void lz77_serialize(const U8* data, U32 n, const int args[9], const LzToken* toks, size_t ntok, std::vector<U8>& out) {
+  out.clear();
+  if ((args[1] & 3) < 1 || (args[1] & 3) > 2) fail(ZPQ_E_ARG, "not an LZ77 method");
+  out.reserve((size_t)n / 2 + 64);
+  Lz77 lz(data, n, args, out, nullptr, true);
+  lz.emit_tokens(toks, ntok);
 }
 
 }  // namespace zpq
