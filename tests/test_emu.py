@@ -314,3 +314,49 @@ def test_random_models_through_both_coders(zlib_, oracle):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_emu
     assert fuzz_emu.run(2, 20260926, verbose=False) == 0
+
+
+def _host_tokens(L, xm, data):
+    import ctypes as C
+    u8p = C.POINTER(C.c_ubyte)
+    L.zpq_lz77_tokens_host.argtypes = [C.c_char_p, u8p, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]
+    buf = np.frombuffer(bytearray(data), np.uint8).copy() if data else np.zeros(1, np.uint8)
+    cap = len(data) + 4
+    toks = np.zeros(4 * cap, np.uint32)
+    cnt = C.c_size_t(0)
+    assert L.zpq_lz77_tokens_host(xm.encode(), buf.ctypes.data_as(u8p), len(data), toks.ctypes.data_as(C.POINTER(C.c_uint32)), cap, C.byref(cnt)) == 0, L.zpq_last_error()
+    return toks[:4 * cnt.value].tobytes(), buf[:len(data)].tobytes()
+
+
+def test_lz77_parse_and_bwt_kernels_against_the_host(zlib_):
+    """device/lz77_kernel.h on the emulator: the search (one lane per position, both values of the pending-literals bit), the
+    walk (one wavefront per block, v_readlane chain) and the BWT emit must give the host's list of matches / BWT stream -- whose
+    coded form the reference's archives pin (test_host.py) -- for both code levels, look-aheads 0..3, small and large buckets,
+    E8E9, ragged and tiny inputs, long repeats, and a block that crosses the inverse array's 2^17-position window."""
+    import ctypes as C
+    L = zlib_.lib()
+    u8p = C.POINTER(C.c_ubyte)
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ins = [corpus.block(kinds[i % 5], n, 100 + i).tobytes() if n else b"" for i, n in enumerate([3000, 1, 2, 70, 257, 5000, 9000, 0, 4097])]
+    ins.append(b"abcdefghij" * 700 + corpus.block("lcg", 500, 3).tobytes() + b"abcdefghij" * 300)
+    for xm in ("x0,2,5,0,7,21,1c0,0,511", "x0,1,4,0,3,21,1", "x0,2,12,0,7,21,1c0,0,511i2", "x0,6,5,0,2,21,0c0,0,511", "x0,2,4,0,7,21,3c0,0,511",
+               "x0,5,5,0,5,21,2"):
+        a = zlib_.method_to_header(xm)[2]
+        host = [_host_tokens(L, xm, d) for d in ins]
+        got = emu.lz77_run(a[1] & 3, a[2], a[6], (1 << a[4]) - 1, 17 + a[0], [h[1] for h in host])
+        for k, (h, g) in enumerate(zip(host, got)):
+            assert h[0] == g, (xm, k, len(ins[k]), len(h[0]) // 16, len(g) // 16)
+    big = corpus.block("text", 140000, 77).tobytes()
+    for xm in ("x0,2,5,0,7,21,1c0,0,511", "x0,1,4,0,3,21,2"):
+        a = zlib_.method_to_header(xm)[2]
+        ht, buf = _host_tokens(L, xm, big)
+        assert emu.lz77_run(a[1] & 3, a[2], a[6], (1 << a[4]) - 1, 17 + a[0], [buf])[0] == ht
+    # the BWT stream preprocess_block makes
+    L.zpq_preprocess_block.argtypes = [C.c_char_p, u8p, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    bw = [corpus.block(kinds[i % 5], n, 300 + i).tobytes() for i, n in enumerate([1, 2, 3, 1000, 4096, 7777])]
+    for d, g in zip(bw, emu.lz77_run(3, 0, 0, 0, 0, bw)):
+        buf = np.frombuffer(bytearray(d), np.uint8).copy()
+        out = np.zeros(len(d) + 16, np.uint8)
+        ln = C.c_size_t(0)
+        assert L.zpq_preprocess_block(b"x0,3ci1", buf.ctypes.data_as(u8p), len(d), out.ctypes.data_as(u8p), out.size, C.byref(ln)) == 0
+        assert out[:ln.value].tobytes() == g, (len(d), ln.value, len(g))

@@ -642,3 +642,49 @@ def test_suffix_arrays_on_the_device(gpu, ref):
         for d, a in zip(blocks, arch):
             assert a == ref.compress_block(d, method), (method, d.size)
     assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)
+
+
+def test_lz77_parse_and_bwt_on_the_device(gpu, ref, monkeypatch):
+    """The pre-processors behind the sort on the device (device/lz77_kernel.h; reference: LZBuffer::fill with a suffix array,
+    libzpaq.cpp:6693-6757, and divbwt's output): for a whole batch the stream zpq_preprocess_blocks_device returns -- sort,
+    parse and BWT on the GPU, LZBuffer's codes written by the host from the list of matches -- must be the host's, byte for
+    byte: both code levels, look-aheads 0..3, E8E9 in front, text / random / zeros / records / patterns, ragged, tiny and
+    empty buffers, a 1 MiB block (eight windows of the inverse array).  Then the archives of compressBlock's sorting methods,
+    from batches that take the device path, against the reference -- with the parse on the device and (knob) on the host."""
+    import ctypes as C
+    L = gpu.lib()
+    u8p = C.POINTER(C.c_ubyte)
+    L.zpq_preprocess_blocks_device.argtypes = [C.c_char_p, C.POINTER(u8p), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(u8p), C.POINTER(C.c_size_t),
+                                               C.POINTER(C.c_size_t)]
+    L.zpq_preprocess_block.argtypes = [C.c_char_p, u8p, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    sizes = [70000, 65536, 40000, 50001, 30000, 1, 2, 3, 0, 255, 256, 257, 1000, 99999, 1 << 20]
+    for xm in ("x0,2,5,0,7,21,1c0,0,511", "x0,1,4,0,3,21,1", "x0,2,12,0,7,21,1c0,0,511i2", "x0,6,5,0,2,21,0c0,0,511", "x0,2,4,0,7,21,3c0,0,511",
+               "x0,5,5,0,5,21,2", "x0,3ci1", "x0,7ci1"):
+        src = [corpus.block(kinds[i % 5], n, 70 + i) if n else np.zeros(0, np.uint8) for i, n in enumerate(sizes)]
+        dev_in = [np.concatenate([b, np.zeros(8, np.uint8)]) for b in src]        # (copies: E8E9 works in place)
+        n = len(src)
+        outs = [np.empty(b.size + b.size // 2 + 4096, np.uint8) for b in src]
+        IA = (u8p * n)(*[b.ctypes.data_as(u8p) for b in dev_in])
+        LN = (C.c_uint32 * n)(*[b.size for b in src])
+        OA = (u8p * n)(*[o.ctypes.data_as(u8p) for o in outs])
+        CP = (C.c_size_t * n)(*[o.size for o in outs])
+        OL = (C.c_size_t * n)()
+        assert L.zpq_preprocess_blocks_device(xm.encode(), IA, LN, n, OA, CP, OL) == 0, (xm, L.zpq_last_error().decode())
+        for k, b in enumerate(src):
+            host_in = b.copy() if b.size else np.zeros(1, np.uint8)
+            want = np.empty(outs[k].size, np.uint8)
+            wl = C.c_size_t(0)
+            assert L.zpq_preprocess_block(xm.encode(), host_in.ctypes.data_as(u8p), b.size, want.ctypes.data_as(u8p), want.size, C.byref(wl)) == 0
+            assert OL[k] == wl.value and (outs[k][:wl.value] == want[:wl.value]).all(), (xm, k, b.size, OL[k], wl.value)
+    blocks = [corpus.block(kinds[i % 4], 150000 + 1111 * i, 500 + i) for i in range(12)]
+    ph = (C.c_double * 8)()
+    for knob in ("1", "0"):
+        monkeypatch.setenv("ZPAQ_AMD_DEVICE_PARSE", knob)
+        for method in ("3", "3,128,1", "2", "x0,6,5,0,7,21,1c0,0,511", "x0,7ci1"):
+            arch = gpu.compress_blocks([b.copy() for b in blocks], method)
+            L.zpq_last_api_timing(ph)
+            assert int(ph[7]) == len(blocks), (method, ph[7])
+            for d, a in zip(blocks, arch):
+                assert a == ref.compress_block(d.copy(), method), (knob, method, d.size)
+        assert gpu.decompress(b"".join(arch)) == b"".join(b.tobytes() for b in blocks)

@@ -238,7 +238,12 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
   // all of them on the device when there are enough to fill it (device/sa_kernels.hip), the host's SA-IS per block otherwise
   // or when the device declines (no GPU, blocks of 16 MiB and more, not enough memory).  The array is canonical: either
   // source gives the reference's parse.  E8E9 comes first where the method has it (it changes the bytes that are sorted).
+  // ... and behind the sort, on the device as well (device/lz77_kernel.h): the LZ77 parse comes back as a list of matches the
+  // host only has to write LZBuffer's codes for, the BWT as its bytes -- 16 bytes per match or n + 5 bytes over PCIe instead
+  // of the 4 n of the array.  ZPAQ_AMD_DEVICE_PARSE=0: only the sort there, the host parses (the previous behaviour).
   std::vector<std::vector<U32>> dev_sa(nb);
+  std::vector<SortOut> dev_pre(nb);
+  std::vector<char> have_pre(nb, 0);
   {
     std::vector<size_t> sorting;
     U64 sort_bytes = 0;
@@ -252,16 +257,25 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
         const size_t b = sorting[k];
         if (front[b].args[1] > 4) e8e9_forward(in[b].data, in[b].n);
       });
-      std::vector<std::pair<const U8*, U32>> blk;
-      for (size_t b : sorting) blk.push_back({in[b].data, in[b].n});
-      std::vector<std::vector<U32>> sa;
       std::string note;
       bool got = false;
-      try { got = engine_suffix_arrays(blk, sa, note); } catch (const Failure&) { got = false; }      // (any device trouble: the host sorts)
-      for (size_t k = 0; k < sorting.size(); ++k) {
-        if (got) dev_sa[sorting[k]].swap(sa[k]);
-        front[sorting[k]].sorts = true;                 // (E8E9 is done either way)
+      const char* knob = getenv("ZPAQ_AMD_DEVICE_PARSE");
+      if (!knob || knob[0] != '0') {
+        std::vector<SortJob> sj;
+        for (size_t b : sorting) sj.push_back(sort_job(in[b].data, in[b].n, front[b].args));
+        std::vector<SortOut> so;
+        try { got = engine_sort_preprocess(sj, so, note); } catch (const Failure&) { got = false; }   // (any device trouble: the next path)
+        if (got)
+          for (size_t k = 0; k < sorting.size(); ++k) { dev_pre[sorting[k]] = std::move(so[k]); have_pre[sorting[k]] = 1; }
       }
+      if (!got) {
+        std::vector<std::pair<const U8*, U32>> blk;
+        for (size_t b : sorting) blk.push_back({in[b].data, in[b].n});
+        std::vector<std::vector<U32>> sa;
+        try { got = engine_suffix_arrays(blk, sa, note); } catch (const Failure&) { got = false; }      // (any device trouble: the host sorts)
+        for (size_t k = 0; k < sorting.size(); ++k) if (got) dev_sa[sorting[k]].swap(sa[k]);
+      }
+      for (size_t b : sorting) front[b].sorts = true;                 // (E8E9 is done either way)
       tm.sa_device_blocks = got ? (U32)sorting.size() : 0;
     } else {
       for (size_t b : sorting) front[b].sorts = false;   // nothing was done up front: preprocess_block does it all
@@ -274,7 +288,14 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     const Assembled& as = f.as;
     const U32 n = in[b].n;
     // LZ77 / BWT / E8E9 (libzpaq.cpp:7709-7716); E8E9 rewrites the caller's buffer in place, as the reference does
-    w.use_pre = preprocess_block(in[b].data, n, args, w.pre, dev_sa[b].empty() ? nullptr : dev_sa[b].data(), f.sorts);
+    if (have_pre[b] && n > 0) {                        // parsed / transformed on the device: the coder, or nothing left to do
+      if ((args[1] & 3) == 3) w.pre.swap(dev_pre[b].bwt);
+      else lz77_serialize(in[b].data, n, args, dev_pre[b].toks.data(), dev_pre[b].toks.size(), w.pre);
+      w.use_pre = true;
+      SortOut().toks.swap(dev_pre[b].toks);
+    } else {
+      w.use_pre = preprocess_block(in[b].data, n, args, w.pre, dev_sa[b].empty() ? nullptr : dev_sa[b].data(), f.sorts);
+    }
     std::vector<U32>().swap(dev_sa[b]);
     std::string cs = std::to_string(n);
     if (in[b].comment) cs += std::string(" ") + in[b].comment;
