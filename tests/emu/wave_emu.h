@@ -83,6 +83,12 @@ static inline bool wave_any(bool x) {        // true if x holds in any lane that
   return false;
 }
 }  // namespace emu
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool x) {      // (every lane of the wavefront is here)
+  const int* v = emu::wave_exchange(x ? 1 : 0);
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) if (v[i]) m |= 1ull << i;
+  return m;
+}
 static inline int __mul24(int a, int b) {
   const int x = (int)((unsigned)a << 8) >> 8, y = (int)((unsigned)b << 8) >> 8;
   return (int)((unsigned)x * (unsigned)y);

@@ -120,8 +120,23 @@ __device__ __forceinline__ void lz77_walk_body(const LzBlock* blocks, const uint
     uint4 e;
     e.x = e.y = e.z = e.w = 0;
     if (base + (uint32_t)lane < B.n) e = r[base + (uint32_t)lane];
+    // positions of this chunk where a match is taken although literals are pending
+    const unsigned long long pending_takes = __builtin_amdgcn_ballot_w64((e.y >> 31) != 0u);
     while (i < B.n && i - base < 64u) {
       const int src = (int)(i - base);
+      if (lit != 0) {
+        // a run of literals in one step: up to the next such position, the end of the chunk or of the block, or the flush
+        const unsigned long long ahead = pending_takes >> src;
+        uint32_t d = ahead ? (uint32_t)__builtin_ctzll(ahead) : 64u - (uint32_t)src;
+        d = d < B.n - i ? d : B.n - i;
+        d = d < kLzMaxLiteral - lit ? d : kLzMaxLiteral - lit;
+        if (d) {
+          i += d;
+          lit += d;
+          if (lit >= kLzMaxLiteral) lit = 0;
+          continue;
+        }
+      }
       const bool none = lit == 0;                                    // (the same in every lane)
       const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)(none ? e.z : e.x), src);
       const uint32_t y = (uint32_t)__builtin_amdgcn_readlane((int)(none ? e.w : e.y), src);
