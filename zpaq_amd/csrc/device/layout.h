@@ -166,7 +166,7 @@ static inline constexpr int spec_wave_lds_bytes(int waves) { return ((kSpecLdsBu
 // The lockstep decoder (spec_team_kernel.h) keeps 8 blocks' side tables in one workgroup's LDS, so it packs: the compact
 // stretch table of the encoder instead of half the full one (8.4 instead of 32 KiB), ICM side-table entries as 16 + 8 bits
 // (cm < 2^23), ISSE weight pairs as 2 x 16 + 8 bits (weights are clamped to +-2^19: libzpaq.cpp:2031-2039).  Of the -m5 chain's
-// 16 side tables 15 then fit a block's region (7 in the unpacked plan above).
+// 18 side tables 14 then fit a block's region (7 in the unpacked plan above).
 static const int kTeamTablesBytes = 2016 * 4 + 256 * 2 + 2688 + 4096 + 512 + 1024;         // 16896
 static inline constexpr int team_block_lds_bytes() { return ((kSpecLdsBudget - kTeamTablesBytes) / 8) & ~15; }   // 18336
 static const int kTeamIcmLds = 256 * 2 + 256, kTeamIsseLds = 256 * 4 + 256;                  // 768, 1280 bytes per table
