@@ -42,17 +42,18 @@ def main():
                  plain=np.concatenate(blocks), prefix=np.array([prefix]))
         print("coded", nb, "x", prefix, "of", bs, "->", int(lens.sum()), "bytes")
         return
-    d = np.load(sys.argv[2])
+    d = dict(np.load(sys.argv[2]))            # (an NpzFile reads an array from the file at EVERY access: load them once)
     hdr, lens, prefix = d["header"].tobytes(), d["lens"], int(d["prefix"][0])
     offs = np.concatenate([[0], np.cumsum(lens)])
-    coded = [d["coded"][offs[i]:offs[i + 1]] for i in range(len(lens))]
+    all_coded, plain = d["coded"], d["plain"]
+    coded = [all_coded[offs[i]:offs[i + 1]] for i in range(len(lens))]
     nb = len(coded)
     z.init(0)
     z.set_kernel(6)
     plan = z.Plan(hdr)
     t0 = time.time()
     out = z.decode_batch([plan] * nb, coded, [prefix + 1] * nb)
-    ok = all(o[0][1:] == d["plain"][i * prefix:(i + 1) * prefix].tobytes() for i, o in enumerate(out))
+    ok = all(o[0][1:] == plain[i * prefix:(i + 1) * prefix].tobytes() for i, o in enumerate(out))
     print("decoded", nb, "x", prefix, "in %.2f s" % (time.time() - t0), "kernel ms", z.last_timing(), "output bytes", nb * (prefix + 1), "identical", ok)
 
 
