@@ -44,6 +44,18 @@ def _cpu_has_v3() -> bool:
 class Ref:
     """The compiled reference (JIT build by default, nojit=True for the interpreter)."""
 
+    def divsufsort(self, data) -> "np.ndarray":
+        """The suffix array libzpaq's LZBuffer sorts with (divsufsort, libzpaq.cpp:4658-6434), as int32[n]."""
+        import numpy as np
+        if self._divsufsort is None:
+            raise RuntimeError("the compiled reference does not export divsufsort")
+        a = np.frombuffer(bytes(data), np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        sa = np.zeros(max(len(data), 1), np.int32)
+        rc = self._divsufsort(a.ctypes.data_as(_u8p), sa.ctypes.data_as(C.POINTER(C.c_int)), len(data))
+        if rc != 0:
+            raise RuntimeError("divsufsort failed: %d" % rc)
+        return sa[:len(data)]
+
     def __init__(self, nojit: bool = False):
         name = "libzpaq_ref_nojit.so" if nojit else "libzpaq_ref.so"
         self.flags = "-O3 -Dunix" + (" -DNOJIT" if nojit else "")
@@ -68,6 +80,11 @@ class Ref:
         L.ref_compress_config.restype = C.c_longlong
         L.ref_compress_config.argtypes = [_u8p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int),
                                           C.c_char_p, C.c_char_p, C.c_int, _u8p, C.c_size_t]
+        # the reference's suffix sorter itself (libzpaq.cpp:6371, an external symbol of the compiled reference)
+        self._divsufsort = getattr(L, "_ZN7libzpaq10divsufsortEPKhPii", None)
+        if self._divsufsort is not None:
+            self._divsufsort.restype = C.c_int
+            self._divsufsort.argtypes = [_u8p, C.POINTER(C.c_int), C.c_int]
         L.ref_make_config.restype = C.c_longlong
         L.ref_make_config.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.ref_compile.restype = C.c_longlong

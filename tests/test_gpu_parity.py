@@ -632,6 +632,7 @@ def test_suffix_arrays_on_the_device(gpu, ref):
         want = np.empty(max(b.size, 1), np.uint32)
         assert L.zpq_suffix_array_host(b.ctypes.data_as(u8p), b.size, want.ctypes.data_as(u32p)) == 0
         assert (o[:b.size] == want[:b.size]).all(), (b.size, int(b[0]))
+        assert (o[:b.size].astype(np.int64) == ref.divsufsort(b.tobytes()).astype(np.int64)).all(), b.size     # ... and the reference's own
     # through compressBlock's own methods, batches that take the device path (4 or more sorting blocks, 1 MiB or more)
     blocks = [corpus.block(kinds[i % 4], 150000 + 1111 * i, 500 + i) for i in range(12)]
     ph = (C.c_double * 8)()

@@ -593,3 +593,21 @@ def test_two_swaps_in_a_row_follow_the_interpreter(zlib_, ref):
     a = ref.compress_config(b"ABCDEFG", cfg, None, "f", None, False)
     assert interp.decompress(a, 100) == b"ABCDEFG\xff"
     assert zlib_.decompress(a) == b"ABCDEFG\xff"
+
+
+def test_host_suffix_sorter_against_the_references_divsufsort(zlib_, ref):
+    """host/preproc.cpp's SA-IS against libzpaq's own sorter (divsufsort, libzpaq.cpp:4658-6434; the compiled reference exports
+    it): entry for entry, on the inputs the device sorter is compared with the host's on (tests/test_gpu_parity.py) -- so the
+    device's arrays are the reference's as well, not only the archives made from them."""
+    import ctypes as C
+    import numpy as np
+    from zpaq_amd import corpus
+    L = zlib_.lib()
+    u8p, u32p = C.POINTER(C.c_ubyte), C.POINTER(C.c_uint32)
+    L.zpq_suffix_array_host.argtypes = [u8p, C.c_uint32, u32p]
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    for i, n in enumerate([70000, 65536, 40000, 50001, 30000, 1, 2, 3, 255, 256, 257, 1000, 99999]):
+        b = corpus.block(kinds[i % 5], n, 70 + i)
+        got = np.empty(max(n, 1), np.uint32)
+        assert L.zpq_suffix_array_host(b.ctypes.data_as(u8p), n, got.ctypes.data_as(u32p)) == 0
+        assert (got[:n].astype(np.int64) == ref.divsufsort(b.tobytes()).astype(np.int64)).all(), (kinds[i % 5], n)
