@@ -136,6 +136,40 @@ __device__ __forceinline__ uint4 pipe_settle(uint4 v) {
 
 typedef __attribute__((address_space(1))) uint2 g_u64v;
 
+// ---- stores the PERSISTENT encoder (pipe_persist.h) hands from one workgroup to another inside a launch -------------
+// A stream element is written once and read by other workgroups -- on other CUs, maybe on other XCDs, whose L2s are not
+// coherent with the writer's -- a chunk later.  Write-through (sc1) stores put it where every reader finds it; the
+// producer then drains its stores (s_waitcnt vmcnt(0)) and publishes its progress counter with an sc1 store, the consumer
+// polls the counter relaxed, takes ONE agent-scope acquire and reads with plain loads (MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility": the drained-sc1 form).  The base is the group's buffer: wave-uniform.
+#ifdef ZPQ_EMU
+__device__ __forceinline__ void pipe_wt_store16(g_u8* base, unsigned off, const uint4& v) { *(g_u128*)(base + off) = v; }
+__device__ __forceinline__ void pipe_wt_store8(g_u8* base, unsigned off, const uint2& v) { *(g_u64v*)(base + off) = v; }
+__device__ __forceinline__ void pipe_wt_store4(g_u8* base, unsigned off, unsigned v) { *(g_u32*)(base + off) = v; }
+__device__ __forceinline__ void pipe_wt_store2(g_u8* base, unsigned off, unsigned v) { *(g_u16*)(base + off) = (unsigned short)v; }
+#else
+typedef unsigned pipe_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned pipe_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pipe_rsrc(g_u8* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00027000);
+}
+__device__ __forceinline__ void pipe_wt_store16(g_u8* base, unsigned off, const uint4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(pipe_v4u{v.x, v.y, v.z, v.w}, pipe_rsrc(base), (int)off, 0, 16);     // aux 16 = sc1
+}
+__device__ __forceinline__ void pipe_wt_store8(g_u8* base, unsigned off, const uint2& v) {
+  __builtin_amdgcn_raw_buffer_store_b64(pipe_v2u{v.x, v.y}, pipe_rsrc(base), (int)off, 0, 16);
+}
+__device__ __forceinline__ void pipe_wt_store4(g_u8* base, unsigned off, unsigned v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, pipe_rsrc(base), (int)off, 0, 16);
+}
+__device__ __forceinline__ void pipe_wt_store2(g_u8* base, unsigned off, unsigned v) {
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, pipe_rsrc(base), (int)off, 0, 16);
+}
+#endif
+
+template <class Chain, class = void> struct PipePersistOf { static constexpr bool value = false; };
+template <class Chain> struct PipePersistOf<Chain, decltype((void)Chain::PIPE_PERSIST)> { static constexpr bool value = Chain::PIPE_PERSIST; };
+
 // One lane's view of its block, its chunk and the group's streams.
 template <class Chain>
 struct PipeLane {
@@ -154,8 +188,16 @@ struct PipeLane {
   unsigned slot;            // chunk % S
   unsigned k0, nb;          // first input byte of the chunk, bytes of this lane in it
 
+  static constexpr bool WT = PipePersistOf<Chain>::value;      // the unit runs inside the persistent launch: streams are stored write-through
   __device__ __forceinline__ void open(const PipeArgs& a, unsigned blk, int level) {
-    live = blk < a.nblocks;
+    bind(a, blk / G, blk % G, true);
+    at_chunk(a.step - level);
+  }
+  // the same in two halves (the persistent launch binds a lane to its block once and then walks the chunks):
+  // g = the group (wave-uniform there), lane_in_group = the block's position in every stream row
+  __device__ __forceinline__ void bind(const PipeArgs& a, unsigned g, unsigned lane_in_group, bool lane_ok) {
+    const unsigned blk = g * G + lane_in_group;
+    live = lane_ok && blk < a.nblocks;
     const BlockJob job = a.jobs[live ? blk : 0];
     arena = (g_u8*)job.arena;
     in = (const g_u8*)job.in;
@@ -165,13 +207,16 @@ struct PipeLane {
     rslot = job.res_slot;
     nseg = job.nseg;
     segs = job.segs;
-    gl = blk % G;
-    gb = (g_u8*)a.pipe + (unsigned long long)(blk / G) * Chain::PIPE_GROUP_BYTES;
-    chunk = a.step - level;
+    gl = lane_in_group;
+    gb = (g_u8*)a.pipe + (unsigned long long)g * Chain::PIPE_GROUP_BYTES;
+  }
+  __device__ __forceinline__ void at_chunk(int chunk_) {
+    chunk = chunk_;
     slot = chunk >= 0 ? (unsigned)chunk % (unsigned)S : 0u;
     k0 = chunk >= 0 ? (unsigned)chunk * (unsigned)C : 0u;
     nb = (chunk >= 0 && len > k0) ? min(len - k0, (unsigned)C) : 0u;
   }
+  __device__ __forceinline__ void idle() { live = false; nb = 0; len = 0; }
   // streams (byte offsets fit 32 bits: a group's buffer is far below 4 GiB)
   __device__ __forceinline__ g_u32& ctx(int ci, unsigned k) const {
     return *(g_u32*)(gb + (unsigned)Chain::PIPE_OFF_CTX + ((((slot * Chain::PIPE_NCTX + ci) * C + k) * G + gl) << 2));
@@ -184,6 +229,25 @@ struct PipeLane {
   }
   __device__ __forceinline__ g_u32& state(int w) const {
     return *(g_u32*)(gb + (unsigned)Chain::PIPE_OFF_STATE + (((unsigned)w * G + gl) << 2));
+  }
+  // what a unit hands to OTHER units goes through these (plain stores between launches, write-through inside one)
+  __device__ __forceinline__ unsigned off_ctx(int ci, unsigned k) const { return (unsigned)Chain::PIPE_OFF_CTX + ((((slot * Chain::PIPE_NCTX + ci) * C + k) * G + gl) << 2); }
+  __device__ __forceinline__ unsigned off_bh(int ri, unsigned k) const { return (unsigned)Chain::PIPE_OFF_BH + ((((slot * Chain::PIPE_NROW + ri) * C + k) * G + gl) << 3); }
+  __device__ __forceinline__ unsigned off_p(int i, unsigned k) const { return (unsigned)Chain::PIPE_OFF_P + ((((slot * N + i) * C + k) * G + gl) << 4); }
+  __device__ __forceinline__ void put_ctx(int ci, unsigned k, unsigned v) const {
+    if constexpr (WT) pipe_wt_store4(gb, off_ctx(ci, k), v); else ctx(ci, k) = v;
+  }
+  __device__ __forceinline__ void put_bh(int ri, unsigned k, const uint2& v) const {
+    if constexpr (WT) pipe_wt_store8(gb, off_bh(ri, k), v); else bh(ri, k) = v;
+  }
+  __device__ __forceinline__ void put_p(int i, unsigned k, const uint4& v) const {
+    if constexpr (WT) pipe_wt_store16(gb, off_p(i, k), v); else p(i, k) = v;
+  }
+  __device__ __forceinline__ void put_p16(int i, unsigned k, unsigned B, int v) const {      // one bit position's half-word
+    if constexpr (WT) pipe_wt_store2(gb, off_p(i, k) + 2u * B, (unsigned)v & 0xFFFFu); else *(g_i16*)((g_u8*)&p(i, k) + 2u * B) = (short)v;
+  }
+  __device__ __forceinline__ void put_state(int w, unsigned v) const {                        // a state word ANOTHER unit reads (HCOMP's status)
+    if constexpr (WT) pipe_wt_store4(gb, (unsigned)Chain::PIPE_OFF_STATE + (((unsigned)w * G + gl) << 2), v); else state(w) = v;
   }
   __device__ __forceinline__ g_u32& A32(unsigned off) const { return *(g_u32*)(arena + off); }
   __device__ __forceinline__ g_u8& A8(unsigned off) const { return *(g_u8*)(arena + off); }
@@ -260,18 +324,13 @@ struct PipeHLds {
   __device__ __forceinline__ unsigned& operator[](unsigned i) const { return base[i * Chain::HCOMP_LANES + lane]; }
 };
 
+// One chunk of the HCOMP unit for the lanes of `L` (lane < HCOMP_LANES; the others are idle).  load_h / store_h: H is
+// staged from / written back to the arena around this chunk (the persistent launch keeps it in LDS from chunk to chunk).
 template <class Chain>
-__device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
-  constexpr int HL = Chain::HCOMP_LANES;
+__device__ __forceinline__ void pipe_hcomp_unit(PipeLane<Chain>& L, unsigned* Hs, int lane, bool load_h, bool store_h) {
   constexpr bool HLDS = Chain::HCOMP_H_LDS;
   constexpr unsigned HW = Chain::HMASK + 1u;
-  __shared__ unsigned Hs[HLDS ? HW * HL : 1];
-  const int lane = threadIdx.x & 63;
-  const bool mine = lane < HL;
-  PipeLane<Chain> L;
-  L.open(a, (blockIdx.x + a.wg0) * HL + (mine ? lane : 0), 0);
-  if (!mine) { L.live = false; L.nb = 0; }
-  if (L.live && L.chunk == 0) L.state(Chain::HCOMP_STATE + 4) = 0u;      // status word, read by the coder at the end
+  if (L.live && L.chunk == 0) L.put_state(Chain::HCOMP_STATE + 4, 0u);      // status word, read by the coder at the end
   unsigned st = L.live && L.chunk > 0 ? (unsigned)L.state(Chain::HCOMP_STATE + 4) : 0u;
   if (st) L.nb = 0;
   if (!pipe_any(L.nb > 0)) return;
@@ -285,7 +344,7 @@ __device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
   g_u32* const Hg = (g_u32*)(L.arena + Chain::OFF_H);
   PipeHLds<Chain> Hl{Hs, lane};
   if constexpr (HLDS) {
-    if (L.nb) for (unsigned i = 0; i < HW; ++i) Hl[i] = Hg[i];
+    if (L.nb && load_h) for (unsigned i = 0; i < HW; ++i) Hl[i] = Hg[i];
   }
   unsigned ch = L.nb ? L.byte_at(0) : 0u;
   for (unsigned k = 0; k < L.nb; ++k) {
@@ -296,7 +355,7 @@ __device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
       if constexpr (Chain::P_CTX[i] >= 0) {
         unsigned hv;
         if constexpr (HLDS) hv = Hl[(unsigned)i & Chain::HMASK]; else hv = Hg[(unsigned)i & Chain::HMASK];
-        L.ctx(Chain::P_CTX[i], k) = hv;
+        L.put_ctx(Chain::P_CTX[i], k, hv);
       }
     });
     int e;
@@ -306,11 +365,25 @@ __device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
     ch = chn;
   }
   if (L.nb) {
-    if constexpr (HLDS) for (unsigned i = 0; i < HW; ++i) Hg[i] = Hl[i];
+    if constexpr (HLDS) { if (store_h) for (unsigned i = 0; i < HW; ++i) Hg[i] = Hl[i]; }
     L.state(Chain::HCOMP_STATE + 0) = vb; L.state(Chain::HCOMP_STATE + 1) = vc;
     L.state(Chain::HCOMP_STATE + 2) = vd; L.state(Chain::HCOMP_STATE + 3) = vf;
-    L.state(Chain::HCOMP_STATE + 4) = st;
+    L.put_state(Chain::HCOMP_STATE + 4, st);
   }
+}
+
+template <class Chain>
+__device__ __forceinline__ void pipe_hcomp_body(const PipeArgs& a) {
+  constexpr int HL = Chain::HCOMP_LANES;
+  constexpr bool HLDS = Chain::HCOMP_H_LDS;
+  constexpr unsigned HW = Chain::HMASK + 1u;
+  __shared__ unsigned Hs[HLDS ? HW * HL : 1];
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane < HL;
+  PipeLane<Chain> L;
+  L.open(a, (blockIdx.x + a.wg0) * HL + (mine ? lane : 0), 0);
+  if (!mine) { L.live = false; L.nb = 0; }
+  pipe_hcomp_unit<Chain>(L, Hs, lane, true, true);
 }
 
 // =====================================================================================================
@@ -412,7 +485,7 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     PipeRow rb = pipe_find(b0, b1, b2, (cxb >> sizebits) & 255u, hb);
     o.y = pipe_row_bits(rb, byte & 15u, ns);
     L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
-    L.bh(ri, k) = o;
+    L.put_bh(ri, k, o);
     if (clash) {
       na0 = L.A128(ht + han); na1 = L.A128(ht + (han ^ 16u)); na2 = L.A128(ht + (han ^ 32u));
       nb0 = L.A128(ht + hbn); nb1 = L.A128(ht + (hbn ^ 16u)); nb2 = L.A128(ht + (hbn ^ 32u));
@@ -427,7 +500,7 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
 template <class Chain, int I>
 __device__ __forceinline__ void pipe_cons(PipeLane<Chain>& L) {
   constexpr unsigned v = (unsigned)(((int)Chain::comp[I].a1 - 128) * 4) & 0xFFFFu;
-  for (unsigned k = 0; k < L.nb; ++k) L.p(I, k) = make_uint4(v | v << 16, v | v << 16, v | v << 16, v | v << 16);
+  for (unsigned k = 0; k < L.nb; ++k) L.put_p(I, k, make_uint4(v | v << 16, v | v << 16, v | v << 16, v | v << 16));
 }
 
 // CM (Predictor::predict0/update0 case CM, libzpaq.cpp:1869-1873, 1969-1971)
@@ -471,7 +544,7 @@ __device__ __forceinline__ void pipe_cm(PipeLane<Chain>& L, const PipeStretch& s
       nv[B] = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
       L.A32(off) = nv[B];
     }
-    L.p(I, k) = out.get();
+    L.put_p(I, k, out.get());
     if constexpr (batch) {
       if (late) {
 #pragma unroll
@@ -533,7 +606,7 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
       out.set(B, stretch(sx));
       ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
     }
-    L.p(I, k) = out.get();
+    L.put_p(I, k, out.get());
     const unsigned wpos = rlimit & mask;                         // where this byte goes
     L.A8(off1 + wpos) = (unsigned char)byte;
     hist = hist << 8 | byte;
@@ -580,7 +653,7 @@ __device__ __forceinline__ void pipe_avg(PipeLane<Chain>& L) {
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) out.set(B, (__mul24(pipe_p_get(vj, B), (int)c.a3) + __mul24(pipe_p_get(vk, B), 256 - (int)c.a3)) >> 8);
-    L.p(I, k) = out.get();
+    L.put_p(I, k, out.get());
   }
 }
 
@@ -634,7 +707,7 @@ __device__ __forceinline__ void pipe_mix2(PipeLane<Chain>& L, const SQ& squash) 
       nv[B] = (unsigned)min(max(w + ((__mul24(err, pj - pk) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
       if constexpr (single) wreg = nv[B]; else L.A32(off) = nv[B];
     }
-    L.p(I, k) = out.get();
+    L.put_p(I, k, out.get());
     if constexpr (batch) {
       if (late) {
 #pragma unroll
@@ -713,7 +786,7 @@ __device__ __forceinline__ void pipe_sse(PipeLane<Chain>& L, const PipeStretch& 
       nv[B] = pipe_train(tv, pipe_y(byte, B), (unsigned)dt[tv & 0x3ffu], c.limit);
       L.A32((unsigned)c.t0 + 4u * ti[B]) = nv[B];
     }
-    L.p(I, k) = out.get();
+    L.put_p(I, k, out.get());
     if constexpr (batch) {
       if (late) {
 #pragma unroll
@@ -756,6 +829,19 @@ __device__ __forceinline__ unsigned pipe_hmap4_at(unsigned byte, unsigned B) {
 }
 __device__ __forceinline__ unsigned pipe_c8_at(unsigned byte, unsigned B) { return (1u << B) | (byte >> (8u - B)); }
 
+// The 8 lanes of a block (lane & 7 = bit position) hold the 8 half-words of one stream element: gathered into the lane of
+// position 0 by DPP shifts inside the row of 16 lanes and stored as ONE 16-byte element (every lane of the wavefront takes
+// part in the shifts: call in wave-uniform control flow).
+template <class Chain>
+__device__ __forceinline__ void pipe_put_bits(const PipeLane<Chain>& L, int I, unsigned k, unsigned B, int pr, bool on) {
+  const int h = pr & 0xFFFF;
+  const int t = h | (__builtin_amdgcn_update_dpp(0, h, 0x101, 0xF, 0xF, true) << 16);        // row_shl:1 -- even lanes: positions B, B + 1
+  const int y = __builtin_amdgcn_update_dpp(0, t, 0x102, 0xF, 0xF, true);                    // row_shl:2
+  const int z = __builtin_amdgcn_update_dpp(0, t, 0x104, 0xF, 0xF, true);
+  const int w = __builtin_amdgcn_update_dpp(0, t, 0x106, 0xF, 0xF, true);
+  if (on && B == 0u) L.put_p(I, k, make_uint4((unsigned)t, (unsigned)y, (unsigned)z, (unsigned)w));
+}
+
 template <class Chain, int I, class DT>
 __device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, const PipeStretch& stretch, const DT& dt) {
   constexpr CompK c = Chain::comp[I];
@@ -796,10 +882,8 @@ __device__ __forceinline__ void pipe_cm_bits(PipeLane<Chain>& L, unsigned B, con
       }
       const int pr = stretch(v >> 17);
       const unsigned nv = pipe_train(v, y, (unsigned)dt[v & 0x3ffu], c.limit);
-      if (on) {
-        L.A32(addr) = nv;
-        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
-      }
+      if (on) L.A32(addr) = nv;
+      pipe_put_bits(L, I, k, B, pr, on);
 #pragma unroll
       for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
       ha[0] = addr; hh[0] = hcur; hv[0] = nv;
@@ -857,10 +941,8 @@ __device__ __forceinline__ void pipe_mix2_bits(PipeLane<Chain>& L, unsigned B, c
       const int pr = (__mul24(w, qj) + __mul24(65536 - w, qk)) >> 16;   // 17-bit x 12-bit
       const int err = __mul24(y * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
       const unsigned nv = (unsigned)min(max(w + ((__mul24(err, qj - qk) + (1 << 12)) >> 13), 0), 65535);   // 19-bit x 13-bit
-      if (on) {
-        L.A32(addr) = nv;
-        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
-      }
+      if (on) L.A32(addr) = nv;
+      pipe_put_bits(L, I, k, B, pr, on);
 #pragma unroll
       for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
       ha[0] = addr; hh[0] = hcur; hv[0] = nv;
@@ -932,10 +1014,8 @@ __device__ __forceinline__ void pipe_sse_bits(PipeLane<Chain>& L, unsigned B, co
       const unsigned tv = (w >> 5) ? v1 : v0;
       const unsigned ti = (w >> 5) ? i1 : i0;
       const unsigned nv = pipe_train(tv, y, (unsigned)dt[tv & 0x3ffu], c.limit);
-      if (on) {
-        L.A32((unsigned)c.t0 + 4u * ti) = nv;
-        *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
-      }
+      if (on) L.A32((unsigned)c.t0 + 4u * ti) = nv;
+      pipe_put_bits(L, I, k, B, pr, on);
 #pragma unroll
       for (int i = HN - 1; i > 0; --i) { ha[i] = ha[i - 1]; hh[i] = hh[i - 1]; hv[i] = hv[i - 1]; }
       ha[0] = ti; hh[0] = hcur; hv[0] = nv;
@@ -1121,6 +1201,46 @@ __device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return 
 // ICM map (libzpaq.cpp:1875-1881, 1973-1977): side table cm[256] of 64 blocks in LDS as [entry][lane].
 // The entry of the NEXT bit is read before this bit's entry is written and patched when they coincide, so the
 // LDS round trip is off the lane's serial chain.
+// one chunk of the ICM map of component I; tab = [256][G] words of LDS; load_tab / store_tab: the side table is staged from /
+// written back to the arena around this chunk (the persistent launch keeps it in LDS from chunk to chunk)
+template <class Chain, int I>
+__device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab, const PipeStretch& stretch, int lane, bool load_tab, bool store_tab) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ri = Chain::P_ROW[I];
+  if (!L.nb) return;
+  if (load_tab)
+    for (int e = 0; e < 256; e += 4) {
+      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+    }
+  unsigned byte = L.byte_at(0);
+  uint2 w = L.bh(ri, 0);
+  unsigned s = pipe_bh_get(w, 0);
+  unsigned v = tab[s * G + lane];
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned byten = L.byte_at(kn);
+    const uint2 wn = L.bh(ri, kn);
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
+      const unsigned vn = tab[sn * G + lane];
+      out.set(B, stretch(v >> 8));
+      const unsigned nv = v + (unsigned)((int)((unsigned)(pipe_y(byte, B) * 32767) - (v >> 8)) >> 2);
+      tab[s * G + lane] = nv;
+      v = sn == s ? nv : vn;
+      s = sn;
+    }
+    L.put_p(I, k, out.get());
+    byte = byten; w = wn;
+  }
+  if (store_tab)
+    for (int e = 0; e < 256; e += 4)
+      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
   constexpr unsigned G = Chain::PIPE_G;
@@ -1134,46 +1254,62 @@ __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
     constexpr int r = decltype(rc)::value;
     if (role != (unsigned)r) return;
     constexpr int I = Chain::ICM_COMP[r];
-    constexpr CompK c = Chain::comp[I];
-    constexpr int ri = Chain::P_ROW[I];
     PipeLane<Chain> L;
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, Chain::P_LEVEL[I]);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     stretch.load(a.tb, lane);
     __syncthreads();
-    if (!L.nb) return;
-    for (int e = 0; e < 256; e += 4) {
-      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
-      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
-    }
-    unsigned byte = L.byte_at(0);
-    uint2 w = L.bh(ri, 0);
-    unsigned s = pipe_bh_get(w, 0);
-    unsigned v = tab[s * G + lane];
-    for (unsigned k = 0; k < L.nb; ++k) {
-      const unsigned kn = L.next(k);
-      const unsigned byten = L.byte_at(kn);
-      const uint2 wn = L.bh(ri, kn);
-      PipeP8 out;
-#pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
-        const unsigned vn = tab[sn * G + lane];
-        out.set(B, stretch(v >> 8));
-        const unsigned nv = v + (unsigned)((int)((unsigned)(pipe_y(byte, B) * 32767) - (v >> 8)) >> 2);
-        tab[s * G + lane] = nv;
-        v = sn == s ? nv : vn;
-        s = sn;
-      }
-      L.p(I, k) = out.get();
-      byte = byten; w = wn;
-    }
-    for (int e = 0; e < 256; e += 4)
-      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+    pipe_icm_unit<Chain, I>(L, tab, stretch, lane, true, true);
   });
 }
 
 // ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
+template <class Chain, int I, class SQ>
+__device__ __forceinline__ void pipe_isse_unit(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab, bool store_tab) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
+  if (!L.nb) return;
+  if (load_tab)
+    for (int e = 0; e < 512; e += 4) {
+      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+    }
+  unsigned byte = L.byte_at(0);
+  uint2 w = L.bh(ri, 0);
+  uint4 vj = L.p(J, 0);
+  unsigned s = pipe_bh_get(w, 0);
+  int w0 = (int)tab[(2u * s) * G + lane], w1 = (int)tab[(2u * s + 1u) * G + lane];
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned byten = L.byte_at(kn);
+    const uint2 wn = L.bh(ri, kn);
+    const uint4 vjn = L.p(J, kn);
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
+      const int n0 = (int)tab[(2u * sn) * G + lane], n1 = (int)tab[(2u * sn + 1u) * G + lane];
+      const int pj = pipe_p_get(vj, B);
+      const int pr = sp_clamp2k((__mul24(w0, pj) + w1 * 64) >> 16);          // 20-bit x 12-bit
+      out.set(B, pr);
+      const int err = pipe_y(byte, B) * 32767 - squash(pr);
+      const int u0 = sp_clamp512k(w0 + ((__mul24(err, pj) + (1 << 12)) >> 13));
+      const int u1 = sp_clamp512k(w1 + ((err + 16) >> 5));
+      tab[(2u * s) * G + lane] = (unsigned)u0;
+      tab[(2u * s + 1u) * G + lane] = (unsigned)u1;
+      w0 = sn == s ? u0 : n0;
+      w1 = sn == s ? u1 : n1;
+      s = sn;
+    }
+    L.put_p(I, k, out.get());
+    byte = byten; w = wn; vj = vjn;
+  }
+  if (store_tab)
+    for (int e = 0; e < 512; e += 4)
+      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
   constexpr unsigned G = Chain::PIPE_G;
@@ -1187,51 +1323,12 @@ __device__ __forceinline__ void pipe_isse_body(const PipeArgs& a) {
     constexpr int r = decltype(rc)::value;
     if (role != (unsigned)r) return;
     constexpr int I = Chain::ISSE_COMP[r];
-    constexpr CompK c = Chain::comp[I];
-    constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
     PipeLane<Chain> L;
     L.open(a, g * Chain::PIPE_G + (unsigned)lane, Chain::P_LEVEL[I]);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
     squash.load(a.tb, lane);
-    if (L.nb)
-      for (int e = 0; e < 512; e += 4) {
-        const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
-        tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
-      }
     __syncthreads();
-    if (!L.nb) return;
-    unsigned byte = L.byte_at(0);
-    uint2 w = L.bh(ri, 0);
-    uint4 vj = L.p(J, 0);
-    unsigned s = pipe_bh_get(w, 0);
-    int w0 = (int)tab[(2u * s) * G + lane], w1 = (int)tab[(2u * s + 1u) * G + lane];
-    for (unsigned k = 0; k < L.nb; ++k) {
-      const unsigned kn = L.next(k);
-      const unsigned byten = L.byte_at(kn);
-      const uint2 wn = L.bh(ri, kn);
-      const uint4 vjn = L.p(J, kn);
-      PipeP8 out;
-#pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
-        const int n0 = (int)tab[(2u * sn) * G + lane], n1 = (int)tab[(2u * sn + 1u) * G + lane];
-        const int pj = pipe_p_get(vj, B);
-        const int pr = sp_clamp2k((__mul24(w0, pj) + w1 * 64) >> 16);          // 20-bit x 12-bit
-        out.set(B, pr);
-        const int err = pipe_y(byte, B) * 32767 - squash(pr);
-        const int u0 = sp_clamp512k(w0 + ((__mul24(err, pj) + (1 << 12)) >> 13));
-        const int u1 = sp_clamp512k(w1 + ((err + 16) >> 5));
-        tab[(2u * s) * G + lane] = (unsigned)u0;
-        tab[(2u * s + 1u) * G + lane] = (unsigned)u1;
-        w0 = sn == s ? u0 : n0;
-        w1 = sn == s ? u1 : n1;
-        s = sn;
-      }
-      L.p(I, k) = out.get();
-      byte = byten; w = wn; vj = vjn;
-    }
-    for (int e = 0; e < 512; e += 4)
-      L.A128((unsigned)c.t0 + 4u * e) = make_uint4(tab[e * G + lane], tab[(e + 1) * G + lane], tab[(e + 2) * G + lane], tab[(e + 3) * G + lane]);
+    pipe_isse_unit<Chain, I>(L, tab, squash, lane, true, true);
   });
 }
 
@@ -1263,6 +1360,118 @@ __device__ __forceinline__ int pipe_group_sum(int v) {
 // order.  Rows, inputs and contexts are fetched MIX_DEPTH bytes ahead; a row rewritten since its fetch is taken from
 // the lane's own history (same context: same bit position, same lane) or fetched again (contexts less than a byte's
 // row range apart: any lane may have written it).
+// one chunk of MIX role r with a lane per (block, bit position, weight quad): q = the lane's quad, B = its bit position
+template <class Chain, int r, class SQ>
+__device__ __forceinline__ void pipe_mix_bits_unit(PipeLane<Chain>& L, unsigned q, unsigned B, const SQ& squash) {
+  constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r];
+  constexpr CompK c = Chain::comp[I];
+  constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
+  constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D;
+  static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "MIX bit lanes need the 8 rows of a byte to be distinct");
+  if (!L.nb) return;
+  const bool act = q < (unsigned)NQ;                               // lanes that hold weights
+  const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+  const unsigned qoff = 16u * (act ? q : 0u);
+  bool have[4];
+  int tin[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int t = (int)q * 4 + x;
+    have[x] = t < m;
+    tin[x] = J + (have[x] ? t : 0);
+  }
+  auto row_of = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
+    const unsigned c8 = (1u << B) | (bytev >> (8u - B));           // pipe_c8 for a lane's own position
+    return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)c.stride) + qoff;
+  };
+  auto input = [&](int x, unsigned kk) __attribute__((always_inline)) -> int {      // this position's half-word of the stream element
+    return (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
+  };
+  const unsigned last = L.nb - 1u;
+  // Ring of W = 2 D slots, slot = byte index mod W, every slot a fixed set of registers (the loop is unrolled W times):
+  // a byte's context and value are fetched W bytes ahead, its row address / weights / inputs D bytes ahead.  A register is
+  // written by one fetch and read D or more bytes later -- nothing is copied while a fetch is in flight.
+  constexpr int W = 2 * D;
+  unsigned hx[W], bx[W];                  // context, input byte
+  unsigned rq[W];                         // row address of this lane's quad
+  uint4 wq[W];                            // weights as fetched
+  int pq[W][4];                           // inputs as fetched (masked when used)
+  // the last D bytes done: row, context, weights as stored
+  unsigned hr[HN], hh[HN];
+  uint4 hw[HN];
+  auto near = [&](int sl, unsigned kk) __attribute__((always_inline)) {
+    rq[sl] = row_of(hx[sl], bx[sl]);
+    wq[sl] = *(g_u128a4*)(L.arena + rq[sl]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) pq[sl][x] = input(x, kk);
+  };
+#pragma unroll
+  for (int sl = 0; sl < W; ++sl) {
+    const unsigned kk = min((unsigned)sl, last);
+    hx[sl] = L.ctx(ci, kk);
+    bx[sl] = L.byte_at(kk);
+  }
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) near(sl, min((unsigned)sl, last));
+#pragma unroll
+  for (int i = 0; i < HN; ++i) { hr[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hw[i] = make_uint4(0u, 0u, 0u, 0u); }
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) {
+      const unsigned k = kb + (unsigned)sl;
+      const bool on = k < L.nb;
+      const unsigned hcur = hx[sl], bcur = bx[sl], row = rq[sl];
+      uint4 w = wq[sl];
+      {
+        bool late = false;
+#pragma unroll
+        for (int i = HN - 1; i >= 0; --i) {                       // oldest first: the most recent store wins
+          const bool fw = row == hr[i];
+          w.x = fw ? hw[i].x : w.x; w.y = fw ? hw[i].y : w.y; w.z = fw ? hw[i].z : w.z; w.w = fw ? hw[i].w : w.w;
+          late = late || (hcur != hh[i] && (((hcur - hh[i]) & c.mask0) < 256u || ((hh[i] - hcur) & c.mask0) < 256u));
+        }
+        if (pipe_any(late)) {
+          pipe_stores_done();
+          if (late) w = pipe_settle(*(g_u128a4*)(L.arena + row));   // after every store so far, in this wavefront's order
+        }
+      }
+      const int w0 = (int)w.x, w1 = (int)w.y, w2 = (int)w.z, w3 = (int)w.w;
+      // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
+      const int p0 = have[0] ? pq[sl][0] : 0, p1 = have[1] ? pq[sl][1] : 0, p2 = have[2] ? pq[sl][2] : 0, p3 = have[3] ? pq[sl][3] : 0;
+      const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
+      const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
+      const int y = (int)((bcur >> (7u - B)) & 1u);
+      const int err = __mul24(y * 32767 - squash(pr), (int)c.a4) >> 4;
+      uint4 nw;
+      nw.x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
+      nw.y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
+      nw.z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
+      nw.w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
+      if (on) {
+        if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
+        if constexpr (TAIL != 0) {
+          if (tail) {
+            L.A32(row) = nw.x;
+            if constexpr (TAIL >= 2) L.A32(row + 4u) = nw.y;
+            if constexpr (TAIL >= 3) L.A32(row + 8u) = nw.z;
+          }
+        }
+        if (q == 0) L.put_p16(I, k, B, pr);
+      }
+#pragma unroll
+      for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
+      hr[0] = row; hh[0] = hcur; hw[0] = nw;
+      // this slot now takes byte k + W; the slot D ahead gets its row, weights and inputs (its context came D bytes ago)
+      {
+        const unsigned kw = min(k + (unsigned)W, last);
+        hx[sl] = L.ctx(ci, kw);
+        bx[sl] = L.byte_at(kw);
+        near((sl + D) % W, min(k + (unsigned)D, last));
+      }
+    }
+  }
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
   __shared__ PipeSquash squash;
@@ -1278,119 +1487,125 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
     static_assert(QL <= 8 && BPW >= 1 && (int)Chain::PIPE_G % BPW == 0, "MIX bit lanes: a block's 8 positions share a wavefront");
     constexpr int WPG = (int)Chain::PIPE_G / BPW;                // wavefronts per group
     if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + WPG) * ngroups) return;
-    constexpr CompK c = Chain::comp[I];
-    constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-    constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D;
-    static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "MIX bit lanes need the 8 rows of a byte to be distinct");
     const unsigned wi = wg - (unsigned)first * ngroups;
     const unsigned g = wi / (unsigned)WPG, sub = wi % (unsigned)WPG;
     const unsigned pair = (unsigned)lane / QL, q = (unsigned)lane % QL, B = pair & 7u;
     PipeLane<Chain> L;
     L.open(a, pipe_opaque(g * Chain::PIPE_G + sub * BPW + (pair >> 3)), Chain::P_LEVEL[I]);
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-    if (!L.nb) return;
-    const bool act = q < (unsigned)NQ;                               // lanes that hold weights
-    const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
-    const unsigned qoff = 16u * (act ? q : 0u);
-    bool have[4];
-    int tin[4];
+    pipe_mix_bits_unit<Chain, r>(L, q, B, squash);
+  });
+}
+
+// one chunk of MIX role r with QL lanes per block: q = the lane's weight quad
+template <class Chain, int r, class SQ>
+__device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, const SQ& squash) {
+  constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r];
+  constexpr CompK c = Chain::comp[I];
+  constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
+  constexpr int NQ = (m + 3) / 4, TAIL = m % 4;
+  static_assert(NQ <= QL, "MIX lane group");
+  constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
+  if (!L.nb) return;
+  const bool act = q < (unsigned)NQ;                               // lanes that hold weights
+  const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+  const unsigned qoff = 16u * (act ? q : 0u);
+  bool have[4];
+  int tin[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int t = (int)q * 4 + x;
-      have[x] = t < m;
-      tin[x] = J + (have[x] ? t : 0);
+  for (int x = 0; x < 4; ++x) {
+    const int t = (int)q * 4 + x;
+    have[x] = t < m;
+    tin[x] = J + (have[x] ? t : 0);
+  }
+  auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)c.stride) + qoff;   // s <= 24
+  };
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  // inputs of the weights a lane does not have read as 0 (masked once per byte, not once per bit)
+  auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
+    const uint4 v = L.p(tin[x], kk);
+    const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
+    return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+  };
+  uint4 pv[4], pv1[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) { pv[x] = inputs(x, 0); pv1[x] = inputs(x, k1); }
+  uint4 w[8];
+  unsigned rowc[8];
+#pragma unroll
+  for (int B = 0; B < 8; ++B) rowc[B] = row_of(h, byte, B);
+  if constexpr (batch) {
+#pragma unroll
+    for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
+  }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    uint4 pv2[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
+    unsigned rown[8];
+#pragma unroll
+    for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
+    // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint),
+    // forwarded below; contexts less than 256 apart -> any position may coincide: fetched after the stores
+    const bool same = h1 == h;
+    const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
+    uint4 wn[8], nw[8];
+    if constexpr (batch) {
+      if (!late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
+      }
     }
-    auto row_of = [&](unsigned hh, unsigned bytev) __attribute__((always_inline)) -> unsigned {
-      const unsigned c8 = (1u << B) | (bytev >> (8u - B));           // pipe_c8 for a lane's own position
-      return (unsigned)c.t0 + 4u * __umul24((hh + c8) & c.mask0, (unsigned)c.stride) + qoff;
-    };
-    auto input = [&](int x, unsigned kk) __attribute__((always_inline)) -> int {      // this position's half-word of the stream element
-      return (int)*(const g_i16*)((const g_u8*)&L.p(tin[x], kk) + 2u * B);
-    };
-    const unsigned last = L.nb - 1u;
-    // Ring of W = 2 D slots, slot = byte index mod W, every slot a fixed set of registers (the loop is unrolled W times):
-    // a byte's context and value are fetched W bytes ahead, its row address / weights / inputs D bytes ahead.  A register is
-    // written by one fetch and read D or more bytes later -- nothing is copied while a fetch is in flight.
-    constexpr int W = 2 * D;
-    unsigned hx[W], bx[W];                  // context, input byte
-    unsigned rq[W];                         // row address of this lane's quad
-    uint4 wq[W];                            // weights as fetched
-    int pq[W][4];                           // inputs as fetched (masked when used)
-    // the last D bytes done: row, context, weights as stored
-    unsigned hr[HN], hh[HN];
-    uint4 hw[HN];
-    auto near = [&](int sl, unsigned kk) __attribute__((always_inline)) {
-      rq[sl] = row_of(hx[sl], bx[sl]);
-      wq[sl] = *(g_u128a4*)(L.arena + rq[sl]);
+    PipeP8 out;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) pq[sl][x] = input(x, kk);
-    };
-#pragma unroll
-    for (int sl = 0; sl < W; ++sl) {
-      const unsigned kk = min((unsigned)sl, last);
-      hx[sl] = L.ctx(ci, kk);
-      bx[sl] = L.byte_at(kk);
-    }
-#pragma unroll
-    for (int sl = 0; sl < D; ++sl) near(sl, min((unsigned)sl, last));
-#pragma unroll
-    for (int i = 0; i < HN; ++i) { hr[i] = 0xFFFFFFFFu; hh[i] = hx[0]; hw[i] = make_uint4(0u, 0u, 0u, 0u); }
-    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)W) {
-#pragma unroll
-      for (int sl = 0; sl < W; ++sl) {
-        const unsigned k = kb + (unsigned)sl;
-        const bool on = k < L.nb;
-        const unsigned hcur = hx[sl], bcur = bx[sl], row = rq[sl];
-        uint4 w = wq[sl];
-        {
-          bool late = false;
-#pragma unroll
-          for (int i = HN - 1; i >= 0; --i) {                       // oldest first: the most recent store wins
-            const bool fw = row == hr[i];
-            w.x = fw ? hw[i].x : w.x; w.y = fw ? hw[i].y : w.y; w.z = fw ? hw[i].z : w.z; w.w = fw ? hw[i].w : w.w;
-            late = late || (hcur != hh[i] && (((hcur - hh[i]) & c.mask0) < 256u || ((hh[i] - hcur) & c.mask0) < 256u));
-          }
-          if (pipe_any(late)) {
-            pipe_stores_done();
-            if (late) w = pipe_settle(*(g_u128a4*)(L.arena + row));   // after every store so far, in this wavefront's order
-          }
-        }
-        const int w0 = (int)w.x, w1 = (int)w.y, w2 = (int)w.z, w3 = (int)w.w;
-        // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
-        const int p0 = have[0] ? pq[sl][0] : 0, p1 = have[1] ? pq[sl][1] : 0, p2 = have[2] ? pq[sl][2] : 0, p3 = have[3] ? pq[sl][3] : 0;
-        const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
-        const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
-        const int y = (int)((bcur >> (7u - B)) & 1u);
-        const int err = __mul24(y * 32767 - squash(pr), (int)c.a4) >> 4;
-        uint4 nw;
-        nw.x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
-        nw.y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
-        nw.z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
-        nw.w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
-        if (on) {
-          if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
-          if constexpr (TAIL != 0) {
-            if (tail) {
-              L.A32(row) = nw.x;
-              if constexpr (TAIL >= 2) L.A32(row + 4u) = nw.y;
-              if constexpr (TAIL >= 3) L.A32(row + 8u) = nw.z;
-            }
-          }
-          if (q == 0) *(g_i16*)((g_u8*)&L.p(I, k) + 2u * B) = (short)pr;
-        }
-#pragma unroll
-        for (int i = HN - 1; i > 0; --i) { hr[i] = hr[i - 1]; hh[i] = hh[i - 1]; hw[i] = hw[i - 1]; }
-        hr[0] = row; hh[0] = hcur; hw[0] = nw;
-        // this slot now takes byte k + W; the slot D ahead gets its row, weights and inputs (its context came D bytes ago)
-        {
-          const unsigned kw = min(k + (unsigned)W, last);
-          hx[sl] = L.ctx(ci, kw);
-          bx[sl] = L.byte_at(kw);
-          near((sl + D) % W, min(k + (unsigned)D, last));
+    for (int B = 0; B < 8; ++B) {
+      const unsigned row = rowc[B];
+      if constexpr (!batch) w[B] = *(g_u128a4*)(L.arena + row);
+      const int w0 = (int)w[B].x, w1 = (int)w[B].y, w2 = (int)w[B].z, w3 = (int)w[B].w;
+      const int p0 = pipe_p_get(pv[0], B), p1 = pipe_p_get(pv[1], B), p2 = pipe_p_get(pv[2], B), p3 = pipe_p_get(pv[3], B);
+      // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
+      const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
+      const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
+      out.set(B, pr);
+      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
+      nw[B].x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
+      nw[B].y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
+      nw[B].z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
+      nw[B].w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
+      if (act && !tail) *(g_u128a4*)(L.arena + row) = nw[B];
+      if constexpr (TAIL != 0) {
+        if (tail) {
+          L.A32(row) = nw[B].x;
+          if constexpr (TAIL >= 2) L.A32(row + 4u) = nw[B].y;
+          if constexpr (TAIL >= 3) L.A32(row + 8u) = nw[B].z;
         }
       }
     }
-  });
+    if (q == 0) L.put_p(I, k, out.get());
+    if constexpr (batch) {
+      if (late) {
+#pragma unroll
+        for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
+      }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        // (the tail lane's words past the row's end are never used: their inputs are 0 and they are not stored)
+        const bool fw = same && rown[B] == rowc[B];
+        w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y;
+        w[B].z = fw ? nw[B].z : wn[B].z; w[B].w = fw ? nw[B].w : wn[B].w;
+      }
+    }
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
+  }
 }
 
 template <class Chain>
@@ -1410,11 +1625,8 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r], first = Chain::MIX_FIRST[r];   // first = sum of QL of earlier roles
     const unsigned per_group = (unsigned)QL;                                                  // wavefronts per group
     if (wg < (unsigned)first * ngroups || wg >= (unsigned)(first + QL) * ngroups) return;
-    constexpr CompK c = Chain::comp[I];
-    constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-    constexpr int NQ = (m + 3) / 4, BPW = (int)Chain::PIPE_G / QL, TAIL = m % 4;
-    static_assert(BPW >= 1 && NQ <= QL, "MIX lane group");
-    constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
+    constexpr int BPW = (int)Chain::PIPE_G / QL;
+    static_assert(BPW >= 1, "MIX lane group");
     const unsigned wi = wg - (unsigned)first * ngroups;
     const unsigned g = wi / per_group, sub = wi % per_group;
     const unsigned bl = (unsigned)lane / QL, q = (unsigned)lane % QL;
@@ -1422,106 +1634,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
     if (bl >= (unsigned)BPW) { L.live = false; L.nb = 0; }          // lanes beyond this wavefront's blocks
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-    if (!L.nb) return;
-    const bool act = q < (unsigned)NQ;                               // lanes that hold weights
-    const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
-    const unsigned qoff = 16u * (act ? q : 0u);
-    bool have[4];
-    int tin[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int t = (int)q * 4 + x;
-      have[x] = t < m;
-      tin[x] = J + (have[x] ? t : 0);
-    }
-    auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
-      return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)c.stride) + qoff;   // s <= 24
-    };
-    unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-    const unsigned k1 = L.next(0);
-    unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
-    // inputs of the weights a lane does not have read as 0 (masked once per byte, not once per bit)
-    auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
-      const uint4 v = L.p(tin[x], kk);
-      const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
-      return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
-    };
-    uint4 pv[4], pv1[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) { pv[x] = inputs(x, 0); pv1[x] = inputs(x, k1); }
-    uint4 w[8];
-    unsigned rowc[8];
-#pragma unroll
-    for (int B = 0; B < 8; ++B) rowc[B] = row_of(h, byte, B);
-    if constexpr (batch) {
-#pragma unroll
-      for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
-    }
-    for (unsigned k = 0; k < L.nb; ++k) {
-      const unsigned k2 = min(k + 2u, L.nb - 1u);
-      const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
-      uint4 pv2[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
-      unsigned rown[8];
-#pragma unroll
-      for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
-      // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint),
-      // forwarded below; contexts less than 256 apart -> any position may coincide: fetched after the stores
-      const bool same = h1 == h;
-      const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
-      uint4 wn[8], nw[8];
-      if constexpr (batch) {
-        if (!late) {
-#pragma unroll
-          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
-        }
-      }
-      PipeP8 out;
-#pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        const unsigned row = rowc[B];
-        if constexpr (!batch) w[B] = *(g_u128a4*)(L.arena + row);
-        const int w0 = (int)w[B].x, w1 = (int)w[B].y, w2 = (int)w[B].z, w3 = (int)w[B].w;
-        const int p0 = pipe_p_get(pv[0], B), p1 = pipe_p_get(pv[1], B), p2 = pipe_p_get(pv[2], B), p3 = pipe_p_get(pv[3], B);
-        // (lanes without weights and the slots past a row's end have zero inputs: they add nothing)
-        const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
-        const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
-        out.set(B, pr);
-        const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
-        nw[B].x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
-        nw[B].y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
-        nw[B].z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
-        nw[B].w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
-        if (act && !tail) *(g_u128a4*)(L.arena + row) = nw[B];
-        if constexpr (TAIL != 0) {
-          if (tail) {
-            L.A32(row) = nw[B].x;
-            if constexpr (TAIL >= 2) L.A32(row + 4u) = nw[B].y;
-            if constexpr (TAIL >= 3) L.A32(row + 8u) = nw[B].z;
-          }
-        }
-      }
-      if (q == 0) L.p(I, k) = out.get();
-      if constexpr (batch) {
-        if (late) {
-#pragma unroll
-          for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
-        }
-#pragma unroll
-        for (int B = 0; B < 8; ++B) {
-          // (the tail lane's words past the row's end are never used: their inputs are 0 and they are not stored)
-          const bool fw = same && rown[B] == rowc[B];
-          w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y;
-          w[B].z = fw ? nw[B].z : wn[B].z; w[B].w = fw ? nw[B].w : wn[B].w;
-        }
-      }
-      h = h1; byte = byte1; h1 = h2; byte1 = byte2;
-#pragma unroll
-      for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
-    }
+    pipe_mix_unit<Chain, r>(L, q, squash);
   });
   }
 }
