@@ -245,7 +245,7 @@ def pipe_build(header: bytes, chunk: int | None = None, group: int | None = None
     dev = os.path.join(ROOT, "zpaq_amd", "csrc", "device")
     deps = b"".join(open(p, "rb").read() for p in (
         os.path.join(EMU, "wave_emu.h"), os.path.join(EMU, "wave_emu.cpp"), os.path.join(EMU, "pipe_emu_main.cpp"), os.path.join(EMU, "guard_alloc.h"),
-        os.path.join(dev, "pipe_kernel.h"), os.path.join(dev, "spec_kernel.h"), os.path.join(dev, "layout.h")))
+        os.path.join(dev, "pipe_kernel.h"), os.path.join(dev, "pipe_persist.h"), os.path.join(dev, "spec_kernel.h"), os.path.join(dev, "layout.h")))
     extra_flags = _sanitize_flags()
     key = hashlib.sha1(src.encode() + deps + " ".join(extra_flags).encode()).hexdigest()[:20]
     os.makedirs(BUILD, exist_ok=True)
@@ -268,8 +268,10 @@ def pipe_build(header: bytes, chunk: int | None = None, group: int | None = None
 
 
 def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, out_cap: int | None = None,
-             group: int | None = None, mode: int = 0):
-    """Encode every input as one block with the pipelined encoder.  Returns [(bytes, status, consumed)]."""
+             group: int | None = None, mode: int = 0, persist: bool = False):
+    """Encode every input as one block with the pipelined encoder.  Returns [(bytes, status, consumed)].
+    persist: the persistent launch (device/pipe_persist.h) -- every workgroup of the grid alive at once, the units waiting
+    for each other through their progress counters -- instead of the six kernels step by step."""
     exe = pipe_build(header, chunk, group, mode)
     cap = out_cap if out_cap is not None else max(len(x) for x in inputs) + 4096
     with tempfile.TemporaryDirectory(dir=BUILD) as td:
@@ -280,7 +282,7 @@ def pipe_run(header: bytes, inputs: Sequence[bytes], chunk: int | None = 64, out
             p = os.path.join(td, f"in{i}")
             open(p, "wb").write(bytes(d))
             paths.append(p)
-        r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), str(int(mode)), str(int(chunk or 0)), str(int(group or 0)), *paths],
+        r = subprocess.run([exe, hp, str(cap), os.path.join(td, "out"), str(int(mode) | (16 if persist else 0)), str(int(chunk or 0)), str(int(group or 0)), *paths],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
         if r.returncode != 0:
             raise RuntimeError(f"pipe emulator failed ({r.returncode}): {r.stderr[-2000:]}")

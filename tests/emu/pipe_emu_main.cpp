@@ -22,6 +22,7 @@ extern "C" void zpq_pipe_light(zpq::PipeArgs a);
 extern "C" void zpq_pipe_icm(zpq::PipeArgs a);
 extern "C" void zpq_pipe_isse(zpq::PipeArgs a);
 extern "C" void zpq_pipe_mix(zpq::PipeArgs a);
+extern "C" void zpq_pipe_persist(zpq::PipeArgs a);
 
 namespace {
 
@@ -45,6 +46,7 @@ void kernel_thunk(void* p) {
     case 2: zpq_pipe_light(l->a); break;
     case 3: zpq_pipe_icm(l->a); break;
     case 4: zpq_pipe_isse(l->a); break;
+    case 6: zpq_pipe_persist(l->a); break;
     default: zpq_pipe_mix(l->a); break;
   }
 }
@@ -75,7 +77,9 @@ int main(int argc, char** argv) {
   const std::vector<uint8_t> header = slurp(argv[1]);
   const uint32_t out_cap = (uint32_t)strtoul(argv[2], nullptr, 10);
   const std::string prefix = argv[3];
-  const int mode = atoi(argv[4]), chunk = atoi(argv[5]), group = atoi(argv[6]);
+  const int mode_arg = atoi(argv[4]), chunk = atoi(argv[5]), group = atoi(argv[6]);
+  const int mode = mode_arg & 15;
+  const bool persist = (mode_arg & 16) != 0;       // the persistent launch (device/pipe_persist.h): ONE grid of live workgroups
   argv += 3; argc -= 3;                    // the inputs follow
   const unsigned nb = (unsigned)(argc - 4);
 
@@ -134,6 +138,22 @@ int main(int argc, char** argv) {
     if (ins[b].size() > maxlen) maxlen = (unsigned)ins[b].size();
   }
   const unsigned nchunks = maxlen ? (maxlen + C - 1) / C : 1;
+  if (persist) {
+    const unsigned wpg = (unsigned)lay[14], waves = (unsigned)(lay[15] & 0xFFFF), nunit = (unsigned)(lay[15] >> 16);
+    if (!wpg) { fprintf(stderr, "pipe_emu_run: this chain has no persistent launch\n"); return 2; }
+    std::vector<uint32_t> prog((size_t)ngroups * nunit, 0), gchunks(ngroups, 1), ctl(4, 0);
+    for (unsigned g = 0; g < ngroups; ++g) {
+      unsigned ml = 0;
+      for (unsigned b = g * G; b < nb && b < (g + 1) * G; ++b) if (ins[b].size() > ml) ml = (unsigned)ins[b].size();
+      gchunks[g] = ml ? (ml + C - 1) / C : 1;
+    }
+    Launch l{6, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, 0, 0u}};
+    l.a.prog = prog.data(); l.a.group_chunks = gchunks.data(); l.a.ctl = ctl.data();
+    l.a.group0 = 0; l.a.ngroups_here = ngroups; l.a.timeout_ticks = 200000;
+    l.a.spread = ngroups > 1 ? 2 : 1;          // (the device spreads over its 8 XCDs: here two, so that the mapping is exercised)
+    emu::run_grid(kernel_thunk, &l, 64 * waves, l.a.spread * ((ngroups + l.a.spread - 1) / l.a.spread) * wpg, 0);
+    if (ctl[0]) { fprintf(stderr, "pipe_emu_run: the persistent launch aborted (slot %u, chunk %u)\n", ctl[1], ctl[2]); return 4; }
+  } else {
   const unsigned grids[6] = {(nb + hl - 1) / hl, nrows * ngroups, nlight * ngroups, nicm * ngroups, nisse * ngroups, mixw * ngroups};
   for (unsigned step = 0; step < nchunks + maxlevel; ++step) {
     Launch l{0, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, (int)step, 0u}};
@@ -141,6 +161,7 @@ int main(int argc, char** argv) {
       l.which = which;
       for (unsigned wg = grids[which]; wg-- > 0;) emu::run_workgroup(kernel_thunk, &l, which == 0 ? 64 : (which == 5 ? mixt : (which == 1 ? rowt : (which == 2 ? lightt : G))), wg);
     }
+  }
   }
   for (unsigned b = 0; b < nb; ++b) {
     for (unsigned k = 0; k < 64; ++k)

@@ -18,12 +18,13 @@ namespace emu {
 
 Dim3 g_threadIdx{0, 0, 0}, g_blockIdx{0, 0, 0}, g_blockDim{1, 1, 1};
 
-enum State { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
+enum State { READY, WAIT_WAVE, WAIT_BLOCK, PARKED, DONE };
 
 struct Fiber {
   void* sp = nullptr;
   void* stack = nullptr;
-  unsigned tid = 0;
+  unsigned tid = 0;            // thread index inside its workgroup
+  unsigned wg = 0;             // workgroup (index into the grid being run)
   State state = READY;
   unsigned long nops = 0;      // cross-lane exchanges done (parity selects the exchange buffer)
 };
@@ -34,8 +35,11 @@ static Fiber* g_cur = nullptr;
 static void* g_sched_sp = nullptr;
 static KernelFn g_fn = nullptr;
 static void* g_args = nullptr;
-static std::vector<int> g_xbuf;          // [wave][2][64]
+static std::vector<int> g_xbuf;          // [workgroup][wave][2][64]
 static unsigned long g_ops = 0;
+static unsigned g_threads = 0, g_waves = 0, g_block0 = 0;
+static std::vector<std::vector<unsigned char>> g_lds;      // per workgroup of the grid (wg_lds)
+static unsigned long long g_ticks = 0;                     // scheduler rounds: the emulated clock
 
 extern "C" void emu_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -75,10 +79,10 @@ int lane_id() { return (int)(g_cur->tid & 63u); }
 int* wave_exchange(int value) {
   Fiber* f = g_cur;
   const unsigned wave = f->tid >> 6, lane = f->tid & 63u;
-  int* buf = &g_xbuf[((size_t)wave * 2 + (f->nops & 1)) * 64];
+  int* buf = &g_xbuf[(((size_t)f->wg * g_waves + wave) * 2 + (f->nops & 1)) * 64];
   buf[lane] = value;
   ++f->nops;
-  if (f->tid == 0) ++g_ops;
+  if (f->tid == 0 && f->wg == 0) ++g_ops;
   f->state = WAIT_WAVE;
   to_scheduler();
   return buf;
@@ -89,25 +93,46 @@ void block_barrier() {
   to_scheduler();
 }
 
-// a lane polling memory another wavefront of the workgroup writes: let everybody else run, then look again
+// a lane polling memory another wavefront writes: let everybody else run, then look again
 void spin_yield() {
   g_cur->state = READY;
   to_scheduler();
 }
 
+// The lanes of a wavefront that left a divergent region early (a `return` out of a unit function whose other lanes still
+// exchange values) wait here until the rest of the wavefront arrives: what the EXEC mask does on the hardware.  While they
+// wait they do not count as participants of the others' cross-lane operations.
+void wave_reconverge() {
+  g_cur->state = PARKED;
+  to_scheduler();
+}
+
+void* wg_lds(size_t bytes) {
+  std::vector<unsigned char>& v = g_lds[g_cur->wg];
+  if (v.size() < bytes) v.resize(bytes, 0xCD);
+  return v.data();
+}
+
+unsigned long long ticks() { return g_ticks; }
+
 unsigned long cross_lane_ops() { return g_ops; }
 
-void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) {
+void run_grid(KernelFn fn, void* args, unsigned threads, unsigned nblocks, unsigned block0) {
   g_fn = fn;
   g_args = args;
-  g_blockIdx = Dim3{bx, 0, 0};
+  g_threads = threads;
+  g_block0 = block0;
   g_blockDim = Dim3{threads, 1, 1};
   const unsigned waves = (threads + 63) / 64;
-  g_xbuf.assign((size_t)waves * 2 * 64, 0);
-  g_fibers.assign(threads, Fiber{});
-  for (unsigned t = 0; t < threads; ++t) {
-    Fiber& f = g_fibers[t];
-    f.tid = t;
+  g_waves = waves;
+  g_xbuf.assign((size_t)nblocks * waves * 2 * 64, 0);
+  g_lds.assign(nblocks, {});
+  const unsigned total = threads * nblocks;
+  g_fibers.assign(total, Fiber{});
+  for (unsigned i = 0; i < total; ++i) {
+    Fiber& f = g_fibers[i];
+    f.tid = i % threads;
+    f.wg = i / threads;
     f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (f.stack == MAP_FAILED) { perror("mmap"); abort(); }
     uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
@@ -123,52 +148,78 @@ void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) {
   static const char* order_env = getenv("ZPQ_EMU_ORDER");
   static const int order_mode = !order_env ? 0 : (!strncmp(order_env, "reverse", 7) ? 1 : (!strncmp(order_env, "shuffle", 7) ? 2 : 0));
   static unsigned long long order_rng = order_env && strchr(order_env, ':') ? strtoull(strchr(order_env, ':') + 1, nullptr, 10) * 2654435761ull + 1 : 12345;
-  std::vector<unsigned> order(threads);
-  for (unsigned t = 0; t < threads; ++t) order[t] = order_mode == 1 ? threads - 1 - t : t;
+  std::vector<unsigned> order(total);
+  for (unsigned t = 0; t < total; ++t) order[t] = order_mode == 1 ? total - 1 - t : t;
   for (;;) {
     bool ran = false;
+    ++g_ticks;
     if (order_mode == 2)
-      for (unsigned t = threads; t > 1; --t) {
+      for (unsigned t = total; t > 1; --t) {
         order_rng = order_rng * 6364136223846793005ull + 1442695040888963407ull;
         std::swap(order[t - 1], order[(unsigned)((order_rng >> 33) % t)]);
       }
-    for (unsigned oi = 0; oi < threads; ++oi) {
-      const unsigned t = order[oi];
-      Fiber& f = g_fibers[t];
+    for (unsigned oi = 0; oi < total; ++oi) {
+      Fiber& f = g_fibers[order[oi]];
       if (f.state != READY) continue;
       g_cur = &f;
-      g_threadIdx = Dim3{t, 0, 0};
+      g_threadIdx = Dim3{f.tid, 0, 0};
+      g_blockIdx = Dim3{block0 + f.wg, 0, 0};
       emu_switch(&g_sched_sp, f.sp);
       ran = true;
     }
-    // release wavefronts whose live lanes have all arrived at the same exchange
-    unsigned done = 0, at_barrier = 0;
-    for (unsigned w = 0; w < waves; ++w) {
-      unsigned waiting = 0, live = 0;
-      const unsigned lo = w * 64, hi = lo + 64 < threads ? lo + 64 : threads;
-      for (unsigned t = lo; t < hi; ++t) {
-        if (g_fibers[t].state == DONE) { ++done; continue; }
-        ++live;
-        if (g_fibers[t].state == WAIT_WAVE) ++waiting;
-        if (g_fibers[t].state == WAIT_BLOCK) ++at_barrier;
+    unsigned done_all = 0;
+    for (unsigned wg = 0; wg < nblocks; ++wg) {
+      const unsigned base = wg * threads;
+      // release wavefronts whose live lanes have all arrived at the same exchange (parked lanes stand aside), and parked
+      // wavefronts once every lane that has not finished is parked
+      unsigned done = 0, at_barrier = 0;
+      for (unsigned w = 0; w < waves; ++w) {
+        unsigned waiting = 0, live = 0, parked = 0, notdone = 0;
+        const unsigned lo = w * 64, hi = lo + 64 < threads ? lo + 64 : threads;
+        for (unsigned t = lo; t < hi; ++t) {
+          const State st = g_fibers[base + t].state;
+          if (st == DONE) { ++done; continue; }
+          ++notdone;
+          if (st == PARKED) { ++parked; continue; }
+          ++live;
+          if (st == WAIT_WAVE) ++waiting;
+          if (st == WAIT_BLOCK) ++at_barrier;
+        }
+        if (live && waiting == live) {
+          unsigned long nops = 0;
+          for (unsigned t = lo; t < hi; ++t)
+            if (g_fibers[base + t].state == WAIT_WAVE) { g_fibers[base + t].state = READY; nops = g_fibers[base + t].nops; }
+          if (parked) {      // parked lanes are inactive: they contribute nothing to this exchange (ballot: 0)
+            int* buf = &g_xbuf[(((size_t)wg * waves + w) * 2 + ((nops - 1) & 1)) * 64];
+            for (unsigned t = lo; t < hi; ++t)
+              if (g_fibers[base + t].state == PARKED) buf[t - lo] = 0;
+          }
+          ran = true;
+        } else if (notdone && parked == notdone) {
+          unsigned long nops = 0;        // the lanes rejoin with one exchange count (the ones that left early did fewer)
+          for (unsigned t = lo; t < hi; ++t)
+            if (g_fibers[base + t].state == PARKED && g_fibers[base + t].nops > nops) nops = g_fibers[base + t].nops;
+          for (unsigned t = lo; t < hi; ++t)
+            if (g_fibers[base + t].state == PARKED) { g_fibers[base + t].state = READY; g_fibers[base + t].nops = nops; }
+          ran = true;
+        }
       }
-      if (live && waiting == live) {
-        for (unsigned t = lo; t < hi; ++t)
-          if (g_fibers[t].state == WAIT_WAVE) g_fibers[t].state = READY;
+      done_all += done;
+      if (at_barrier && at_barrier + done == threads) {
+        for (unsigned t = 0; t < threads; ++t)
+          if (g_fibers[base + t].state == WAIT_BLOCK) g_fibers[base + t].state = READY;
         ran = true;
       }
     }
-    if (done == threads) break;
-    if (at_barrier && at_barrier + done == threads) {
-      for (unsigned t = 0; t < threads; ++t)
-        if (g_fibers[t].state == WAIT_BLOCK) g_fibers[t].state = READY;
-      ran = true;
-    }
+    if (done_all == total) break;
     if (!ran) { fprintf(stderr, "wave_emu: deadlock -- the lanes of a wavefront disagree about the next cross-lane operation "
                            "(one sits in divergent control flow) or a barrier is not reached by every thread\n"); abort(); }
   }
   for (Fiber& f : g_fibers) munmap(f.stack, kStack);
   g_fibers.clear();
+  g_lds.clear();
 }
+
+void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx) { run_grid(fn, args, threads, 1, bx); }
 
 }  // namespace emu

@@ -55,11 +55,16 @@ extern Dim3 g_threadIdx, g_blockIdx, g_blockDim;   // of the fiber that is runni
 int* wave_exchange(int value);          // publish `value`, wait, return pointer to the 64 published values
 void block_barrier();                   // __syncthreads
 void spin_yield();                      // inside a poll loop on LDS / memory another wavefront writes
+void wave_reconverge();                 // lanes that returned early out of a divergent region wait for the rest of their wavefront
+void* wg_lds(size_t bytes);             // the running workgroup's LDS (kernels that run as a GRID of live workgroups: run_grid)
+unsigned long long ticks();             // the emulated clock: scheduler rounds
 int lane_id();
 
 typedef void (*KernelFn)(void* args);
 // run `fn(args)` once per thread of a workgroup of `threads` threads, block index `bx`
 void run_workgroup(KernelFn fn, void* args, unsigned threads, unsigned bx);
+// all workgroups block0 .. block0 + nblocks - 1 alive together (a persistent launch whose workgroups wait for each other)
+void run_grid(KernelFn fn, void* args, unsigned threads, unsigned nblocks, unsigned block0);
 unsigned long cross_lane_ops();         // statistics: exchanges executed by lane 0 of wave 0
 
 }  // namespace emu

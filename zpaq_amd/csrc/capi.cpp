@@ -214,6 +214,8 @@ int zpq_plan_pipe_layout_opts(const zpq_plan* p, int mode, int chunk, int group,
   out[4] = L.icm.size(); out[5] = L.isse.size(); out[6] = (uint64_t)L.mix_waves_per_group();
   out[7] = (uint64_t)L.hcomp_lanes; out[8] = (uint64_t)L.coder_level; out[9] = (uint64_t)L.G; out[10] = L.rows.size();
   out[11] = (uint64_t)L.mix_threads(); out[12] = (uint64_t)L.G; out[13] = (uint64_t)L.light_threads();
+  // the persistent launch (0: the chain cannot be packed): workgroups per group, wavefronts per workgroup | progress counters per group << 16
+  out[14] = L.persist_ok ? (uint64_t)L.ps_wpg : 0; out[15] = (uint64_t)L.ps_waves | (uint64_t)L.ps_nunit << 16;
   return ZPQ_OK;
   ZPQ_CATCH
 }

@@ -99,12 +99,14 @@ struct Engine {
   DevBuf segs;                         // segment tables of multi-segment blocks
   DevBuf sha_jobs, sha_out;            // SHA-1 of the staged inputs (sha1_blocks_kernel)
   DevBuf pipe;                         // stream buffers of the pipelined encoder (device/pipe_kernel.h)
+  DevBuf pipe_ctl;                     // the persistent launch's progress counters, chunk counts and abort words (device/pipe_persist.h)
   HostPinned pin_in;                   // page-locked staging of host inputs, kept between calls (ZPAQ_AMD_PINNED_STAGE=0: pageable)
   HostPinned pin_out;                  // ... and of the outputs of a large batch
   hipStream_t pstream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per pipe kernel
   std::vector<hipStream_t> side;       // extra streams: independent launch groups run concurrently
   Timing last{};
   int last_kind = 0;
+  bool last_persist = false;           // the last batch's pipelined groups ran as persistent launches
   int jit_left = 0;                    // hipRTC compilations still allowed in the current call
   int cus = 256;                       // compute units of the device
   hipEvent_t busy = nullptr;           // recorded after the last launch of a call that returned with work in flight
@@ -493,6 +495,10 @@ struct PipeRun {
   bool consumes[6][6];
   int slack;
   uint32_t chunk;            // input bytes per step
+  // the persistent launch (device/pipe_persist.h)
+  uint32_t group_blocks = 0; // blocks per group
+  uint32_t ps_wpg = 0, ps_waves = 0, ps_nunit = 0;     // workgroups per group (0: the chain has none), wavefronts per workgroup, counters per group
+  std::vector<uint32_t> group_chunks;                  // per group: chunks of its longest block
 };
 
 // ZPAQ_AMD_PIPE_PROFILE=1: run every unit type of every step alone on one stream between two events and print the
@@ -543,6 +549,119 @@ struct LateInput {
   uint32_t from_byte = 0;                       // 0: nothing is late
   std::function<hipEvent_t()> arrive;
 };
+
+// ---- the persistent launch ------------------------------------------------------------------------------------
+// ONE launch per run for the whole sequence: every unit of every group is a wavefront that walks its chunks and waits for
+// the units it depends on through progress counters in HBM (device/pipe_persist.h).  All workgroups must be resident at
+// once, so the engine launches at most what the device holds (occupancy API x compute units): a run with more groups goes
+// in rounds, several runs go side by side when they fit together -- otherwise the six kernels code the batch.
+// Returns false when the persistent path does not apply (nothing was launched).  A launch whose watchdog fired (a
+// workgroup did not get a compute unit: something else held the GPU) sets *aborted: the caller re-initialises the arenas
+// and runs the six kernels.
+static uint32_t persist_timeout_ticks() {
+  uint32_t ms = 3000;
+  if (const char* t = getenv("ZPAQ_AMD_PERSIST_TIMEOUT_MS")) ms = (uint32_t)std::max(1, atoi(t));
+  return (uint32_t)std::min<uint64_t>((uint64_t)ms * 100000ull, 0xFFFFFFF0ull);      // s_memrealtime: 100 MHz
+}
+
+static bool persist_wanted(const std::vector<PipeRun>& runs, bool single_launch_batch) {
+  const char* v = getenv("ZPAQ_AMD_PIPE_PERSIST");
+  if (v && !strcmp(v, "0")) return false;
+  if (getenv("ZPAQ_AMD_PIPE_PROFILE") || getenv("ZPAQ_AMD_PIPE_TRACE")) return false;
+  if (!single_launch_batch) return false;
+  for (const PipeRun& r : runs) if (!r.k->persist || !r.ps_wpg) return false;
+  return !runs.empty();
+}
+
+// workgroups of a run's persistent kernel the device holds at once (0: unknown / none)
+static uint32_t persist_capacity(Engine& e, PipeRun& r) {
+  if (!r.k->persist_wg_per_cu) {
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, r.k->persist, (int)(64 * r.ps_waves), 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    r.k->persist_wg_per_cu = nb > 0 ? nb : -1;
+  }
+  return r.k->persist_wg_per_cu > 0 ? (uint32_t)r.k->persist_wg_per_cu * (uint32_t)e.cus : 0u;
+}
+
+static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, bool* aborted, std::string* what) {
+  *aborted = false;
+  // what the device holds
+  uint64_t need_wg = 0;
+  std::vector<uint32_t> cap(runs.size());
+  for (size_t i = 0; i < runs.size(); ++i) {
+    PipeRun& r = runs[i];
+    cap[i] = persist_capacity(e, r);
+    need_wg += (uint64_t)r.ngroups * r.ps_wpg;
+    if (cap[i] < r.ps_wpg) return false;
+  }
+  // several runs: only side by side (a second round costs a whole block's serial time whatever it holds)
+  if (runs.size() > 1) {
+    uint32_t c = cap[0];
+    for (uint32_t x : cap) c = std::min(c, x);
+    if (need_wg > c) return false;
+  }
+  // control block per run: [ctl 4 words][group_chunks ngroups][prog ngroups * nunit]
+  uint64_t words = 0;
+  std::vector<uint64_t> base(runs.size());
+  for (size_t i = 0; i < runs.size(); ++i) {
+    base[i] = words;
+    words += 4 + runs[i].ngroups + (uint64_t)runs[i].ngroups * runs[i].ps_nunit;
+    words = (words + 63) & ~63ull;
+  }
+  e.pipe_ctl.ensure(words * 4);
+  std::vector<uint32_t> host(words, 0);
+  for (size_t i = 0; i < runs.size(); ++i)
+    for (uint32_t g = 0; g < runs[i].ngroups; ++g) host[base[i] + 4 + g] = runs[i].group_chunks[g];
+  HIP_CHECK(hipMemcpyAsync(e.pipe_ctl.p, host.data(), words * 4, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));            // (host vector; and nothing else of this call may still occupy compute units)
+  const uint32_t timeout = persist_timeout_ticks();
+  while (e.side.size() + 1 < runs.size()) {
+    hipStream_t s2;
+    HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    e.side.push_back(s2);
+  }
+  Event fork;
+  if (runs.size() > 1) HIP_CHECK(hipEventRecord(fork, st));
+  std::vector<std::unique_ptr<Event>> joins;
+  for (size_t i = 0; i < runs.size(); ++i) {
+    PipeRun& r = runs[i];
+    hipStream_t rs = i == 0 ? st : e.side[i - 1];
+    if (i) HIP_CHECK(hipStreamWaitEvent(rs, fork, 0));
+    uint32_t* ctl = (uint32_t*)e.pipe_ctl.p + base[i];
+    const uint32_t most = std::max<uint32_t>(1u, cap[i] / r.ps_wpg);                  // groups that are resident together
+    const uint32_t rounds = (r.ngroups + most - 1) / most;
+    const uint32_t per_round = (r.ngroups + rounds - 1) / rounds;                     // (rounds of equal size)
+    for (uint32_t g0 = 0; g0 < r.ngroups; g0 += per_round) {
+      PipeArgs a = r.args;
+      a.step = 0; a.wg0 = 0;
+      a.ctl = ctl;
+      a.group_chunks = ctl + 4;
+      a.prog = ctl + 4 + r.ngroups;
+      a.group0 = g0;
+      a.ngroups_here = std::min(per_round, r.ngroups - g0);
+      a.timeout_ticks = timeout;
+      a.spread = a.ngroups_here >= 8 ? 8u : 1u;
+      const uint32_t grid = a.spread * ((a.ngroups_here + a.spread - 1) / a.spread) * r.ps_wpg;
+      void* args[1] = {(void*)&a};
+      HIP_CHECK(hipModuleLaunchKernel(r.k->persist, grid, 1, 1, 64u * r.ps_waves, 1, 1, 0, rs, args, nullptr));
+    }
+    if (i) {
+      joins.emplace_back(new Event());
+      HIP_CHECK(hipEventRecord(*joins.back(), rs));
+      HIP_CHECK(hipStreamWaitEvent(st, *joins.back(), 0));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (size_t i = 0; i < runs.size(); ++i) {
+    uint32_t c[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpy(c, (uint32_t*)e.pipe_ctl.p + base[i], sizeof c, hipMemcpyDeviceToHost));
+    if (c[0]) {
+      *aborted = true;
+      if (what) *what = "run " + std::to_string(i) + ": the unit in slot " + std::to_string(c[1]) + " gave up waiting at chunk " + std::to_string(c[2]);
+    }
+  }
+  return true;
+}
 
 static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, LateInput* late = nullptr) {
   if (runs.empty()) { if (late && late->from_byte) (void)late->arrive(); return; }
@@ -646,7 +765,7 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, L
 // so that each group is one launch (or one launch sequence).
 static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res,
                        const std::vector<LaunchGroup>& groups, uint32_t nb, uint64_t max_arena, hipStream_t st,
-                       bool timed, LateInput* late = nullptr) {
+                       bool timed, LateInput* late = nullptr, const BlockJob* h_jobs = nullptr) {
   Event ev0(true), ev1(true), ev2(true), ev3(true);
   // enough 256-thread groups per block to stream the arena at HBM rate
   uint64_t per = max_arena / (256 * 16 * 8) + 1;
@@ -688,6 +807,16 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.grid[5] = (uint32_t)L.mix_waves_per_group() * ng;
     const uint32_t nchunks = g.max_len ? (g.max_len + (uint32_t)L.C - 1) / (uint32_t)L.C : 1u;
     r.nsteps = nchunks + (uint32_t)L.coder_level;
+    r.group_blocks = (uint32_t)L.G;
+    if (L.persist_ok && h_jobs) {
+      r.ps_wpg = (uint32_t)L.ps_wpg; r.ps_waves = (uint32_t)L.ps_waves; r.ps_nunit = (uint32_t)L.ps_nunit;
+      r.group_chunks.assign(ng, 1u);
+      for (uint32_t b = 0; b < g.count; ++b) {
+        const uint32_t len = h_jobs[g.first + b].in_len;
+        uint32_t& gc = r.group_chunks[b / (uint32_t)L.G];
+        gc = std::max(gc, len ? (len + (uint32_t)L.C - 1) / (uint32_t)L.C : 1u);
+      }
+    }
     pipe_off += (uint64_t)ng * L.group_bytes;
     runs.push_back(r);
   }
@@ -714,7 +843,32 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     else HIP_CHECK(launch_code_serial(decode, d_jobs + g.first, d_res, g.count, e.d_tables, gs));
     ++gi;
   }
-  launch_pipe(e, runs, st, late);
+  // the persistent launch when every group of the batch is a pipelined one, the call waits for its results anyway, and the
+  // groups are resident together (one round, or rounds that are nearly full: a round costs a block's serial time whatever it holds)
+  bool coded = false;
+  if (timed && nsingle == 0 && persist_wanted(runs, true)) {
+    bool fits = true;
+    if (runs.size() == 1 && persist_capacity(e, runs[0]) >= runs[0].ps_wpg) {
+      const uint32_t per_round = std::max<uint32_t>(1u, persist_capacity(e, runs[0]) / runs[0].ps_wpg);
+      const uint32_t rounds = (runs[0].ngroups + per_round - 1) / per_round;
+      fits = rounds == 1 || (double)runs[0].ngroups / ((double)rounds * per_round) >= 0.85 || getenv("ZPAQ_AMD_PIPE_PERSIST");
+    }
+    if (fits) {
+      if (late && late->from_byte) HIP_CHECK(hipStreamWaitEvent(st, late->arrive(), 0));
+      bool aborted = false;
+      std::string what;
+      if (launch_pipe_persist(e, runs, st, &aborted, &what)) {
+        coded = !aborted;
+        if (aborted) {
+          fprintf(stderr, "[zpaq_amd] persistent encoder launch gave up (%s): coding the batch with the step kernels\n", what.c_str());
+          for (uint32_t b0 = 0; b0 < nb; b0 += 65535u)
+            HIP_CHECK(launch_init_arena(d_jobs + b0, std::min(nb - b0, 65535u), e.d_tables, chunks, st));
+        }
+      }
+    }
+  }
+  e.last_persist = coded;
+  if (!coded) launch_pipe(e, runs, st, late);
   for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
     Event done;
     HIP_CHECK(hipEventRecord(done, e.side[k]));
@@ -1171,7 +1325,7 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     const auto wave_t0 = std::chrono::steady_clock::now();
     e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
-               e.stream, true, split ? &late : nullptr);
+               e.stream, true, split ? &late : nullptr, jobs.data());
     if (split && !tail_sent) HIP_CHECK(hipStreamWaitEvent(e.stream, late.arrive(), 0));   // (no pipelined group after all)
     e.last.init_ms += before.init_ms;
     e.last.code_ms += before.code_ms;
@@ -1298,7 +1452,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   HIP_CHECK(hipStreamSynchronize(st));   // jobs vector goes out of scope below
   e.last = Timing{};
   e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
-  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed);
+  launch_all(e, decode, (const BlockJob*)e.jobs.p, d_res, groups, nblocks, max_arena, st, timed, nullptr, jobs.data());
   if (!timed) mark_in_flight(e, st);
 }
 

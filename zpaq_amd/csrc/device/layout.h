@@ -154,6 +154,13 @@ struct PipeArgs {
   unsigned long long* trace;
   uint32_t trace_base;
   uint32_t reserved;
+  // The persistent launch (device/pipe_persist.h): one workgroup set per group of blocks for the whole sequence
+  uint32_t* prog;                 // progress counters, PS_NUNIT per group, zero at launch
+  const uint32_t* group_chunks;   // per group: chunks of its longest block (at least 1)
+  uint32_t* ctl;                  // [0] abort flag (zero at launch), [1] the slot whose watchdog fired, [2] its chunk
+  uint32_t group0, ngroups_here;  // the groups this launch serves
+  uint32_t timeout_ticks;         // 100 MHz ticks a poller waits without progress before it raises the abort flag
+  uint32_t spread;                // workgroup b serves group group0 + b % spread + spread * (b / spread / PS_WPG): 8 = one XCD per group
 };
 
 // LDS plan of the specialised kernel (spec_kernel.h), known to the host code

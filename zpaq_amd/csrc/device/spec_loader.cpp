@@ -122,9 +122,10 @@ bool spec_source_and_key(const zpq_plan& plan, int variant, std::string& source,
 
 bool pipe_source_and_key(const zpq_plan& plan, const PipeOptions& opt, std::string& source, std::string& key, std::string& why_not) {
   if (!generate_pipe_source(plan, opt, source, why_not)) return false;
-  std::string h1, h2, h3;
+  std::string h1, h2, h3, h4;
   const std::string inc = spec_include_dir();
-  if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) || !read_file(inc + "/pipe_kernel.h", h3)) {
+  if (!read_file(inc + "/spec_kernel.h", h1) || !read_file(inc + "/layout.h", h2) || !read_file(inc + "/pipe_kernel.h", h3) ||
+      !read_file(inc + "/pipe_persist.h", h4)) {
     why_not = "kernel template headers not found under " + inc;
     return false;
   }
@@ -133,6 +134,7 @@ bool pipe_source_and_key(const zpq_plan& plan, const PipeOptions& opt, std::stri
   s.update(h1.data(), h1.size());
   s.update(h2.data(), h2.size());
   s.update(h3.data(), h3.size());
+  s.update(h4.data(), h4.size());
   if (const char* defs = getenv("ZPAQ_AMD_SPEC_DEFS")) s.update(defs, strlen(defs));
   key = hex20(s.result());
   return true;
@@ -448,6 +450,7 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit, bool* did_
     delete k;
     return nullptr;
   }
+  if (hipModuleGetFunction(&k->persist, k->module, "zpq_pipe_persist") != hipSuccess) { (void)hipGetLastError(); k->persist = nullptr; }
   k->origin = origin;
   plan->cur().pipe[mode] = k;
   plan->cur().pipe_state[mode] = 1;

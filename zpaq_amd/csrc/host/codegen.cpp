@@ -299,6 +299,135 @@ PipeOptions pipe_options(int variant) {
   return o;
 }
 
+// The persistent launch: units, their dependencies, and a packing of a group's unit wavefronts into workgroups whose LDS
+// fits a CU (device/pipe_persist.h).  Leaves L.persist_ok false (with a reason) when the chain cannot be packed; the six
+// kernels then code it step by step.
+static const int kPersistRoBytes = 4096 + 512 + 2688 + (2016 * 4 + 512) + 1024;      // = sizeof(zpq::PipeRO) on the device
+static const int kPersistLdsCap = 163840 - 512;                                       // gfx950: 160 KiB per workgroup
+static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
+  const CompDesc* comp = plan.comps();
+  const PlanHeader& ph = plan.hdr();
+  const int n = L.n, G = L.G;
+  enum { K_CONS = 2, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER, K_CM_BITS, K_MIX2_BITS, K_SSE_BITS };
+  L.persist_ok = false;
+  L.ps_slots.clear(); L.ps_deps.clear();
+  // units: 0 = HCOMP, then per component its ROW unit (ICM / ISSE) and the unit that writes its p stream, then the coder
+  int nunit = 1;
+  std::vector<int> row_unit(n, -1), p_unit(n, -1);
+  for (int i = 0; i < n; ++i) {
+    if (L.row[i] >= 0) row_unit[i] = nunit++;
+    p_unit[i] = nunit++;
+  }
+  const int coder_unit = nunit++;
+  L.ps_nunit = nunit;
+  std::vector<int> unit_waves(nunit, 0);
+  std::vector<PipeLayout::Slot> slots;
+  auto add = [&](int kind, int role, int sub, int unit, int lds, float cost) {
+    PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost;
+    slots.push_back(s); ++unit_waves[unit];
+  };
+  const int hl = std::min(L.hcomp_lanes, G);
+  const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
+  for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.22f);
+  for (size_t r = 0; r < L.rows.size(); ++r) add(1, (int)r, 0, row_unit[L.rows[r]], 0, 0.53f);
+  for (size_t r = 0; r < L.light.size(); ++r) {
+    const int k = L.light[r].first, i = L.light[r].second;
+    static const float lc[12] = {0, 0, 0.1f, 0.75f, 0.65f, 0.2f, 0.64f, 1.2f, 0.62f, 0.45f, 0.45f, 0.98f};
+    add(2, (int)r, 0, k == K_CODER ? coder_unit : p_unit[i], 0, lc[k < 12 ? k : 0]);
+  }
+  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 0.45f);
+  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 0.47f);
+  for (size_t r = 0; r < L.mix.size(); ++r)
+    for (int sub = 0; sub < L.mix_waves_of(L.mix_ql[r]); ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.4f : 1.1f);
+  // who reads whose streams
+  std::vector<std::vector<int>> producers(nunit);
+  auto reads = [&](int u, int v) { if (u != v && std::find(producers[u].begin(), producers[u].end(), v) == producers[u].end()) producers[u].push_back(v); };
+  for (int i = 0; i < n; ++i) {
+    const CompDesc& c = comp[i];
+    const int u = p_unit[i];
+    if (L.row[i] >= 0) { reads(row_unit[i], 0); reads(u, row_unit[i]); }       // ROW unit: contexts; the map: bit histories
+    else if (L.ctx[i] >= 0) reads(u, 0);
+    switch (c.type) {
+      case C_ISSE: reads(u, p_unit[c.a2]); break;
+      case C_AVG: reads(u, p_unit[c.a1]); reads(u, p_unit[c.a2]); break;
+      case C_MIX2: reads(u, p_unit[c.a2]); reads(u, p_unit[c.a3]); break;
+      case C_SSE: reads(u, p_unit[c.a2]); break;
+      case C_MIX: for (unsigned t = 0; t < c.a3; ++t) reads(u, p_unit[c.a2 + t]); break;
+      default: break;
+    }
+  }
+  reads(coder_unit, p_unit[n - 1]);
+  reads(coder_unit, 0);                                  // HCOMP's status word
+  std::vector<std::vector<PipeLayout::Dep>> unit_deps(nunit);
+  for (int u = 0; u < nunit; ++u)
+    for (int v : producers[u]) {
+      unit_deps[u].push_back({v, 0, unit_waves[v]});        // v has finished the chunk
+      unit_deps[v].push_back({u, L.S, unit_waves[u]});      // u is done with the ring slot v is about to overwrite
+    }
+  // A unit of several wavefronts shares ONE counter: its wavefronts start chunk c together (counter >= waves * c), so that a
+  // sum of waves * (c + 1) can only be made of everybody's chunk c (a wavefront that ran ahead would otherwise stand in for a late one)
+  for (int u = 0; u < nunit; ++u)
+    if (unit_waves[u] > 1) unit_deps[u].push_back({u, 1, unit_waves[u]});
+  // pack: wavefronts per workgroup W (<= 8: the MIX units' ~180 VGPRs allow two wavefronts per SIMD), LDS per workgroup
+  const int total = (int)slots.size();
+  const int cap = kPersistLdsCap - kPersistRoBytes;
+  for (const auto& s : slots) if (s.lds > cap) { L.persist_why = "a unit's tables do not fit a workgroup's LDS"; return; }
+  for (int wpg = (total + 7) / 8; wpg <= total; ++wpg) {
+    const int W = std::min(8, total);
+    struct Bin { std::vector<int> s; int lds = 0; float cost = 0; };
+    std::vector<Bin> bins(wpg);
+    std::vector<int> order(total);
+    for (int i = 0; i < total; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      if (slots[x].lds != slots[y].lds) return slots[x].lds > slots[y].lds;
+      return slots[x].cost > slots[y].cost;
+    });
+    bool fits = true;
+    for (int idx : order) {
+      const auto& s = slots[idx];
+      int best = -1;
+      for (int b = 0; b < wpg; ++b) {
+        if ((int)bins[b].s.size() >= W || bins[b].lds + s.lds > cap) continue;
+        // tables first-fit by LDS left (the emptiest bin), the rest to the bin with the least work
+        if (best < 0 || (s.lds ? bins[b].lds < bins[best].lds : bins[b].cost < bins[best].cost)) best = b;
+      }
+      if (best < 0) { fits = false; break; }
+      bins[best].s.push_back(idx); bins[best].lds += s.lds; bins[best].cost += s.cost;
+    }
+    if (!fits) continue;
+    L.ps_wpg = wpg; L.ps_waves = W;
+    int max_lds = 0;
+    L.ps_slots.assign((size_t)wpg * W, PipeLayout::Slot());
+    L.ps_deps.assign((size_t)wpg * W, {});
+    for (int b = 0; b < wpg; ++b) {
+      // wavefront w runs on SIMD w % 4: the four heaviest units first, then the next four against them
+      std::vector<int> v = bins[b].s;
+      std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return slots[x].cost > slots[y].cost; });
+      std::vector<int> at(W, -1);
+      for (int k = 0; k < (int)v.size(); ++k) {
+        const int round = k / 4, pos = k % 4;
+        const int w = round * 4 + ((round & 1) ? 3 - pos : pos);
+        at[w < W ? w : k] = v[k];
+      }
+      // (W < 8 or a short last round: close the gaps)
+      std::vector<int> seq;
+      for (int w = 0; w < W; ++w) if (at[w] >= 0) seq.push_back(at[w]);
+      int off = (kPersistRoBytes + 255) & ~255;
+      for (int w = 0; w < (int)seq.size(); ++w) {
+        PipeLayout::Slot s = slots[seq[w]];
+        s.lds_off = off; off += s.lds;
+        L.ps_slots[(size_t)b * W + w] = s;
+        L.ps_deps[(size_t)b * W + w] = unit_deps[s.unit];
+      }
+      max_lds = std::max(max_lds, off);
+    }
+    L.ps_lds_bytes = max_lds;
+    L.persist_ok = true;
+    return;
+  }
+  L.persist_why = "the units of a group cannot be packed into workgroups";
+}
+
 bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, std::string& why_not) {
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
@@ -392,6 +521,7 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
   L.off_state = off; off += (uint64_t)L.nstate * G * 4;
   L.group_bytes = (off + 4095) & ~4095ull;
   if (L.group_bytes >= (1ull << 32)) { why_not = "stream buffer of a block group exceeds 4 GiB"; return false; }
+  plan_persistent(plan, L);
   return true;
 }
 
@@ -403,7 +533,8 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
   const CompDesc* comp = plan.comps();
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " (pipelined encoder) -- do not edit\n"
-       "#include \"pipe_kernel.h\"\n"
+       "#define ZPQ_PERSIST_LDS_BYTES " << (L.persist_ok && opt.persist ? L.ps_lds_bytes : 16) << "\n"
+       "#include \"pipe_persist.h\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
   int nmix = 0, nsse = 0;
@@ -460,8 +591,39 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
   arr("MIX_FIRST", mf.data(), (int)mf.size());
   const U8* prog = plan.blob.data() + ph.off_prog;
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
-  o << "};\n"
-       "}  // namespace zpq_gen\n";
+  o << "};\n";
+  if (L.persist_ok && opt.persist) {
+    // the persistent launch: the same chain, its units packed into workgroups (device/pipe_persist.h)
+    std::vector<int> kind, role, sub, unit, ldso, dep0, ndep, du, dl, dm;
+    for (size_t i = 0; i < L.ps_slots.size(); ++i) {
+      const PipeLayout::Slot& sl = L.ps_slots[i];
+      kind.push_back(sl.kind); role.push_back(sl.role); sub.push_back(sl.sub); unit.push_back(sl.unit); ldso.push_back(sl.lds_off);
+      dep0.push_back((int)du.size()); ndep.push_back(sl.kind < 0 ? 0 : (int)L.ps_deps[i].size());
+      if (sl.kind >= 0) for (const PipeLayout::Dep& d : L.ps_deps[i]) { du.push_back(d.unit); dl.push_back(d.lag); dm.push_back(d.mult); }
+    }
+    if (du.empty()) { du.push_back(0); dl.push_back(0); dm.push_back(0); }
+    o << "struct ChainP : Chain {\n"
+         "  static constexpr bool PIPE_PERSIST = true;\n"
+         "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
+      << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";
+    arr("PS_KIND", kind.data(), (int)kind.size());
+    arr("PS_ROLE", role.data(), (int)role.size());
+    arr("PS_SUB", sub.data(), (int)sub.size());
+    arr("PS_UNIT", unit.data(), (int)unit.size());
+    arr("PS_LDS", ldso.data(), (int)ldso.size());
+    arr("PS_DEP0", dep0.data(), (int)dep0.size());
+    arr("PS_NDEP", ndep.data(), (int)ndep.size());
+    arr("PS_DEP_UNIT", du.data(), (int)du.size());
+    arr("PS_DEP_LAG", dl.data(), (int)dl.size());
+    arr("PS_DEP_MULT", dm.data(), (int)dm.size());
+    o << "};\n";
+  }
+  o << "}  // namespace zpq_gen\n";
+  if (L.persist_ok && opt.persist)
+    o << "extern \"C\" __global__ __launch_bounds__(" << 64 * L.ps_waves << ") void zpq_pipe_persist(zpq::PipeArgs a) {\n"
+         "  zpq::pipe_persist_body<zpq_gen::ChainP>(a);\n}\n";
+  else
+    o << "#ifdef ZPQ_EMU\nextern \"C\" void zpq_pipe_persist(zpq::PipeArgs) {}\n#endif\n";     // (the emulator's driver links against the name)
   const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
   for (int k = 0; k < 6; ++k)
     o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << names[k] << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp, light, bit-lane mix: 64)

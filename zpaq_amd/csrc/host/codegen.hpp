@@ -36,6 +36,7 @@ struct PipeOptions {
   int mode = 0;
   int chunk = 0;
   int group = 0;
+  bool persist = true;         // also emit the persistent launch (device/pipe_persist.h) when the chain can be packed
 };
 // The product's variants of a chain's encoder: 0 = throughput shape, 1 = latency shape, 2 = latency shape with steps
 // of 2048 bytes instead of 512.  A step costs a fixed ~0.3 ms of launches and dependencies between the six streams
@@ -69,6 +70,25 @@ struct PipeLayout {
   int mix_bits = 0;            // MIX with a lane per (block, bit position, weight quad): latency mode, when every MIX of the chain allows it
   int light_bits = 4;          // which light units have a lane per (block, bit position): 1 CM | 2 MIX2 | 4 SSE (SSE always: it wins everywhere)
   int depth = 3;               // bytes a bit-lane unit fetches ahead (measured 1..4 on the MI355X: flat, 3 never worse)
+  // ---- the persistent launch (device/pipe_persist.h): the units of a group packed into workgroups that are resident together ----
+  struct Slot {
+    int kind = -1;             // 0 hcomp, 1 row, 2 light, 3 icm, 4 isse, 5 mix (= the six kernels); -1: an idle wavefront
+    int role = 0;              // index in that kernel's role list (rows / light / icm / isse / mix)
+    int sub = 0;               // which wavefront of a unit that has several (MIX lane groups, HCOMP with fewer lanes than a group has blocks)
+    int unit = 0;              // progress counter the wavefront bumps
+    int lds = 0;               // bytes of private LDS (HCOMP: H, ICM / ISSE: the side tables of the group)
+    int lds_off = 0;           // where in the workgroup's LDS
+    float cost = 0;            // relative time per chunk (packing heuristic only)
+  };
+  struct Dep { int unit, lag, mult; };   // wait for progress[unit] >= mult * (chunk + 1 - lag)
+  bool persist_ok = false;
+  std::string persist_why;
+  int ps_waves = 0;            // wavefronts per workgroup
+  int ps_wpg = 0;              // workgroups per group
+  int ps_nunit = 0;
+  int ps_lds_bytes = 0;        // per workgroup: shared tables + the largest flavour's private tables
+  std::vector<Slot> ps_slots;  // ps_wpg * ps_waves, flavour-major
+  std::vector<std::vector<Dep>> ps_deps;   // per slot
   int light_threads() const { return 64; }                                                // workgroup size of the light kernel (bit-lane units: 8 blocks x 8 positions)
   int mix_waves_of(int ql) const { return mix_bits ? G * ql / 8 : ql; }                   // wavefronts per group of one MIX
   int mix_waves_per_group() const { int s = 0; for (int q : mix_ql) s += mix_waves_of(q); return s; }
