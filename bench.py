@@ -576,6 +576,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    persistent = bool(L.zpq_last_persistent()) if a.mode == "encode" else None
     res = d_res.cpu().numpy()[:nb]
     out_len, status = res[:, 0].astype(np.int64), res[:, 2]
     dec_info = None
@@ -728,6 +729,7 @@ def main():
         "ratio": coded_total / (float(nb) * bs) if nb else None,
         "all_status_ok": ok, "roundtrip_verified_blocks": verified,
         "kernel_ms": {"init_arena": init_ms / max(a.steps, 1), "code": code_ms / max(a.steps, 1)},
+        "persistent_launch": persistent,
         "dist_ms": dist_ms or None,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

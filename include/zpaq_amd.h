@@ -206,6 +206,9 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
 /* Durations (ms, hipEvent) of the last timed call on this process: Predictor
  * init kernel and coding kernel(s); blocks = blocks they covered. */
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
+/* 1 when the pipelined encoder of the last timed call ran as persistent launches (one launch per chain for the whole
+ * sequence, device/pipe_persist.h), 0 when it ran step by step (or the call had no pipelined group). */
+int zpq_last_persistent(void);
 /* SHA-1 (libzpaq::SHA1, libzpaq.cpp:106-177) of n buffers ON THE DEVICE, one lane per buffer, 20 bytes each into
  * out20n.  zpq_compress_blocks uses the same kernel for blocks that reach the device unchanged (methods without
  * pre-processing): the digest for the segment trailer is computed beside the coder instead of on a host thread. */

@@ -302,6 +302,8 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
   ZPQ_CATCH
 }
 
+int zpq_last_persistent(void) { return engine_last_persistent() ? 1 : 0; }
+
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks) {
   Timing t = engine_last_timing();
   if (init_ms) *init_ms = t.init_ms;

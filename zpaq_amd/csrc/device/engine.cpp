@@ -310,6 +310,7 @@ void engine_set_kernel(int which) {
   for (Engine& e : g_engines) { std::lock_guard<std::mutex> g(e.mu); e.kernel_choice = which; }
 }
 Timing engine_last_timing() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last; }
+bool engine_last_persistent() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last_persist; }
 
 static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
   zpq_plan* p = const_cast<zpq_plan*>(plan);
@@ -366,7 +367,9 @@ static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32
     if (!strcmp(m, "throughput")) latency = false;
   }
   if (!latency) return 0;
-  const bool long_steps = longest_block >= kLongStepBytes && stream_bytes_per_byte &&
+  // (long steps exist to spread the per-step launch cost; the persistent launch has none and takes the 512-byte shape)
+  const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
+  const bool long_steps = pp && !strcmp(pp, "0") && longest_block >= kLongStepBytes && stream_bytes_per_byte &&
                           (uint64_t)blocks_of_plan * 2048u * stream_bytes_per_byte <= kLongStepStreamBytes;
   return long_steps ? 2 : 1;
 }

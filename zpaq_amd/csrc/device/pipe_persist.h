@@ -89,9 +89,9 @@ __device__ __forceinline__ T* pipe_uniform(T* p) {
 
 // Wait until every unit slot SLOT depends on is far enough for chunk c.  Lane d looks after dependency d.  false: the
 // launch was aborted (by this wavefront's own watchdog or by another's).
-template <class Chain, int SLOT>
-__device__ __forceinline__ bool pipe_wait(const PipeArgs& a, const unsigned* prog, unsigned c, int lane) {
-  constexpr int nd = Chain::PS_NDEP[SLOT], d0 = Chain::PS_DEP0[SLOT];
+template <class Chain>
+__device__ __forceinline__ bool pipe_wait(const PipeArgs& a, const unsigned* prog, unsigned c, int lane, int SLOT) {
+  const int nd = Chain::PS_NDEP[SLOT], d0 = Chain::PS_DEP0[SLOT];
   for (int base = 0; base < nd; base += 64) {
     const int d = base + lane;
     const bool mine = d < nd;
@@ -127,12 +127,14 @@ __device__ __forceinline__ void pipe_publish(unsigned* prog, int unit, int lane)
   if (lane == 0) pipe_prog_add(prog + unit);
 }
 
-// The whole life of one unit wavefront.
-template <class Chain, int SLOT>
-__device__ __attribute__((noinline)) void pipe_persist_slot(const PipeArgs& a, unsigned g, int lane) {
+// The whole life of one unit wavefront: unit type `kind` (0 hcomp, 1 row, 2 light, 3 icm, 4 isse, 5 mix), `role` = which of
+// that type's units (for the code: the wavefronts of a unit that has several -- MIX lane groups, a light unit's bit-lane
+// workgroups -- share ONE function and differ in `sub`, read from the slot tables).
+template <class Chain, int kind, int role>
+__device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, unsigned g, int lane, int SLOT) {
   unsigned char* const lds = ZPQ_PERSIST_LDS(Chain::PS_LDS_BYTES);
   const PipeRO& ro = *(const PipeRO*)lds;
-  constexpr int kind = Chain::PS_KIND[SLOT], role = Chain::PS_ROLE[SLOT], sub = Chain::PS_SUB[SLOT], unit = Chain::PS_UNIT[SLOT];
+  const int sub = Chain::PS_SUB[SLOT], unit = Chain::PS_UNIT[SLOT];
   constexpr unsigned G = Chain::PIPE_G;
   unsigned* const prog = pipe_uniform(a.prog + (unsigned long long)g * (unsigned)Chain::PS_NUNIT);
   const unsigned nchunks = a.group_chunks[g];
@@ -160,7 +162,7 @@ __device__ __attribute__((noinline)) void pipe_persist_slot(const PipeArgs& a, u
     }
   } else if constexpr (kind == 2 && Chain::LIGHT_KIND[role < 0 ? 0 : role] >= PK_CM_BITS) {
     B = (unsigned)lane & 7u;
-    const unsigned gl = (unsigned)Chain::LIGHT_SUB[role] * 8u + ((unsigned)lane >> 3);
+    const unsigned gl = (unsigned)sub * 8u + ((unsigned)lane >> 3);
     L.bind(a, g, gl < G ? gl : 0u, gl < G);
   } else {
     const bool okl = (unsigned)lane < G;
@@ -169,7 +171,7 @@ __device__ __attribute__((noinline)) void pipe_persist_slot(const PipeArgs& a, u
   if (!L.live) L.idle();
   L.gb = pipe_uniform(L.gb);
   for (unsigned c = 0; c < nchunks; ++c) {
-    if (!pipe_wait<Chain, SLOT>(a, prog, c, lane)) return;
+    if (!pipe_wait<Chain>(a, prog, c, lane, SLOT)) return;
     L.at_chunk((int)c);
 #if defined(ZPQ_EMU) && defined(ZPQ_PERSIST_DEBUG)
     if (lane == 0) fprintf(stderr, "[tick %llu] slot %d kind %d role %d unit %d chunk %u nb %u g %u\n", emu::ticks(), SLOT, kind, role, unit, c, L.nb, g);
@@ -228,7 +230,7 @@ __device__ __forceinline__ void pipe_persist_body(const PipeArgs& a) {
   static_for<0, Chain::PS_NSLOT>([&](auto sc) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value;
     if constexpr (Chain::PS_KIND[S] >= 0) {
-      if (slot == S) pipe_persist_slot<Chain, S>(a, g, lane);
+      if (slot == S) pipe_persist_unit<Chain, Chain::PS_KIND[S], Chain::PS_ROLE[S]>(a, g, lane, S);
     }
   });
 }

@@ -333,7 +333,10 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
   for (size_t r = 0; r < L.light.size(); ++r) {
     const int k = L.light[r].first, i = L.light[r].second;
     static const float lc[12] = {0, 0, 0.1f, 0.75f, 0.65f, 0.2f, 0.64f, 1.2f, 0.62f, 0.45f, 0.45f, 0.98f};
-    add(2, (int)r, 0, k == K_CODER ? coder_unit : p_unit[i], 0, lc[k < 12 ? k : 0]);
+    // (the workgroups of a light unit with a lane per bit position share their code: role = the first of them, sub = which eighth of the group)
+    int code_role = (int)r;
+    for (size_t r2 = 0; r2 < r; ++r2) if (L.light[r2] == L.light[r]) { code_role = (int)r2; break; }
+    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], 0, lc[k < 12 ? k : 0]);
   }
   for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 0.45f);
   for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 0.47f);
@@ -533,7 +536,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
   const CompDesc* comp = plan.comps();
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " (pipelined encoder) -- do not edit\n"
-       "#define ZPQ_PERSIST_LDS_BYTES " << (L.persist_ok && opt.persist ? L.ps_lds_bytes : 16) << "\n"
+       "#define ZPQ_PERSIST_LDS_BYTES " << (L.persist_ok && opt.persist && opt.chunk != 2048 ? L.ps_lds_bytes : 16) << "\n"
        "#include \"pipe_persist.h\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
@@ -592,7 +595,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
   const U8* prog = plan.blob.data() + ph.off_prog;
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
   o << "};\n";
-  if (L.persist_ok && opt.persist) {
+  if (L.persist_ok && opt.persist && opt.chunk != 2048) {
     // the persistent launch: the same chain, its units packed into workgroups (device/pipe_persist.h)
     std::vector<int> kind, role, sub, unit, ldso, dep0, ndep, du, dl, dm;
     for (size_t i = 0; i < L.ps_slots.size(); ++i) {
@@ -619,7 +622,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     o << "};\n";
   }
   o << "}  // namespace zpq_gen\n";
-  if (L.persist_ok && opt.persist)
+  if (L.persist_ok && opt.persist && opt.chunk != 2048)
     o << "extern \"C\" __global__ __launch_bounds__(" << 64 * L.ps_waves << ") void zpq_pipe_persist(zpq::PipeArgs a) {\n"
          "  zpq::pipe_persist_body<zpq_gen::ChainP>(a);\n}\n";
   else
