@@ -501,6 +501,7 @@ struct PipeRun {
   // the persistent launch (device/pipe_persist.h)
   uint32_t group_blocks = 0; // blocks per group
   uint32_t ps_wpg = 0, ps_waves = 0, ps_nunit = 0;     // workgroups per group (0: the chain has none), wavefronts per workgroup, counters per group
+  uint32_t ps_nslot = 0;
   std::vector<uint32_t> group_chunks;                  // per group: chunks of its longest block
 };
 
@@ -618,6 +619,17 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
   HIP_CHECK(hipMemcpyAsync(e.pipe_ctl.p, host.data(), words * 4, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));            // (host vector; and nothing else of this call may still occupy compute units)
   const uint32_t timeout = persist_timeout_ticks();
+  // ZPAQ_AMD_PERSIST_PROF=<file>: where every unit wavefront's time went (waiting / working, 100 MHz ticks), first run only
+  const char* prof_path = getenv("ZPAQ_AMD_PERSIST_PROF");
+  unsigned long long* d_prof = nullptr;
+  uint64_t prof_words = 0;
+  uint32_t prof_nslot = 0;
+  if (prof_path && prof_path[0] && !runs.empty()) {
+    prof_nslot = runs[0].ps_nslot;
+    prof_words = 4ull * runs[0].ngroups * prof_nslot;
+    HIP_CHECK(hipMalloc((void**)&d_prof, prof_words * 8));
+    HIP_CHECK(hipMemset(d_prof, 0, prof_words * 8));
+  }
   while (e.side.size() + 1 < runs.size()) {
     hipStream_t s2;
     HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -644,6 +656,7 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
       a.ngroups_here = std::min(per_round, r.ngroups - g0);
       a.timeout_ticks = timeout;
       a.spread = a.ngroups_here >= 8 ? 8u : 1u;
+      a.trace = i == 0 ? d_prof : nullptr;
       const uint32_t grid = a.spread * ((a.ngroups_here + a.spread - 1) / a.spread) * r.ps_wpg;
       void* args[1] = {(void*)&a};
       HIP_CHECK(hipModuleLaunchKernel(r.k->persist, grid, 1, 1, 64u * r.ps_waves, 1, 1, 0, rs, args, nullptr));
@@ -655,6 +668,17 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
     }
   }
   HIP_CHECK(hipStreamSynchronize(st));
+  if (d_prof) {
+    std::vector<unsigned long long> hp(prof_words);
+    HIP_CHECK(hipMemcpy(hp.data(), d_prof, prof_words * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_prof);
+    if (FILE* f = fopen(prof_path, "wb")) {
+      const unsigned long long hdr[4] = {runs[0].ngroups, prof_nslot, runs[0].ps_waves, runs[0].ps_wpg};
+      fwrite(hdr, 8, 4, f);
+      fwrite(hp.data(), 8, prof_words, f);
+      fclose(f);
+    }
+  }
   for (size_t i = 0; i < runs.size(); ++i) {
     uint32_t c[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpy(c, (uint32_t*)e.pipe_ctl.p + base[i], sizeof c, hipMemcpyDeviceToHost));
@@ -813,6 +837,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     r.group_blocks = (uint32_t)L.G;
     if (L.persist_ok && h_jobs) {
       r.ps_wpg = (uint32_t)L.ps_wpg; r.ps_waves = (uint32_t)L.ps_waves; r.ps_nunit = (uint32_t)L.ps_nunit;
+      r.ps_nslot = (uint32_t)L.ps_slots.size();
       r.group_chunks.assign(ng, 1u);
       for (uint32_t b = 0; b < g.count; ++b) {
         const uint32_t len = h_jobs[g.first + b].in_len;

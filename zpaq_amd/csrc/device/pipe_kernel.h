@@ -624,6 +624,22 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
           m = diff ? (unsigned)(__builtin_ctzll(diff) >> 3) : 8u;
         }
         ra = m;
+        // a match that goes on: 16 more bytes per round trip (four 8-byte loads in flight) while neither range wraps -- the
+        // reference's byte loop spends a memory latency per byte, and every lane of the wavefront waits for the one that is in it
+        if (!wraps && !overlap && m == 8u) {
+          for (;;) {
+            if (ra >= 255u) break;
+            const unsigned pa = (rlimit - ra - 16u) & mask, pb = (rlimit - ra - rb - 16u) & mask;
+            if (pa + 16u > mask + 1u || pb + 16u > mask + 1u) break;
+            const unsigned long long a1 = *(g_u64u*)(L.arena + off1 + pa + 8u), b1 = *(g_u64u*)(L.arena + off1 + pb + 8u);
+            const unsigned long long a0 = *(g_u64u*)(L.arena + off1 + pa), b0 = *(g_u64u*)(L.arena + off1 + pb);
+            const unsigned long long d1 = __builtin_bswap64(a1) ^ __builtin_bswap64(b1), d0 = __builtin_bswap64(a0) ^ __builtin_bswap64(b0);
+            if (d1) { ra += (unsigned)(__builtin_ctzll(d1) >> 3); break; }        // (the byte nearest the current position is the first compared)
+            if (d0) { ra += 8u + (unsigned)(__builtin_ctzll(d0) >> 3); break; }
+            ra += 16u;
+          }
+          ra = min(ra, 255u);
+        }
         if (wraps || overlap || m == 8u)
           while (ra < 255 && L.A8(off1 + ((rlimit - ra - 1) & mask)) == L.A8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
       }
@@ -1369,8 +1385,12 @@ __device__ __forceinline__ void pipe_mix_bits_unit(PipeLane<Chain>& L, unsigned 
   constexpr int NQ = (m + 3) / 4, TAIL = m % 4, D = Chain::MIX_DEPTH, HN = D;
   static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "MIX bit lanes need the 8 rows of a byte to be distinct");
   if (!L.nb) return;
-  const bool act = q < (unsigned)NQ;                               // lanes that hold weights
-  const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+  // A row padded to at least 4 words per lane of the group (layout.h mix_row_stride: every m but 2) is loaded and stored
+  // as whole quads by EVERY lane: a quad past the row's end lies in the padding, its inputs read as 0, its words go back as
+  // they came -- no lane is masked, the 8 bits of a byte are straight-line code and the scheduler interleaves them.
+  constexpr bool FULL = c.stride >= 4u * (unsigned)QL;
+  const bool act = FULL || q < (unsigned)NQ;                       // lanes that hold weights
+  const bool tail = !FULL && TAIL != 0 && q == (unsigned)(NQ - 1); // the lane whose quad is cut short by the row's end
   const unsigned qoff = 16u * (act ? q : 0u);
   bool have[4];
   int tin[4];
@@ -1448,8 +1468,9 @@ __device__ __forceinline__ void pipe_mix_bits_unit(PipeLane<Chain>& L, unsigned 
       nw.z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
       nw.w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
       if (on) {
-        if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
-        if constexpr (TAIL != 0) {
+        if constexpr (FULL) *(g_u128a4*)(L.arena + row) = nw;
+        else if (act && !tail) *(g_u128a4*)(L.arena + row) = nw;
+        if constexpr (TAIL != 0 && !FULL) {
           if (tail) {
             L.A32(row) = nw.x;
             if constexpr (TAIL >= 2) L.A32(row + 4u) = nw.y;
@@ -1507,8 +1528,12 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
   static_assert(NQ <= QL, "MIX lane group");
   constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
   if (!L.nb) return;
-  const bool act = q < (unsigned)NQ;                               // lanes that hold weights
-  const bool tail = TAIL != 0 && q == (unsigned)(NQ - 1);          // the lane whose quad is cut short by the row's end
+  // A row padded to at least 4 words per lane of the group (layout.h mix_row_stride: every m but 2) is loaded and stored
+  // as whole quads by EVERY lane: a quad past the row's end lies in the padding, its inputs read as 0, its words go back as
+  // they came -- no lane is masked, the 8 bits of a byte are straight-line code and the scheduler interleaves them.
+  constexpr bool FULL = c.stride >= 4u * (unsigned)QL;
+  const bool act = FULL || q < (unsigned)NQ;                       // lanes that hold weights
+  const bool tail = !FULL && TAIL != 0 && q == (unsigned)(NQ - 1); // the lane whose quad is cut short by the row's end
   const unsigned qoff = 16u * (act ? q : 0u);
   bool have[4];
   int tin[4];
@@ -1577,8 +1602,9 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
       nw[B].y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
       nw[B].z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
       nw[B].w = (unsigned)sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13));
-      if (act && !tail) *(g_u128a4*)(L.arena + row) = nw[B];
-      if constexpr (TAIL != 0) {
+      if constexpr (FULL) *(g_u128a4*)(L.arena + row) = nw[B];
+      else if (act && !tail) *(g_u128a4*)(L.arena + row) = nw[B];
+      if constexpr (TAIL != 0 && !FULL) {
         if (tail) {
           L.A32(row) = nw[B].x;
           if constexpr (TAIL >= 2) L.A32(row + 4u) = nw[B].y;

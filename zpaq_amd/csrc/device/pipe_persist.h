@@ -170,8 +170,11 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
   }
   if (!L.live) L.idle();
   L.gb = pipe_uniform(L.gb);
+  // a.trace (ZPAQ_AMD_PERSIST_PROF=<file>): per (group, slot) four words -- ticks spent waiting, ticks spent working, chunks, slot
+  unsigned long long t_wait = 0, t_work = 0, t_mark = a.trace ? pipe_clock() : 0ull;
   for (unsigned c = 0; c < nchunks; ++c) {
     if (!pipe_wait<Chain>(a, prog, c, lane, SLOT)) return;
+    if (a.trace) { const unsigned long long t = pipe_clock(); t_wait += t - t_mark; t_mark = t; }
     L.at_chunk((int)c);
 #if defined(ZPQ_EMU) && defined(ZPQ_PERSIST_DEBUG)
     if (lane == 0) fprintf(stderr, "[tick %llu] slot %d kind %d role %d unit %d chunk %u nb %u g %u\n", emu::ticks(), SLOT, kind, role, unit, c, L.nb, g);
@@ -207,6 +210,11 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     }
     pipe_reconverge();
     pipe_publish<Chain>(prog, unit, lane);
+    if (a.trace) { const unsigned long long t = pipe_clock(); t_work += t - t_mark; t_mark = t; }
+  }
+  if (a.trace && lane == 0) {
+    unsigned long long* rec = a.trace + 4ull * ((unsigned long long)g * (unsigned)Chain::PS_NSLOT + (unsigned)SLOT);
+    rec[0] = t_wait; rec[1] = t_work; rec[2] = nchunks; rec[3] = ((unsigned long long)kind << 32) | ((unsigned long long)(unsigned)role << 16) | (unsigned)unit;
   }
 }
 

@@ -409,15 +409,15 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
       std::vector<int> at(W, -1);
       for (int k = 0; k < (int)v.size(); ++k) {
         const int round = k / 4, pos = k % 4;
-        const int w = round * 4 + ((round & 1) ? 3 - pos : pos);
-        at[w < W ? w : k] = v[k];
+        int w = round * 4 + ((round & 1) ? 3 - pos : pos);
+        if (w >= W) { w = 0; while (at[w] >= 0) ++w; }
+        at[w] = v[k];
       }
-      // (W < 8 or a short last round: close the gaps)
-      std::vector<int> seq;
-      for (int w = 0; w < W; ++w) if (at[w] >= 0) seq.push_back(at[w]);
+      // (a wavefront without a unit exits at once: the unit that would have shared its SIMD has it to itself)
       int off = (kPersistRoBytes + 255) & ~255;
-      for (int w = 0; w < (int)seq.size(); ++w) {
-        PipeLayout::Slot s = slots[seq[w]];
+      for (int w = 0; w < W; ++w) {
+        if (at[w] < 0) continue;
+        PipeLayout::Slot s = slots[at[w]];
         s.lds_off = off; off += s.lds;
         L.ps_slots[(size_t)b * W + w] = s;
         L.ps_deps[(size_t)b * W + w] = unit_deps[s.unit];
