@@ -287,6 +287,43 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
         _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256, mode=mode)
 
 
+def test_persistent_launch_of_the_pipelined_encoder(zlib_, oracle, golden):
+    """The same units inside ONE launch (device/pipe_persist.h): every workgroup of the grid alive at once in the emulator,
+    the units waiting for each other through their progress counters, streams stored through the write-through accessors,
+    CM / MIX2 tables and the ICM / ISSE side tables resident in LDS from chunk to chunk.  Standard chains in both shapes
+    (several groups, ragged blocks, empty blocks, more chunks than ring slots), the aliasing stress chain, every component
+    type and the legacy models."""
+    blk = corpus.block("text", 1 << 20, corpus.BASE_SEED)
+    h5, _, _ = zlib_.method_to_header(zlib_.expand_method("5", blk))
+    h4, _, _ = zlib_.method_to_header(zlib_.expand_method("4", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65])]
+    assert "zpq_pipe_persist" in emu.pipe_source(h5, 64, mode=0) and "PS_WPG" in emu.pipe_source(h5, 64, mode=1)
+    for mode in (0, 1):
+        _pipe_check(oracle, h5, ragged + [b""], chunk=64, mode=mode, persist=True)
+        _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16, mode=mode, persist=True)
+    # more chunks than ring slots: producers have to wait for their consumers' progress
+    _pipe_check(oracle, h5, [b"\0" + corpus.block("text", 64 * 45 + 7, 3).tobytes(), b"\0" + corpus.block("records", 64 * 30, 4).tobytes()], chunk=64, mode=0, persist=True)
+    header, _ = zlib_.assemble(PIPE_STRESS_CFG)
+    r = np.random.default_rng(1)
+    walk = (np.cumsum(r.integers(-3, 4, 700)) & 255).astype(np.uint8).tobytes()
+    rep = bytes(np.random.default_rng(5).integers(0, 256, 97, dtype=np.uint8)) * 40
+    datas = [walk, corpus.block("text", 600, 5).tobytes(), bytes(500), bytes([7, 7, 8, 8] * 150), rep, b"abcabcabd" * 400]
+    for mode in (0, 1):
+        _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mode=mode, persist=True)
+    seen = set()
+    for e in [golden["config_cases"][0]] + golden["level_cases"]:
+        hdr = bytes.fromhex(e["header"])
+        if hdr in seen or not hdr[6] or hdr[6] > 64:
+            continue
+        seen.add(hdr)
+        d = gen_input(e).tobytes()
+        if len(d) < 64:
+            d = corpus.block("records", 600, 3).tobytes()
+        _pipe_check(oracle, hdr, [b"\0" + d[:500], b"", d[100:230], b"\0"], chunk=64, mode=0, persist=True)
+    assert len(seen) >= 3
+
+
 def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
     """Between two cross-lane operations the emulator may run the lanes of a wavefront in any order; the hardware runs them
     together.  The bit-lane units' lanes meet in memory (the positions of one block share its tables), so they must give

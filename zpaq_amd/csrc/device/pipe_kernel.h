@@ -557,6 +557,79 @@ __device__ __forceinline__ void pipe_cm(PipeLane<Chain>& L, const PipeStretch& s
   }
 }
 
+// CM whose table fits the LDS (persistent launch: the table of the group's blocks lives there as [entry][lane] for the whole
+// sequence; staged from the arena at the first chunk).  A wavefront's LDS operations execute in order, so the next byte's
+// reads follow this byte's writes without any of the forwarding the global version needs.
+template <class Chain, int I, class DT>
+__device__ __forceinline__ void pipe_cm_lds(PipeLane<Chain>& L, unsigned* tab, const PipeStretch& stretch, const DT& dt, int lane, bool load_tab) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I];
+  if (!L.nb) return;
+  if (load_tab)
+    for (unsigned e = 0; e <= c.mask0; e += 4) {
+      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+    }
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    PipeP8 out;
+    unsigned v[8], ix[8];
+#pragma unroll
+    for (int B = 0; B < 8; ++B) { ix[B] = ((h ^ pipe_hmap4(byte, B)) & c.mask0) * G + (unsigned)lane; v[B] = tab[ix[B]]; }
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      if constexpr (c.mask0 < 511u) { if (B) v[B] = tab[ix[B]]; }       // (a table this small: two positions of a byte may share a word)
+      out.set(B, stretch(v[B] >> 17));
+      tab[ix[B]] = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+    }
+    L.put_p(I, k, out.get());
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+  }
+}
+
+// MIX2 whose weights fit the LDS (persistent launch; see pipe_cm_lds)
+template <class Chain, int I, class SQ>
+__device__ __forceinline__ void pipe_mix2_lds(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I];
+  if (!L.nb) return;
+  if (load_tab)
+    for (unsigned e = 0; e <= c.mask0; e += 4) {
+      const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
+      tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
+    }
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  uint4 vj = L.p((int)c.a2, 0), vk = L.p((int)c.a3, 0);
+  uint4 vj1 = L.p((int)c.a2, k1), vk1 = L.p((int)c.a3, k1);
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    const uint4 vj2 = L.p((int)c.a2, k2), vk2 = L.p((int)c.a3, k2);
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned ix = ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0) * G + (unsigned)lane;
+      const int w = (int)tab[ix];
+      const int pj = pipe_p_get(vj, B), pk = pipe_p_get(vk, B);
+      const int pr = (__mul24(w, pj) + __mul24(65536 - w, pk)) >> 16;
+      out.set(B, pr);
+      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
+      tab[ix] = (unsigned)min(max(w + ((__mul24(err, pj - pk) + (1 << 12)) >> 13), 0), 65535);
+    }
+    L.put_p(I, k, out.get());
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+    vj = vj1; vk = vk1; vj1 = vj2; vk1 = vk2;
+  }
+}
+
 // MATCH (libzpaq.cpp:1883-1892, 1985-2008): length / offset / position live in registers.  What update0 reads from
 // memory at the end of a byte -- the index entry of the byte's context, the history behind the candidate it names
 // (compared backwards with the bytes just coded) and the byte the match predicts next -- has addresses that are

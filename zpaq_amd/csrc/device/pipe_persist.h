@@ -74,6 +74,17 @@ __device__ __forceinline__ void pipe_nap() { __builtin_amdgcn_s_sleep(32); }
 __device__ __forceinline__ void pipe_reconverge() {}
 #endif
 
+// Light units whose table lives in the LDS inside the persistent launch: words per block (0: the table stays in the arena).
+// host/codegen.cpp plan_persistent reserves the same amount (x PIPE_G lanes x 4 bytes).
+static const unsigned kPipeLightLdsMaxWords = 512u;
+template <class Chain>
+__device__ __forceinline__ constexpr unsigned pipe_light_lds_words(int lk, int I) {
+  const CompK c = Chain::comp[I];
+  if (lk == PK_CM && c.mask0 + 1u <= kPipeLightLdsMaxWords && c.mask0 >= 3u) return c.mask0 + 1u;
+  if (lk == PK_MIX2 && c.mask0 != 0u && c.mask0 + 1u <= kPipeLightLdsMaxWords && c.mask0 >= 3u) return c.mask0 + 1u;
+  return 0u;
+}
+
 // a pointer every lane holds the same value of, as a value the compiler knows to be wave-uniform (function arguments and
 // what is loaded through them arrive in vector registers; a buffer descriptor built from one would be waterfalled)
 template <class T>
@@ -154,7 +165,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       q = (unsigned)lane % QL; B = pair & 7u;
       L.bind(a, g, pipe_opaque((unsigned)sub * BPW + (pair >> 3)), true);
     } else {
-      constexpr int BPW = (int)G / QL;
+      constexpr int BPW = 64 / QL < (int)G ? 64 / QL : (int)G;       // all 64 lanes: 64 / QL blocks per wavefront
       const unsigned bl = (unsigned)lane / QL;
       q = (unsigned)lane % QL;
       const bool okl = bl < (unsigned)BPW;
@@ -198,10 +209,16 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
         pipe_coder<Chain>(L, a, ro.squash);
       } else if (pipe_any(L.nb > 0)) {
         if constexpr (lk == PK_CONS) pipe_cons<Chain, I>(L);
-        else if constexpr (lk == PK_CM) pipe_cm<Chain, I>(L, ro.stretch, ro.dt);
+        else if constexpr (lk == PK_CM) {
+          if constexpr (pipe_light_lds_words<Chain>(lk, I) != 0u) pipe_cm_lds<Chain, I>(L, (unsigned*)priv, ro.stretch, ro.dt, lane, c == 0);
+          else pipe_cm<Chain, I>(L, ro.stretch, ro.dt);
+        }
         else if constexpr (lk == PK_MATCH) pipe_match<Chain, I>(L, ro.stretch, ro.dt2k);
         else if constexpr (lk == PK_AVG) pipe_avg<Chain, I>(L);
-        else if constexpr (lk == PK_MIX2) pipe_mix2<Chain, I>(L, ro.squash);
+        else if constexpr (lk == PK_MIX2) {
+          if constexpr (pipe_light_lds_words<Chain>(lk, I) != 0u) pipe_mix2_lds<Chain, I>(L, (unsigned*)priv, ro.squash, lane, c == 0);
+          else pipe_mix2<Chain, I>(L, ro.squash);
+        }
         else if constexpr (lk == PK_SSE) pipe_sse<Chain, I>(L, ro.stretch, ro.dt);
         else if constexpr (lk == PK_CM_BITS) pipe_cm_bits<Chain, I>(L, B, ro.stretch, ro.dt);
         else if constexpr (lk == PK_MIX2_BITS) pipe_mix2_bits<Chain, I>(L, B, ro.squash);

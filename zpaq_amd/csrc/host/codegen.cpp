@@ -328,20 +328,28 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
   };
   const int hl = std::min(L.hcomp_lanes, G);
   const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
-  for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.22f);
-  for (size_t r = 0; r < L.rows.size(); ++r) add(1, (int)r, 0, row_unit[L.rows[r]], 0, 0.53f);
+  // relative time per chunk of a unit wavefront inside a full launch (-m5, 1024 blocks, profiles/r05/call5: ms per 2049 chunks / 1000)
+  for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.94f);
+  for (size_t r = 0; r < L.rows.size(); ++r) add(1, (int)r, 0, row_unit[L.rows[r]], 0, 1.8f);
   for (size_t r = 0; r < L.light.size(); ++r) {
     const int k = L.light[r].first, i = L.light[r].second;
-    static const float lc[12] = {0, 0, 0.1f, 0.75f, 0.65f, 0.2f, 0.64f, 1.2f, 0.62f, 0.45f, 0.45f, 0.98f};
+    static const float lc[12] = {0, 0, 0.1f, 2.5f, 3.1f, 0.3f, 1.5f, 2.5f, 1.43f, 0.45f, 0.45f, 0.78f};
     // (the workgroups of a light unit with a lane per bit position share their code: role = the first of them, sub = which eighth of the group)
     int code_role = (int)r;
     for (size_t r2 = 0; r2 < r; ++r2) if (L.light[r2] == L.light[r]) { code_role = (int)r2; break; }
-    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], 0, lc[k < 12 ? k : 0]);
+    // a CM / MIX2 with a table of up to 512 words keeps it in the LDS (device/pipe_persist.h pipe_light_lds_words)
+    int lds = 0;
+    if ((k == K_CM || (k == K_MIX2 && comp[i].mask0 != 0u)) && comp[i].mask0 + 1u <= 512u && comp[i].mask0 >= 3u) lds = (int)(comp[i].mask0 + 1u) * G * 4;
+    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0]);
   }
-  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 0.45f);
-  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 0.47f);
-  for (size_t r = 0; r < L.mix.size(); ++r)
-    for (int sub = 0; sub < L.mix_waves_of(L.mix_ql[r]); ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.4f : 1.1f);
+  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f);
+  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 1.4f);
+  // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
+  //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
+  for (size_t r = 0; r < L.mix.size(); ++r) {
+    const int nw = L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
+    for (int sub = 0; sub < nw; ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.55f : 2.6f);
+  }
   // who reads whose streams
   std::vector<std::vector<int>> producers(nunit);
   auto reads = [&](int u, int v) { if (u != v && std::find(producers[u].begin(), producers[u].end(), v) == producers[u].end()) producers[u].push_back(v); };
@@ -407,11 +415,14 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
       std::vector<int> v = bins[b].s;
       std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return slots[x].cost > slots[y].cost; });
       std::vector<int> at(W, -1);
-      for (int k = 0; k < (int)v.size(); ++k) {
-        const int round = k / 4, pos = k % 4;
-        int w = round * 4 + ((round & 1) ? 3 - pos : pos);
-        if (w >= W) { w = 0; while (at[w] >= 0) ++w; }
-        at[w] = v[k];
+      if (W == 8) {
+        // two wavefronts per SIMD (w and w + 4): the units sorted by cost, the k-th heaviest shares its SIMD with the k-th lightest
+        // (an idle slot counts as the lightest)
+        std::vector<int> padded = v;
+        padded.resize(8, -1);
+        for (int k = 0; k < 4; ++k) { at[k] = padded[k]; at[4 + k] = padded[7 - k]; }
+      } else {
+        for (int k = 0; k < (int)v.size(); ++k) at[k] = v[k];
       }
       // (a wavefront without a unit exits at once: the unit that would have shared its SIMD has it to itself)
       int off = (kPersistRoBytes + 255) & ~255;
