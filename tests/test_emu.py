@@ -282,9 +282,16 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
     # MATCH: long matches, a history buffer (1 KiB here) that wraps, candidates overlapping the byte being written
     rep = bytes(np.random.default_rng(5).integers(0, 256, 97, dtype=np.uint8)) * 40
     more = [rep, corpus.block("text", 1500, 3).tobytes() * 3, bytes(3000), b"abcabcabd" * 400, corpus.block("records", 4000, 8).tobytes()]
+    # ... and blocks that FIT the history buffer (MATCH then reads its history from the input: pipe_match_in): long and
+    # short repeats, runs of one byte from the block's start on (the reference compares with its zero-filled buffer there),
+    # matches that reach back to the first bytes, a match running across chunk boundaries
+    fit = [rep[:1000], bytes(1000), b"abcabcabd" * 100, corpus.block("text", 1000, 3).tobytes(), bytes([0, 0, 0, 5]) * 200,
+           corpus.block("text", 300, 9).tobytes() * 3, b"\1" * 700, bytes(range(40)) * 20]
     for mode in (0, 1):
         _pipe_check(oracle, header, [b"\0" + d for d in datas], chunk=64, mode=mode)
         _pipe_check(oracle, header, [b"\0" + d for d in more], chunk=256, mode=mode)
+        _pipe_check(oracle, header, [b"\0" + d for d in fit], chunk=64, mode=mode)
+    _pipe_check(oracle, header, [b"\0" + d for d in fit] + [d[:1023] for d in fit], chunk=128, mode=0, persist=True)
 
 
 def test_persistent_launch_of_the_pipelined_encoder(zlib_, oracle, golden):

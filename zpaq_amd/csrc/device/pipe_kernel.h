@@ -580,12 +580,24 @@ __device__ __forceinline__ void pipe_cm_lds(PipeLane<Chain>& L, unsigned* tab, c
     PipeP8 out;
     unsigned v[8], ix[8];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) { ix[B] = ((h ^ pipe_hmap4(byte, B)) & c.mask0) * G + (unsigned)lane; v[B] = tab[ix[B]]; }
+    for (int B = 0; B < 8; ++B) ix[B] = ((h ^ pipe_hmap4(byte, B)) & c.mask0) * G + (unsigned)lane;
+    if constexpr (c.mask0 >= 511u) {
+      // the 8 words of a byte are distinct: all reads, then all table lookups, then all writes -- three LDS round trips per
+      // byte instead of three per bit (the compiler cannot move a lookup above a store into the same LDS array by itself)
+      unsigned d[8];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
-      if constexpr (c.mask0 < 511u) { if (B) v[B] = tab[ix[B]]; }       // (a table this small: two positions of a byte may share a word)
-      out.set(B, stretch(v[B] >> 17));
-      tab[ix[B]] = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+      for (int B = 0; B < 8; ++B) v[B] = tab[ix[B]];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) { d[B] = (unsigned)dt[v[B] & 0x3ffu]; out.set(B, stretch(v[B] >> 17)); }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) tab[ix[B]] = pipe_train(v[B], pipe_y(byte, B), d[B], c.limit);
+    } else {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {        // (a table this small: two positions of a byte may share a word)
+        v[B] = tab[ix[B]];
+        out.set(B, stretch(v[B] >> 17));
+        tab[ix[B]] = pipe_train(v[B], pipe_y(byte, B), (unsigned)dt[v[B] & 0x3ffu], c.limit);
+      }
     }
     L.put_p(I, k, out.get());
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
@@ -614,15 +626,34 @@ __device__ __forceinline__ void pipe_mix2_lds(PipeLane<Chain>& L, unsigned* tab,
     const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
     const uint4 vj2 = L.p((int)c.a2, k2), vk2 = L.p((int)c.a3, k2);
     PipeP8 out;
+    if constexpr (c.a5 == 255u && c.mask0 >= 255u) {
+      // the 8 weights of a byte are distinct: reads, squash lookups and writes in three rounds (see pipe_cm_lds)
+      unsigned ix[8];
+      int w[8], pr[8], sq[8];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
-      const unsigned ix = ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0) * G + (unsigned)lane;
-      const int w = (int)tab[ix];
-      const int pj = pipe_p_get(vj, B), pk = pipe_p_get(vk, B);
-      const int pr = (__mul24(w, pj) + __mul24(65536 - w, pk)) >> 16;
-      out.set(B, pr);
-      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
-      tab[ix] = (unsigned)min(max(w + ((__mul24(err, pj - pk) + (1 << 12)) >> 13), 0), 65535);
+      for (int B = 0; B < 8; ++B) { ix[B] = ((h + pipe_c8(byte, B)) & c.mask0) * G + (unsigned)lane; w[B] = (int)tab[ix[B]]; }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        pr[B] = (__mul24(w[B], pipe_p_get(vj, B)) + __mul24(65536 - w[B], pipe_p_get(vk, B))) >> 16;
+        out.set(B, pr[B]);
+        sq[B] = squash(sp_clamp2k(pr[B]));
+      }
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const int err = __mul24(pipe_y(byte, B) * 32767 - sq[B], (int)c.a4) >> 5;
+        tab[ix[B]] = (unsigned)min(max(w[B] + ((__mul24(err, pipe_p_get(vj, B) - pipe_p_get(vk, B)) + (1 << 12)) >> 13), 0), 65535);
+      }
+    } else {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) {
+        const unsigned ix = ((h + (pipe_c8(byte, B) & c.a5)) & c.mask0) * G + (unsigned)lane;
+        const int w = (int)tab[ix];
+        const int pj = pipe_p_get(vj, B), pk = pipe_p_get(vk, B);
+        const int pr = (__mul24(w, pj) + __mul24(65536 - w, pk)) >> 16;
+        out.set(B, pr);
+        const int err = __mul24(pipe_y(byte, B) * 32767 - squash(sp_clamp2k(pr)), (int)c.a4) >> 5;
+        tab[ix] = (unsigned)min(max(w + ((__mul24(err, pj - pk) + (1 << 12)) >> 13), 0), 65535);
+      }
     }
     L.put_p(I, k, out.get());
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
@@ -731,6 +762,167 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
   L.state(sw + 0) = ra; L.state(sw + 1) = rb; L.state(sw + 2) = rlimit;
   L.state(sw + 3) = mpred; L.state(sw + 4) = mdd; L.state(sw + 5) = rc;
   L.state(sw + 6) = (unsigned)hist; L.state(sw + 7) = (unsigned)(hist >> 32);
+}
+
+// MATCH for blocks that fit the component's history buffer (every block compressBlock's methods make: the buffer is at
+// least as long as the block).  The history IS the input -- position p of the buffer holds input byte p -- so everything
+// update0 reads from it (the bytes behind a candidate, the byte a match predicts next) is read from the block's INPUT,
+// which nobody writes: no load ever waits for a store of ours, and every address is known as soon as the index entry is.
+// The unit runs a software pipeline over the bytes.  While byte k is coded,
+//   * the context of byte k + 6 and the index entry of byte k + 4 are requested;
+//   * the entry of byte k + 2 (requested two bytes ago) is final once the entries that bytes k - 2 .. k + 1 store into
+//     the same slot have been forwarded arithmetically (byte j stores j + 1); the 24 bytes behind its candidate, the 4
+//     bytes from the candidate on and 16 older bytes of our own side are requested;
+//   * a running match requests the byte it will predict at the end of byte k + 2;
+// and at the end of byte k everything a new match needs arrived two bytes ago.  The slow paths that remain: candidates
+// within 24 bytes of the block's start (the reference compares with the never-written end of its buffer there: zeros),
+// matches longer than 24 bytes (16 more bytes per round trip), blocks shorter than 24 bytes.  The history buffer in the
+// arena is neither read nor written here; the index table is.  State words: len, distance, -, predicted byte,
+// 2048 / len, last predicted bit, last 8 input bytes (2 words), the 4 bytes from the match's start, bytes since it started.
+template <class Chain, int I, class DT2K>
+__device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStretch& stretch, const DT2K& dt2k) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ci = Chain::P_CTX[I], sw = Chain::P_STATE[I];
+  constexpr unsigned off0 = (unsigned)c.t0;
+  typedef unsigned long long __attribute__((aligned(1))) u64u;
+  typedef __attribute__((address_space(1))) const u64u g_u64u;
+  typedef unsigned __attribute__((aligned(1))) u32u;
+  typedef __attribute__((address_space(1))) const u32u g_u32u;
+  if (!L.nb) return;
+  unsigned ra = 0, rd = 0, mpred = 0, mdd = 0, rc = 0, pwin = 0, age = 0;
+  unsigned long long hist = 0;
+  if (L.chunk > 0) {
+    ra = L.state(sw + 0); rd = L.state(sw + 1); mpred = L.state(sw + 3); mdd = L.state(sw + 4); rc = L.state(sw + 5);
+    hist = (unsigned long long)(unsigned)L.state(sw + 6) | (unsigned long long)(unsigned)L.state(sw + 7) << 32;
+    pwin = L.state(sw + 8); age = L.state(sw + 9);
+  }
+  const unsigned last = L.nb - 1u, len = L.len, n0 = L.k0;
+  const g_u8* const in = L.in;
+  const bool big = len >= 24u;          // (shorter blocks: everything through the slow paths)
+  // input byte i as the reference's buffer holds it: zero before the block's start (its never-written end)
+  auto at = [&](int i) __attribute__((always_inline)) -> unsigned { return i < 0 ? 0u : (unsigned)in[(unsigned)i]; };
+  auto slot_of = [&](unsigned hh) __attribute__((always_inline)) -> unsigned { return off0 + 4u * (hh & c.mask0); };
+  auto ctx_at = [&](unsigned kk) __attribute__((always_inline)) -> unsigned { return L.ctx(ci, min(kk, last)); };
+  struct Cand { unsigned long long a, b1, b0, o1, o0; unsigned pn; };      // candidate bytes -8..-1, -16..-9, -24..-17; ours -15..-8, -23..-16; the 4 bytes from it on
+  // what the end of the byte at absolute index n needs when its candidate is cv (static input; clamped where a window
+  // would leave the block -- the clamped cases take the slow path and do not look at it)
+  auto fetch = [&](unsigned n, unsigned cv) __attribute__((always_inline)) -> Cand {
+    Cand r;
+    if (!big) { r.a = r.b1 = r.b0 = r.o1 = r.o0 = 0ull; r.pn = 0u; return r; }
+    const unsigned base = min(cv >= 24u ? cv : 24u, len), nn = min(n >= 23u ? n : 23u, len - 1u);      // (requests for the bytes past the block's end stay inside it)
+    r.a = *(g_u64u*)(in + (base - 8u));
+    r.b1 = *(g_u64u*)(in + (base - 16u));
+    r.b0 = *(g_u64u*)(in + (base - 24u));
+    r.o1 = *(g_u64u*)(in + (nn - 15u));
+    r.o0 = *(g_u64u*)(in + (nn - 23u));
+    const unsigned pa = min(cv, len - 4u);
+    r.pn = (unsigned)*(g_u32u*)(in + pa) >> (8u * (cv - pa));
+    return r;
+  };
+  // ---- prime the pipeline for the chunk's first bytes (everything earlier chunks stored is long done)
+  unsigned h4 = ctx_at(4), h5 = ctx_at(5);
+  unsigned em2 = 0xFFFFFFFFu, em1 = 0xFFFFFFFFu;                               // slots of the two bytes before byte k (their stores: n - 1, n)
+  unsigned e0 = slot_of(ctx_at(0)), e1 = slot_of(ctx_at(1)), e2 = slot_of(ctx_at(2)), e3 = slot_of(ctx_at(3));
+  unsigned b0 = L.byte_at(0), b1 = L.byte_at(min(1u, last));
+  const unsigned r0 = L.A32(e0), r1 = L.A32(e1);
+  unsigned ri2 = L.A32(e2), ri3 = L.A32(e3);                                   // raw entries of bytes k + 2, k + 3
+  unsigned cm0 = r0, cm1 = e1 == e0 ? n0 + 1u : r1;                            // final candidates of bytes k, k + 1
+  Cand c0 = fetch(n0, cm0), c1 = fetch(n0 + 1u, cm1);
+  unsigned sp0 = 0, sp1 = 0;                                                   // a running match's predicted byte for the end of bytes k, k + 1
+  if (ra != 0u) { sp0 = at((int)min(n0 + 1u - rd, len - 1u)); sp1 = at((int)min(n0 + 2u - rd, len - 1u)); }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned n = n0 + k, n1 = n + 1u;
+    const unsigned byte = b0;
+    // ---- requests for the bytes ahead
+    const unsigned h6 = ctx_at(k + 6u);
+    const unsigned b2 = L.byte_at(min(k + 2u, last));
+    const unsigned e4 = slot_of(h4);
+    const unsigned ri4 = L.A32(e4);
+    unsigned cm2 = ri2;                                                        // byte k + 2's candidate: the youngest store into its slot wins
+    cm2 = e2 == em2 ? n - 1u : cm2;
+    cm2 = e2 == em1 ? n : cm2;
+    cm2 = e2 == e0 ? n + 1u : cm2;
+    cm2 = e2 == e1 ? n + 2u : cm2;
+    const Cand c2 = fetch(n + 2u, cm2);
+    const unsigned sp2 = ra != 0u ? at((int)min(n + 3u - rd, len - 1u)) : 0u;
+    // ---- the byte's 8 bits (libzpaq.cpp:1883-1892, 1985-1990)
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const bool on = ra != 0;
+      rc = on ? ((mpred >> (7 - B)) & 1u) : rc;
+      const unsigned sx = on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;     // stretch(16384) = 0: "p[i]=0"
+      out.set(B, stretch(sx));
+      ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
+    }
+    L.put_p(I, k, out.get());
+    hist = hist << 8 | byte;
+    // ---- end of the byte (libzpaq.cpp:1991-2008)
+    bool fresh = false;
+    if (ra == 0u) {
+      const unsigned cv = cm0;
+      rd = n1 - cv;                                                            // (never 0: no earlier byte can have stored n + 1)
+      const bool fast = big && cv >= 24u;
+      unsigned m = 0;
+      if (fast) {
+        const unsigned long long d = __builtin_bswap64(c0.a) ^ hist;
+        m = d ? (unsigned)(__builtin_ctzll(d) >> 3) : 8u;
+        if (m == 8u) {
+          const unsigned long long d1 = __builtin_bswap64(c0.b1) ^ __builtin_bswap64(c0.o1);
+          if (d1) m = 8u + (unsigned)(__builtin_ctzll(d1) >> 3);
+          else {
+            const unsigned long long d0 = __builtin_bswap64(c0.b0) ^ __builtin_bswap64(c0.o0);
+            m = d0 ? 16u + (unsigned)(__builtin_ctzll(d0) >> 3) : 24u;
+          }
+        }
+      }
+      ra = m;
+      if (fast && m == 24u) {
+        for (;;) {             // a longer match: 16 bytes per round trip while the candidate's side stays inside the block
+          if (ra >= 255u || cv < ra + 16u) break;
+          const unsigned long long a1 = *(g_u64u*)(in + (n1 - ra - 8u)), x1 = *(g_u64u*)(in + (cv - ra - 8u));
+          const unsigned long long a0 = *(g_u64u*)(in + (n1 - ra - 16u)), x0 = *(g_u64u*)(in + (cv - ra - 16u));
+          const unsigned long long d1 = __builtin_bswap64(a1) ^ __builtin_bswap64(x1), d0 = __builtin_bswap64(a0) ^ __builtin_bswap64(x0);
+          if (d1) { ra += (unsigned)(__builtin_ctzll(d1) >> 3); break; }
+          if (d0) { ra += 8u + (unsigned)(__builtin_ctzll(d0) >> 3); break; }
+          ra += 16u;
+        }
+        ra = min(ra, 255u);
+      }
+      if (!fast || (m == 24u && ra < 255u && cv < ra + 16u))
+        while (ra < 255u && at((int)(n1 - ra - 1u)) == at((int)cv - (int)ra - 1)) ++ra;
+      fresh = true;
+    } else ra += ra < 255u;
+    L.A32(e0) = n1;
+    if (ra != 0u) {
+      if (fresh) { pwin = big ? c0.pn : 0u; age = 0u; }
+      // the byte the match predicts next, in[n1 - rd]: from the window behind the candidate while the match is young, from the
+      // request made two bytes ago afterwards
+      mpred = !big ? at((int)min(n1 - rd, len - 1u)) : (age < 4u ? (pwin >> (8u * age)) & 255u : sp0);
+      mdd = dt2k[ra];
+      age += age < 255u;
+    }
+    // ---- the pipeline moves on by one byte
+    em2 = em1; em1 = e0; e0 = e1; e1 = e2; e2 = e3; e3 = e4;
+    ri2 = ri3; ri3 = ri4;
+    h4 = h5; h5 = h6;
+    cm0 = cm1; cm1 = cm2;
+    c0 = c1; c1 = c2;
+    sp0 = sp1; sp1 = sp2;
+    b0 = b1; b1 = b2;
+  }
+  L.state(sw + 0) = ra; L.state(sw + 1) = rd; L.state(sw + 3) = mpred; L.state(sw + 4) = mdd; L.state(sw + 5) = rc;
+  L.state(sw + 6) = (unsigned)hist; L.state(sw + 7) = (unsigned)(hist >> 32);
+  L.state(sw + 8) = pwin; L.state(sw + 9) = age;
+}
+
+// the MATCH unit: from the input when every block of the wavefront fits the history buffer (a property of the blocks'
+// lengths: the same choice at every chunk), through the buffer in the arena otherwise
+template <class Chain, int I, class DT2K>
+__device__ __forceinline__ void pipe_match_any(PipeLane<Chain>& L, const PipeStretch& stretch, const DT2K& dt2k) {
+  constexpr CompK c = Chain::comp[I];
+  if (pipe_any(L.live && L.len > c.mask1 + 1u)) pipe_match<Chain, I>(L, stretch, dt2k);
+  else pipe_match_in<Chain, I>(L, stretch, dt2k);
 }
 
 // AVG (libzpaq.cpp:1894-1896)
@@ -1263,7 +1455,7 @@ __device__ __forceinline__ void pipe_light_body(const PipeArgs& a) {
       for (int i = lane; i < 256; i += (int)blockDim.x) dt2k[i] = (unsigned short)a.tb->dt2k[i];
       stretch.load(a.tb, lane);
       __syncthreads();
-      pipe_match<Chain, I>(L, stretch, dt2k);
+      pipe_match_any<Chain, I>(L, stretch, dt2k);
     } else if constexpr (kind == PK_AVG) {
       pipe_avg<Chain, I>(L);
     } else if constexpr (kind == PK_MIX2) {

@@ -213,7 +213,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
           if constexpr (pipe_light_lds_words<Chain>(lk, I) != 0u) pipe_cm_lds<Chain, I>(L, (unsigned*)priv, ro.stretch, ro.dt, lane, c == 0);
           else pipe_cm<Chain, I>(L, ro.stretch, ro.dt);
         }
-        else if constexpr (lk == PK_MATCH) pipe_match<Chain, I>(L, ro.stretch, ro.dt2k);
+        else if constexpr (lk == PK_MATCH) pipe_match_any<Chain, I>(L, ro.stretch, ro.dt2k);
         else if constexpr (lk == PK_AVG) pipe_avg<Chain, I>(L);
         else if constexpr (lk == PK_MIX2) {
           if constexpr (pipe_light_lds_words<Chain>(lk, I) != 0u) pipe_mix2_lds<Chain, I>(L, (unsigned*)priv, ro.squash, lane, c == 0);

@@ -469,7 +469,7 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
     switch (c.type) {
       case C_CONS: light_unit(K_CONS, K_CM_BITS, false, i); break;
       case C_CM: L.ctx[i] = L.nctx++; light_unit(K_CM, K_CM_BITS, c.mask0 >= 511u, i); break;
-      case C_MATCH: L.ctx[i] = L.nctx++; L.state[i] = L.nstate; L.nstate += 8; light_unit(K_MATCH, K_CM_BITS, false, i); break;
+      case C_MATCH: L.ctx[i] = L.nctx++; L.state[i] = L.nstate; L.nstate += 12; light_unit(K_MATCH, K_CM_BITS, false, i); break;
       case C_ICM: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = 2; L.icm.push_back(i); break;
       case C_ISSE: L.ctx[i] = L.nctx++; L.row[i] = L.nrow++; lv = std::max(2, L.level[c.a2] + 1); L.isse.push_back(i); break;
       case C_AVG: lv = std::max(L.level[c.a1], L.level[c.a2]) + 1; light_unit(K_AVG, K_CM_BITS, false, i); break;
