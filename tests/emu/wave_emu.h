@@ -41,6 +41,7 @@ struct uint4 { unsigned x, y, z, w; };
 struct int2 { int x, y; };
 struct uint2 { unsigned x, y; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }

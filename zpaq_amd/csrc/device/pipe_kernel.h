@@ -243,6 +243,9 @@ struct PipeLane {
   __device__ __forceinline__ void put_p(int i, unsigned k, const uint4& v) const {
     if constexpr (WT) pipe_wt_store16(gb, off_p(i, k), v); else p(i, k) = v;
   }
+  __device__ __forceinline__ void put_p64(int i, unsigned k, unsigned half, const uint2& v) const {      // bits 0 .. 3 or 4 .. 7 of the element
+    if constexpr (WT) pipe_wt_store8(gb, off_p(i, k) + 8u * half, v); else *(g_u64v*)((g_u8*)&p(i, k) + 8u * half) = v;
+  }
   __device__ __forceinline__ void put_p16(int i, unsigned k, unsigned B, int v) const {      // one bit position's half-word
     if constexpr (WT) pipe_wt_store2(gb, off_p(i, k) + 2u * B, (unsigned)v & 0xFFFFu); else *(g_i16*)((g_u8*)&p(i, k) + 2u * B) = (short)v;
   }
@@ -690,6 +693,7 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
   const unsigned k1 = L.next(0);
   unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
   unsigned cmv = L.A32(off0 + 4u * (h & c.mask0));
+  int st_pos = stretch(mdd & 32767u), st_neg = stretch((0u - mdd) & 32767u);
   for (unsigned k = 0; k < L.nb; ++k) {
     const unsigned k2 = min(k + 2u, L.nb - 1u);
     const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
@@ -701,13 +705,14 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
     const unsigned long long cand = *(g_u64u*)(L.arena + off1 + (wraps ? 0u : cpos));
     const unsigned at_cand = L.A8(off1 + (cmv & mask));
     const unsigned at_cont = L.A8(off1 + ((rlimit + 1u - rb) & mask));
+    // (the prediction is one of three values for the whole byte -- stretch(+-2048 / len) or 0 -- looked up when the length changes,
+    //  not once per bit: the bit loop is a select and a compare)
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
       const bool on = ra != 0;
       rc = on ? ((mpred >> (7 - B)) & 1u) : rc;
-      const unsigned sx = on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;     // stretch(16384) = 0: "p[i]=0"
-      out.set(B, stretch(sx));
+      out.set(B, on ? (rc ? st_neg : st_pos) : 0);                            // stretch(16384) = 0: "p[i]=0"
       ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
     }
     L.put_p(I, k, out.get());
@@ -755,6 +760,7 @@ __device__ __forceinline__ void pipe_match(PipeLane<Chain>& L, const PipeStretch
       const unsigned early = fresh ? at_cand : at_cont;
       mpred = ppos == wpos ? byte : early;
       mdd = dt2k[ra];
+      st_pos = stretch(mdd & 32767u); st_neg = stretch((0u - mdd) & 32767u);
     }
     cmv = eon == eo ? rlimit : cmvn_mem;
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
@@ -806,17 +812,20 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
   struct Cand { unsigned long long a, b1, b0, o1, o0; unsigned pn; };      // candidate bytes -8..-1, -16..-9, -24..-17; ours -15..-8, -23..-16; the 4 bytes from it on
   // what the end of the byte at absolute index n needs when its candidate is cv (static input; clamped where a window
   // would leave the block -- the clamped cases take the slow path and do not look at it)
+  // (no branch around a request: where a conditional load joins the main path the compiler waits for it -- the youngest
+  //  request -- and with it for everything requested ahead; a block too short for the windows reads its arena instead)
+  const g_u8* const src = big ? in : (const g_u8*)L.arena;
+  const unsigned lim = big ? len : 64u;
   auto fetch = [&](unsigned n, unsigned cv) __attribute__((always_inline)) -> Cand {
     Cand r;
-    if (!big) { r.a = r.b1 = r.b0 = r.o1 = r.o0 = 0ull; r.pn = 0u; return r; }
-    const unsigned base = min(cv >= 24u ? cv : 24u, len), nn = min(n >= 23u ? n : 23u, len - 1u);      // (requests for the bytes past the block's end stay inside it)
-    r.a = *(g_u64u*)(in + (base - 8u));
-    r.b1 = *(g_u64u*)(in + (base - 16u));
-    r.b0 = *(g_u64u*)(in + (base - 24u));
-    r.o1 = *(g_u64u*)(in + (nn - 15u));
-    r.o0 = *(g_u64u*)(in + (nn - 23u));
-    const unsigned pa = min(cv, len - 4u);
-    r.pn = (unsigned)*(g_u32u*)(in + pa) >> (8u * (cv - pa));
+    const unsigned base = min(cv >= 24u ? cv : 24u, lim), nn = min(n >= 23u ? n : 23u, lim - 1u);      // (requests for the bytes past the block's end stay inside it)
+    r.a = *(g_u64u*)(src + (base - 8u));
+    r.b1 = *(g_u64u*)(src + (base - 16u));
+    r.b0 = *(g_u64u*)(src + (base - 24u));
+    r.o1 = *(g_u64u*)(src + (nn - 15u));
+    r.o0 = *(g_u64u*)(src + (nn - 23u));
+    const unsigned pa = min(cv, lim - 4u);
+    r.pn = (unsigned)*(g_u32u*)(src + pa) >> (8u * min(cv - pa, 3u));
     return r;
   };
   // ---- prime the pipeline for the chunk's first bytes (everything earlier chunks stored is long done)
@@ -828,6 +837,7 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
   unsigned ri2 = L.A32(e2), ri3 = L.A32(e3);                                   // raw entries of bytes k + 2, k + 3
   unsigned cm0 = r0, cm1 = e1 == e0 ? n0 + 1u : r1;                            // final candidates of bytes k, k + 1
   Cand c0 = fetch(n0, cm0), c1 = fetch(n0 + 1u, cm1);
+  int st_pos = stretch(mdd & 32767u), st_neg = stretch((0u - mdd) & 32767u);
   unsigned sp0 = 0, sp1 = 0;                                                   // a running match's predicted byte for the end of bytes k, k + 1
   if (ra != 0u) { sp0 = at((int)min(n0 + 1u - rd, len - 1u)); sp1 = at((int)min(n0 + 2u - rd, len - 1u)); }
   for (unsigned k = 0; k < L.nb; ++k) {
@@ -844,15 +854,16 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
     cm2 = e2 == e0 ? n + 1u : cm2;
     cm2 = e2 == e1 ? n + 2u : cm2;
     const Cand c2 = fetch(n + 2u, cm2);
-    const unsigned sp2 = ra != 0u ? at((int)min(n + 3u - rd, len - 1u)) : 0u;
+    const unsigned sp2 = (unsigned)src[min(n + 3u - rd, lim - 1u)];                  // (meaningful while a match runs; rd <= n)
     // ---- the byte's 8 bits (libzpaq.cpp:1883-1892, 1985-1990)
+    // (the prediction is one of three values for the whole byte -- stretch(+-2048 / len) or 0 -- looked up when the length changes,
+    //  not once per bit: the bit loop is a select and a compare)
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
       const bool on = ra != 0;
       rc = on ? ((mpred >> (7 - B)) & 1u) : rc;
-      const unsigned sx = on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;     // stretch(16384) = 0: "p[i]=0"
-      out.set(B, stretch(sx));
+      out.set(B, on ? (rc ? st_neg : st_pos) : 0);                            // stretch(16384) = 0: "p[i]=0"
       ra = ((int)rc != pipe_y(byte, B)) ? 0u : ra;
     }
     L.put_p(I, k, out.get());
@@ -862,16 +873,18 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
     if (ra == 0u) {
       const unsigned cv = cm0;
       rd = n1 - cv;                                                            // (never 0: no earlier byte can have stored n + 1)
-      const bool fast = big && cv >= 24u;
+      // candidate 0 = a context never seen before (the index table starts zeroed): the reference compares with the zeros
+      // at the end of its buffer -- by far the most frequent case besides a real candidate, and it needs no load at all
+      const bool fast = big && cv >= 24u, zero = big && cv == 0u && n >= 23u;
       unsigned m = 0;
-      if (fast) {
-        const unsigned long long d = __builtin_bswap64(c0.a) ^ hist;
+      if (fast || zero) {
+        const unsigned long long d = (zero ? 0ull : __builtin_bswap64(c0.a)) ^ hist;
         m = d ? (unsigned)(__builtin_ctzll(d) >> 3) : 8u;
         if (m == 8u) {
-          const unsigned long long d1 = __builtin_bswap64(c0.b1) ^ __builtin_bswap64(c0.o1);
+          const unsigned long long d1 = (zero ? 0ull : __builtin_bswap64(c0.b1)) ^ __builtin_bswap64(c0.o1);
           if (d1) m = 8u + (unsigned)(__builtin_ctzll(d1) >> 3);
           else {
-            const unsigned long long d0 = __builtin_bswap64(c0.b0) ^ __builtin_bswap64(c0.o0);
+            const unsigned long long d0 = (zero ? 0ull : __builtin_bswap64(c0.b0)) ^ __builtin_bswap64(c0.o0);
             m = d0 ? 16u + (unsigned)(__builtin_ctzll(d0) >> 3) : 24u;
           }
         }
@@ -889,7 +902,7 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
         }
         ra = min(ra, 255u);
       }
-      if (!fast || (m == 24u && ra < 255u && cv < ra + 16u))
+      if ((!fast && !zero) || (m == 24u && ra < 255u && (zero || cv < ra + 16u)))
         while (ra < 255u && at((int)(n1 - ra - 1u)) == at((int)cv - (int)ra - 1)) ++ra;
       fresh = true;
     } else ra += ra < 255u;
@@ -900,6 +913,7 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
       // request made two bytes ago afterwards
       mpred = !big ? at((int)min(n1 - rd, len - 1u)) : (age < 4u ? (pwin >> (8u * age)) & 255u : sp0);
       mdd = dt2k[ra];
+      st_pos = stretch(mdd & 32767u); st_neg = stretch((0u - mdd) & 32767u);
       age += age < 255u;
     }
     // ---- the pipeline moves on by one byte
@@ -1350,12 +1364,14 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
           seg_end = segs[seg].in_end;
         }
       }
+      // (the 8 probabilities first: their table lookups do not depend on the coder's state, and behind the data-dependent
+      //  loops of encode() the compiler would leave each where it is used)
+      unsigned prs[8];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) prs[B] = (unsigned)squash(sp_clamp2k(pipe_p_get(v, B))) * 2u + 1u;
       encode(0, 0);
 #pragma unroll
-      for (int B = 0; B < 8; ++B) {
-        const int pr = squash(sp_clamp2k(pipe_p_get(v, B)));
-        encode(pipe_y(byte, B), (unsigned)pr * 2u + 1u);
-      }
+      for (int B = 0; B < 8; ++B) encode(pipe_y(byte, B), prs[B]);
       byte = byten; v = vn;
     }
   }
@@ -1783,15 +1799,20 @@ __device__ __forceinline__ void pipe_mix_bits_body(const PipeArgs& a) {
   });
 }
 
-// one chunk of MIX role r with QL lanes per block: q = the lane's weight quad
-template <class Chain, int r, class SQ>
-__device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, const SQ& squash) {
+// one chunk of MIX role r with QL lanes per block and byte PART: q = the lane's weight quad.  NH = 1: a lane group codes all 8
+// bits of its block's byte.  NH = 2 (the persistent launch's throughput shape): two lane groups per block, `half` 0 codes bits
+// 0 .. 3 and half 1 bits 4 .. 7 -- with all bits known the positions of a byte are independent for a mixer whose row index
+// contains the bit position (see pipe_mix_bits_unit), so the per-byte chain is half as long for twice the wavefronts; both
+// halves of a block sit in ONE wavefront, so a row another half wrote is ordered by the wavefront's instruction order.
+template <class Chain, int r, int NH, class SQ>
+__device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, unsigned half, const SQ& squash) {
   constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r];
   constexpr CompK c = Chain::comp[I];
   constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-  constexpr int NQ = (m + 3) / 4, TAIL = m % 4;
+  constexpr int NQ = (m + 3) / 4, TAIL = m % 4, NB = 8 / NH;
   static_assert(NQ <= QL, "MIX lane group");
   constexpr bool batch = c.a5 == 255u && c.mask0 >= 255u;      // the 8 rows of a byte are distinct
+  static_assert(NH == 1 || (NH == 2 && batch), "a byte is split over lane groups only when its 8 rows are distinct");
   if (!L.nb) return;
   // A row padded to at least 4 words per lane of the group (layout.h mix_row_stride: every m but 2) is loaded and stored
   // as whole quads by EVERY lane: a quad past the row's end lies in the padding, its inputs read as 0, its words go back as
@@ -1808,28 +1829,39 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
     have[x] = t < m;
     tin[x] = J + (have[x] ? t : 0);
   }
-  auto row_of = [&](unsigned hh, unsigned bytev, int B) __attribute__((always_inline)) -> unsigned {
-    return (unsigned)c.t0 + 4u * __umul24((hh + (pipe_c8(bytev, B) & c.a5)) & c.mask0, (unsigned)c.stride) + qoff;   // s <= 24
+  // bit b of this lane's part of the byte: its c8 and its value
+  auto c8_of = [&](unsigned bytev, int b) __attribute__((always_inline)) -> unsigned {
+    if constexpr (NH == 1) return pipe_c8(bytev, b);
+    else return ((half ? 16u : 1u) << b) | ((half ? bytev : bytev >> 4) >> (4 - b));
+  };
+  auto y_of = [&](unsigned bytev, int b) __attribute__((always_inline)) -> int {
+    if constexpr (NH == 1) return pipe_y(bytev, b);
+    else return (int)(((half ? bytev : bytev >> 4) >> (3 - b)) & 1u);
+  };
+  auto row_of = [&](unsigned hh, unsigned bytev, int b) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)c.t0 + 4u * __umul24((hh + (c8_of(bytev, b) & c.a5)) & c.mask0, (unsigned)c.stride) + qoff;   // s <= 24
   };
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
   const unsigned k1 = L.next(0);
   unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
-  // inputs of the weights a lane does not have read as 0 (masked once per byte, not once per bit)
+  // inputs of the weights a lane does not have read as 0 (masked once per byte, not once per bit); NH = 2: the two words
+  // of the lane's half in .x / .y
   auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
     const uint4 v = L.p(tin[x], kk);
     const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
-    return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+    if constexpr (NH == 1) return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+    else return make_uint4((half ? v.z : v.x) & mk, (half ? v.w : v.y) & mk, 0u, 0u);
   };
   uint4 pv[4], pv1[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) { pv[x] = inputs(x, 0); pv1[x] = inputs(x, k1); }
-  uint4 w[8];
-  unsigned rowc[8];
+  uint4 w[NB];
+  unsigned rowc[NB];
 #pragma unroll
-  for (int B = 0; B < 8; ++B) rowc[B] = row_of(h, byte, B);
+  for (int B = 0; B < NB; ++B) rowc[B] = row_of(h, byte, B);
   if constexpr (batch) {
 #pragma unroll
-    for (int B = 0; B < 8; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
+    for (int B = 0; B < NB; ++B) w[B] = *(g_u128a4*)(L.arena + rowc[B]);
   }
   for (unsigned k = 0; k < L.nb; ++k) {
     const unsigned k2 = min(k + 2u, L.nb - 1u);
@@ -1837,23 +1869,23 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
     uint4 pv2[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
-    unsigned rown[8];
+    unsigned rown[NB];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
+    for (int B = 0; B < NB; ++B) rown[B] = row_of(h1, byte1, B);
     // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint),
     // forwarded below; contexts less than 256 apart -> any position may coincide: fetched after the stores
     const bool same = h1 == h;
     const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
-    uint4 wn[8], nw[8];
+    uint4 wn[NB], nw[NB];
     if constexpr (batch) {
       if (!late) {
 #pragma unroll
-        for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
+        for (int B = 0; B < NB; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
       }
     }
     PipeP8 out;
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
+    for (int B = 0; B < NB; ++B) {
       const unsigned row = rowc[B];
       if constexpr (!batch) w[B] = *(g_u128a4*)(L.arena + row);
       const int w0 = (int)w[B].x, w1 = (int)w[B].y, w2 = (int)w[B].z, w3 = (int)w[B].w;
@@ -1862,7 +1894,7 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
       const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
       const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
       out.set(B, pr);
-      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
+      const int err = __mul24(y_of(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
       nw[B].x = (unsigned)sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13));
       nw[B].y = (unsigned)sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13));
       nw[B].z = (unsigned)sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13));
@@ -1877,14 +1909,20 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
         }
       }
     }
-    if (q == 0) L.put_p(I, k, out.get());
+    if (q == 0) {
+      if constexpr (NH == 1) L.put_p(I, k, out.get());
+      else L.put_p64(I, k, half, make_uint2(out.w[0], out.w[1]));
+    }
     if constexpr (batch) {
+      if constexpr (NH == 2) {
+        if (pipe_any(late)) pipe_stores_done();       // (the other half's stores of this byte: ordered before the re-fetch)
+      }
       if (late) {
 #pragma unroll
-        for (int B = 0; B < 8; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
+        for (int B = 0; B < NB; ++B) wn[B] = *(g_u128a4*)(L.arena + rown[B]);
       }
 #pragma unroll
-      for (int B = 0; B < 8; ++B) {
+      for (int B = 0; B < NB; ++B) {
         // (the tail lane's words past the row's end are never used: their inputs are 0 and they are not stored)
         const bool fw = same && rown[B] == rowc[B];
         w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y;
@@ -1893,7 +1931,7 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, co
     }
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
 #pragma unroll
-    for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
+    for (int B = 0; B < NB; ++B) rowc[B] = rown[B];
 #pragma unroll
     for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
   }
@@ -1925,7 +1963,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
     if (bl >= (unsigned)BPW) { L.live = false; L.nb = 0; }          // lanes beyond this wavefront's blocks
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-    pipe_mix_unit<Chain, r>(L, q, squash);
+    pipe_mix_unit<Chain, r, 1>(L, q, 0u, squash);
   });
   }
 }

@@ -165,9 +165,10 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       q = (unsigned)lane % QL; B = pair & 7u;
       L.bind(a, g, pipe_opaque((unsigned)sub * BPW + (pair >> 3)), true);
     } else {
-      constexpr int BPW = 64 / QL < (int)G ? 64 / QL : (int)G;       // all 64 lanes: 64 / QL blocks per wavefront
-      const unsigned bl = (unsigned)lane / QL;
-      q = (unsigned)lane % QL;
+      constexpr int NH = Chain::PS_MIX_NH;                           // lane groups per block: 2 = one for bits 0 .. 3, one for bits 4 .. 7
+      constexpr int BPW = 64 / (QL * NH) < (int)G ? 64 / (QL * NH) : (int)G;       // all 64 lanes: 64 / (QL NH) blocks per wavefront
+      const unsigned bl = (unsigned)lane / (QL * NH);
+      q = (unsigned)lane % QL; B = ((unsigned)lane / QL) % NH;       // (B: the half)
       const bool okl = bl < (unsigned)BPW;
       L.bind(a, g, (unsigned)sub * BPW + (okl ? bl : 0u), okl);
     }
@@ -201,7 +202,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     } else if constexpr (kind == 5) {
       if (pipe_any(L.nb > 0)) {
         if constexpr (Chain::MIX_BITS != 0) pipe_mix_bits_unit<Chain, role>(L, q, B, ro.squash);
-        else pipe_mix_unit<Chain, role>(L, q, ro.squash);
+        else pipe_mix_unit<Chain, role, Chain::PS_MIX_NH>(L, q, B, ro.squash);
       }
     } else {
       constexpr int lk = Chain::LIGHT_KIND[role], I = Chain::LIGHT_COMP[role];

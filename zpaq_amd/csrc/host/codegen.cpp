@@ -346,9 +346,22 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
   for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 1.4f);
   // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
   //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
+  // throughput shape: a MIX whose 8 rows of a byte are distinct splits the byte over two lane groups (device: pipe_mix_unit NH = 2)
+  L.ps_mix_nh = 1;
+  // (measured on the MI355X, profiles/r05/call12: no faster than one lane group per block -- at 1024 blocks the MIX units wait
+  //  for their rows, not for their own instructions -- and 8 more wavefronts per group; ZPAQ_AMD_MIX_HALVES=1 builds it)
+  static const bool halves_wanted = [] { const char* v = getenv("ZPAQ_AMD_MIX_HALVES"); return v && v[0] == '1'; }();
+  if (halves_wanted && !L.mix_bits && !L.mix.empty()) {
+    bool ok = true;
+    for (size_t r = 0; r < L.mix.size(); ++r) {
+      const CompDesc& c = comp[L.mix[r]];
+      ok = ok && c.a5 == 255u && c.mask0 >= 255u && L.mix_ql[r] * 2 <= 64;
+    }
+    if (ok) L.ps_mix_nh = 2;
+  }
   for (size_t r = 0; r < L.mix.size(); ++r) {
-    const int nw = L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
-    for (int sub = 0; sub < nw; ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.55f : 2.6f);
+    const int nw = L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] * L.ps_mix_nh / 64);
+    for (int sub = 0; sub < nw; ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : 2.6f));
   }
   // who reads whose streams
   std::vector<std::vector<int>> producers(nunit);
@@ -618,6 +631,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     if (du.empty()) { du.push_back(0); dl.push_back(0); dm.push_back(0); }
     o << "struct ChainP : Chain {\n"
          "  static constexpr bool PIPE_PERSIST = true;\n"
+         "  static constexpr int PS_MIX_NH = " << L.ps_mix_nh << ";\n"
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
       << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";
     arr("PS_KIND", kind.data(), (int)kind.size());

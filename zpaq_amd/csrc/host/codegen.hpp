@@ -87,6 +87,7 @@ struct PipeLayout {
   int ps_wpg = 0;              // workgroups per group
   int ps_nunit = 0;
   int ps_lds_bytes = 0;        // per workgroup: shared tables + the largest flavour's private tables
+  int ps_mix_nh = 1;           // lane groups a MIX unit gives a block: 2 = bits 0 .. 3 and bits 4 .. 7 apart (half the chain per byte)
   std::vector<Slot> ps_slots;  // ps_wpg * ps_waves, flavour-major
   std::vector<std::vector<Dep>> ps_deps;   // per slot
   int light_threads() const { return 64; }                                                // workgroup size of the light kernel (bit-lane units: 8 blocks x 8 positions)
