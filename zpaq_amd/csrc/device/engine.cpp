@@ -86,6 +86,8 @@ struct Event {
   operator hipEvent_t() const { return ev; }
 };
 
+static int g_cus_hint = 256;              // compute units of the device the batches run on (set when an engine is created)
+
 struct Engine {
   std::mutex mu;
   bool ready = false;
@@ -196,6 +198,7 @@ void engine_init_device(Engine& e, int slot, int device) {
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     fail(ZPQ_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
   e.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_cus_hint = e.cus;
   if (!e.stream) HIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
   // constant tables
   const Tables& t = tables();
@@ -360,8 +363,23 @@ static const uint32_t kLongStepBytes = 128u << 10;       // latency shape: block
 // 256 MB Infinity Cache instead of HBM.  Measured (profiles/r03/call10_summary.txt): -m3's n = 2 chain on 256 blocks
 // (29 MB per step) 483 -> 440 ms; -m5 (588 B per byte) +4 % at 64 blocks (77 MB), +6 % at 512 (616 MB), -20 % at 640.
 static const uint64_t kLongStepStreamBytes = 96ull << 20;
-static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte) {
+static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte, const zpq_plan* plan = nullptr) {
   bool latency = blocks_of_plan <= kLatencyModeBlocks;
+  // With the persistent launch the shapes differ in how many workgroups a group of blocks needs (-m5: 14 against 8): the
+  // latency shape is the faster one exactly while ALL its workgroups are resident together (measured, profiles/r05
+  // call13: 512 blocks 268 MB/s against 187; beyond that -- 640 blocks: 280 workgroups -- it would need a second round,
+  // which costs a whole block's serial time, and the throughput shape in one round wins: 768 blocks 264 MB/s, 1024: 350)
+  {
+    const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
+    if (plan && !(pp && !strcmp(pp, "0"))) {
+      PipeLayout L1;
+      std::string why;
+      if (pipe_layout(*plan, pipe_options(1), L1, why) && L1.persist_ok) {
+        const uint64_t groups = (blocks_of_plan + (uint32_t)L1.G - 1) / (uint32_t)L1.G;
+        latency = groups * (uint64_t)L1.ps_wpg <= (uint64_t)g_cus_hint;
+      }
+    }
+  }
   if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
     if (!strcmp(m, "latency")) latency = true;
     if (!strcmp(m, "throughput")) latency = false;
@@ -444,7 +462,7 @@ int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode, uint32_
   require_ready(e);
   bind_device(e);
   e.jit_left = jit_budget();
-  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes, pipe_stream_bytes_per_byte(p)));
+  const KernelPick k = kernel_kind(e, p, nblocks > (uint32_t)4 * e.cus, decode, pipe_mode_for(nblocks ? nblocks : 0xFFFFFFFFu, block_bytes, pipe_stream_bytes_per_byte(p), p));
   // (the note of the kernel that was PICKED: the plan's spec_note is the note of whichever shape was loaded last)
   if (k.kind == 3 && k.spec)
     note = k.spec->origin + (k.spec->encode ? "" : (k.spec->threads > 256 ? " (zpq_spec_decode3: row / mixer wavefronts in lockstep)"
@@ -944,7 +962,35 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
   std::map<const zpq_plan*, std::pair<uint32_t, uint32_t>> cnt;
   for (uint32_t b : order) { auto& c = cnt[plan_of(b)]; ++c.first; c.second = std::max(c.second, (uint32_t)len_of(b)); }
   std::map<const zpq_plan*, int> mode;
-  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second, pipe_stream_bytes_per_byte(kv.first));
+  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second, pipe_stream_bytes_per_byte(kv.first), kv.first);
+  // several chains in one batch share the device's workgroup slots: the persistent launches run side by side only when they
+  // are resident TOGETHER, so chains go from the latency shape to the throughput shape (fewer workgroups per group), the one
+  // that frees the most first, until the batch fits
+  const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
+  if (cnt.size() > 1 && !(pp && !strcmp(pp, "0")) && !getenv("ZPAQ_AMD_PIPE_MODE")) {
+    struct Need { const zpq_plan* p; uint64_t lat, thr; };
+    std::vector<Need> need;
+    bool all = true;
+    for (auto& kv : cnt) {
+      PipeLayout L0, L1;
+      std::string why;
+      if (!pipe_layout(*kv.first, pipe_options(0), L0, why) || !L0.persist_ok || !pipe_layout(*kv.first, pipe_options(1), L1, why) || !L1.persist_ok) { all = false; break; }
+      const uint64_t groups = (kv.second.first + (uint32_t)L0.G - 1) / (uint32_t)L0.G;
+      need.push_back(Need{kv.first, groups * (uint64_t)L1.ps_wpg, groups * (uint64_t)L0.ps_wpg});
+    }
+    if (all) {
+      for (;;) {
+        uint64_t total = 0;
+        for (const Need& n : need) total += mode[n.p] == 0 ? n.thr : n.lat;
+        if (total <= (uint64_t)g_cus_hint) break;
+        const Need* best = nullptr;
+        for (const Need& n : need)
+          if (mode[n.p] != 0 && n.lat > n.thr && (!best || n.lat - n.thr > best->lat - best->thr)) best = &n;
+        if (!best) break;
+        mode[best->p] = 0;
+      }
+    }
+  }
   return mode;
 }
 

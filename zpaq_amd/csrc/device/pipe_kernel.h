@@ -1560,6 +1560,61 @@ __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
   });
 }
 
+// ISSE map inside the persistent launch: the weight pairs PACKED -- both weights are clamped to +-2^19 (libzpaq.cpp:2031-2039),
+// 40 bits per pair: a word [entry][lane] with w0 and the low 12 bits of w1, and w1's high 8 bits in a byte of the word
+// [entry / 4][lane] -- 40 KiB instead of 64 for a group of 32 blocks, which is what decides how many workgroups a group needs.
+template <class Chain, int I, class SQ>
+__device__ __forceinline__ void pipe_isse_packed_unit(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab) {
+  constexpr unsigned G = Chain::PIPE_G;
+  constexpr CompK c = Chain::comp[I];
+  constexpr int ri = Chain::P_ROW[I], J = (int)c.a2;
+  if (!L.nb) return;
+  unsigned* const lo = tab;
+  unsigned char* const hi = (unsigned char*)(tab + 256u * G);
+  auto hi_at = [&](unsigned s) __attribute__((always_inline)) -> unsigned { return (((s >> 2) * G + (unsigned)lane) << 2) + (s & 3u); };
+  auto w0_of = [&](unsigned l) __attribute__((always_inline)) -> int { return (int)(l << 12) >> 12; };
+  auto w1_of = [&](unsigned l, unsigned h) __attribute__((always_inline)) -> int { return (int)(((l >> 20) | (h << 12)) << 12) >> 12; };
+  if (load_tab)
+    for (unsigned e = 0; e < 256u; e += 2) {
+      const uint4 q = L.A128((unsigned)c.t0 + 8u * e);                 // (w0, w1) of entries e, e + 1
+      lo[e * G + lane] = (q.x & 0xFFFFFu) | (q.y << 20);
+      hi[hi_at(e)] = (unsigned char)(q.y >> 12);
+      lo[(e + 1u) * G + lane] = (q.z & 0xFFFFFu) | (q.w << 20);
+      hi[hi_at(e + 1u)] = (unsigned char)(q.w >> 12);
+    }
+  unsigned byte = L.byte_at(0);
+  uint2 w = L.bh(ri, 0);
+  uint4 vj = L.p(J, 0);
+  unsigned s = pipe_bh_get(w, 0);
+  unsigned l0 = lo[s * G + lane], h0 = hi[hi_at(s)];
+  int w0 = w0_of(l0), w1 = w1_of(l0, h0);
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned kn = L.next(k);
+    const unsigned byten = L.byte_at(kn);
+    const uint2 wn = L.bh(ri, kn);
+    const uint4 vjn = L.p(J, kn);
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const unsigned sn = B < 7 ? pipe_bh_get(w, B + 1) : pipe_bh_get(wn, 0);
+      const unsigned ln = lo[sn * G + lane], hn = hi[hi_at(sn)];
+      const int pj = pipe_p_get(vj, B);
+      const int pr = sp_clamp2k((__mul24(w0, pj) + w1 * 64) >> 16);          // 20-bit x 12-bit
+      out.set(B, pr);
+      const int err = pipe_y(byte, B) * 32767 - squash(pr);
+      const int u0 = sp_clamp512k(w0 + ((__mul24(err, pj) + (1 << 12)) >> 13));
+      const int u1 = sp_clamp512k(w1 + ((err + 16) >> 5));
+      lo[s * G + lane] = ((unsigned)u0 & 0xFFFFFu) | ((unsigned)u1 << 20);
+      hi[hi_at(s)] = (unsigned char)((unsigned)u1 >> 12);
+      w0 = sn == s ? u0 : w0_of(ln);
+      w1 = sn == s ? u1 : w1_of(ln, hn);
+      s = sn;
+    }
+    L.put_p(I, k, out.get());
+    byte = byten; w = wn; vj = vjn;
+  }
+}
+
 // ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
 template <class Chain, int I, class SQ>
 __device__ __forceinline__ void pipe_isse_unit(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab, bool store_tab) {

@@ -198,7 +198,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     } else if constexpr (kind == 3) {
       if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
     } else if constexpr (kind == 4) {
-      if (pipe_any(L.nb > 0)) pipe_isse_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0, false);
+      if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0);
     } else if constexpr (kind == 5) {
       if (pipe_any(L.nb > 0)) {
         if constexpr (Chain::MIX_BITS != 0) pipe_mix_bits_unit<Chain, role>(L, q, B, ro.squash);

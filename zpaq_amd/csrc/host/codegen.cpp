@@ -343,7 +343,7 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
     add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0]);
   }
   for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f);
-  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 512 * G * 4, 1.4f);
+  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 256 * G * 4 + 64 * G * 4, 1.5f);      // (packed pairs: pipe_isse_packed_unit)
   // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
   //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
   // throughput shape: a MIX whose 8 rows of a byte are distinct splits the byte over two lane groups (device: pipe_mix_unit NH = 2)
@@ -396,7 +396,21 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
   const int total = (int)slots.size();
   const int cap = kPersistLdsCap - kPersistRoBytes;
   for (const auto& s : slots) if (s.lds > cap) { L.persist_why = "a unit's tables do not fit a workgroup's LDS"; return; }
-  for (int wpg = (total + 7) / 8; wpg <= total; ++wpg) {
+  // Workgroups per group.  A chain of the standard size (-m5: 54 unit wavefronts) is packed into 8 even where 7 would do: 32
+  // groups x 8 = the MI355X's 256 compute units, one workgroup each (measured, profiles/r05 call14: 346 MB/s against 326 with
+  // 7 x 32 = 224 workgroups); otherwise the fewest that hold the units.  The tables go first (largest first, each into the
+  // bin it fits best -- tried emptiest-first as well), then the units without tables to the bin with the least work.
+  static const int wpg_floor = [] { const char* v = getenv("ZPAQ_AMD_PERSIST_WPG_MIN"); return v ? atoi(v) : -1; }();      // (experiments)
+  const int wpg_min = (total + 7) / 8;
+  std::vector<int> tries;
+  if (wpg_floor >= 0) { for (int w = std::max(wpg_min, std::min(wpg_floor, total)); w <= total; ++w) tries.push_back(w); }
+  else {
+    if (total >= 40 && wpg_min < 8) tries.push_back(8);
+    for (int w = wpg_min; w <= total; ++w) tries.push_back(w);
+  }
+  for (size_t ti = 0; ti < tries.size() * 2; ++ti) {
+    const int wpg = tries[ti / 2];
+    const bool best_fit = (ti & 1) == 0;
     const int W = std::min(8, total);
     struct Bin { std::vector<int> s; int lds = 0; float cost = 0; };
     std::vector<Bin> bins(wpg);
@@ -406,14 +420,20 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
       if (slots[x].lds != slots[y].lds) return slots[x].lds > slots[y].lds;
       return slots[x].cost > slots[y].cost;
     });
+    int with_tables = 0;
+    for (const auto& sl : slots) with_tables += sl.lds != 0;
     bool fits = true;
     for (int idx : order) {
       const auto& s = slots[idx];
       int best = -1;
       for (int b = 0; b < wpg; ++b) {
         if ((int)bins[b].s.size() >= W || bins[b].lds + s.lds > cap) continue;
-        // tables first-fit by LDS left (the emptiest bin), the rest to the bin with the least work
-        if (best < 0 || (s.lds ? bins[b].lds < bins[best].lds : bins[b].cost < bins[best].cost)) best = b;
+        if (best < 0) { best = b; continue; }
+        if (s.lds) {
+          // a table: the fullest bin it still fits (best fit) while every bin can still get its share of wavefronts, or the emptiest
+          const bool fuller = bins[b].lds > bins[best].lds;
+          if (best_fit ? (fuller && (int)bins[b].s.size() < (with_tables + wpg - 1) / wpg + 1) : !fuller && bins[b].lds != bins[best].lds) best = b;
+        } else if (bins[b].cost < bins[best].cost) best = b;
       }
       if (best < 0) { fits = false; break; }
       bins[best].s.push_back(idx); bins[best].lds += s.lds; bins[best].cost += s.cost;
