@@ -232,6 +232,69 @@ def in_library_bench(a, torch, z):
 
 
 
+def dry_run_bench(a):
+    """--dry-run: the N-rank flow of `bench.py --gpus N` WITHOUT GPUs -- torch.distributed over gloo on 127.0.0.1, CPU tensors,
+    a method that has no model (LZ77 on the host: the library needs no device for it).  What it exercises is everything
+    around the hot path that a multi-GPU run adds: launching the ranks, the corpus made on rank 0 and scattered in
+    contiguous ranges (zpaq_amd.dist.scatter_blocks), every rank coding its range with no collective, the timed region
+    between barriers with the maximum over the ranks, the archives gathered to rank 0 in block order, ONE JSON line with
+    dist_ms.  tests/test_dist.py runs it with two ranks; the numbers mean nothing."""
+    import subprocess
+    import torch
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    import torch.distributed as dist
+    import zpaq_amd as z
+    from zpaq_amd import dist as zd
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+    method = a.method if a.method in ("0", "1", "2") else "1"
+    per, bs = (a.blocks if a.blocks and a.blocks <= 64 else 12), min(a.block_bytes, 1 << 16)
+    total = per * world + (1 if world > 1 else 0)          # (an uneven split)
+    full = make_corpus("mixed", total, bs, first=0, dev=None) if rank == 0 else None
+    dist_ms = {}
+    zd.barrier(); t0 = time.perf_counter()
+    mine = zd.scatter_blocks(full, total, bs).numpy()
+    zd.barrier()
+    dist_ms["scatter"] = (time.perf_counter() - t0) * 1e3
+    dist_ms["scatter_bytes"] = total * bs
+    rows = [mine[i] for i in range(mine.shape[0])]
+    for _ in range(a.warmup):
+        z.compress_blocks(rows, method)
+    zd.barrier(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        archives = z.compress_blocks(rows, method)
+    zd.barrier()
+    elapsed = zd.max_over_ranks(time.perf_counter() - t0)
+    zd.barrier(); t0 = time.perf_counter()
+    allc = zd.gather_archives(archives)
+    zd.barrier()
+    dist_ms["gather"] = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        dist_ms["gather_bytes"] = sum(len(x) for x in allc)
+        ok = len(allc) == total and z.decompress(b"".join(allc)) == full.tobytes()
+        print(json.dumps({"metric": f"compress MB/s, dry run of the {world}-rank flow on CPU (gloo, method {method}: no model, no GPU)",
+                          "value": total * bs * a.steps / 1e6 / elapsed, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u8", "data": "synthetic", "dry_run": True, "backend": "gloo",
+                          "config": {"workload": f"method \"{method}\" x {total} blocks x {bs} B 'mixed', {world} CPU ranks", "blocks_total": total,
+                                     "block_bytes": bs, "parallelism": f"blocks/{world}ranks"},
+                          "all_status_ok": bool(ok), "archives_in_block_order_and_round_trip": bool(ok), "dist_ms": dist_ms,
+                          "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def machine_code_sha256(path):
     """sha256 over the .text and .rodata bytes of the gfx950 code object inside a clang offload bundle (or a bare ELF):
     what the GPU executes, without the bundle's ids and the notes that change with the name of the source file."""
@@ -285,12 +348,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--api-blocks", type=int, default=-1,
                     help="blocks of the end-to-end API leg on host buffers (-1 = the whole batch, 0 = skip)")
-    ap.add_argument("--verify-blocks", type=int, default=4, help="blocks whose first --verify-bytes are decoded back on the device")
-    ap.add_argument("--verify-bytes", type=int, default=32768)
+    ap.add_argument("--verify-blocks", type=int, default=-1, help="blocks decoded back on the device (-1: every block of the batch)")
+    ap.add_argument("--verify-bytes", type=int, default=0, help="how much of each of them (0: the whole block)")
     ap.add_argument("--kernel", type=int, default=0, help="zpq_set_kernel: 0 the engine's choice, 3 / 5 with --mode decode: one / two blocks per wavefront")
     ap.add_argument("--decode-blocks", type=int, default=2048,
                     help="blocks of the `decode` leg of an encode run on one GPU (BASELINE configs[4]'s operating point: one "
                          "residency wave of the 8192-block archive = 2048 x 1 MiB), outside the timed region; 0 = skip")
+    ap.add_argument("--decode-kind", default=None,
+                    help="corpus of the decode leg: default 'mixed' (BASELINE configs[4] decodes configs[3]'s archive); the same as --kind reuses the timed run's payloads")
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
                     help="decode = BASELINE configs[4]: time Decoder::decompress over the archive just produced")
     ap.add_argument("--distribute", dest="distribute", action="store_true", default=None,
@@ -301,7 +366,11 @@ def main():
     ap.add_argument("--in-library", action="store_true",
                     help="N>1 in ONE process: zpq_init(-1), one engine per device inside the library, the host-buffer batch "
                          "sharded over them (no torch.distributed)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="the N-rank flow on CPU: gloo, a method without a model (scatter, code, gather, one line with dist_ms); no GPU needed")
     a = ap.parse_args()
+    if a.dry_run:
+        return dry_run_bench(a)
     if a.blocks is None:
         a.blocks = 2048 if a.mode == "decode" else 1024
     if a.kind is None:
@@ -466,20 +535,31 @@ def main():
             torch.cuda.synchronize()
 
 
-    def decode_leg(nd):
-        """BASELINE configs[4] beside the headline: Decoder::decompress (libzpaq.cpp:2104-2155) over nd blocks of the same
-        corpus in ONE launch -- the nb coded payloads of the timed run plus nd - nb more blocks coded here --, every decoded
+    def decode_leg(nd, kind):
+        """BASELINE configs[4] beside the headline: Decoder::decompress (libzpaq.cpp:2104-2155) over nd blocks in ONE launch --
+        by default blocks of configs[3]'s MIXED corpus (text, text, LCG, records: the archive configs[4] decodes), coded here by
+        the device encoder; with --decode-kind equal to --kind the coded payloads of the timed run are reused --, every decoded
         byte compared with the coder's input on the device; its own roofline and the reference's Decompresser beside it."""
-        extra = max(nd - nb, 0)
-        nd = nb + extra if extra else min(nd, nb)
-        ins, lens_in, plans = [d_in[:nd]], list(in_len[:nd]), list(plan_of[:nd])
-        codes, lens_out = [d_out[:nd]], [int(x) for x in out_len[:nd]]
-        if extra:
-            from zpaq_amd import corpus, corpus_torch
-            if a.kind == "text":
-                more = corpus_torch.text_blocks(extra, bs, corpus.BASE_SEED + first + nb, dev).cpu().numpy()
+        reuse = kind == a.kind
+        extra = max(nd - nb, 0) if reuse else nd
+        nd = (nb + extra if extra else min(nd, nb)) if reuse else nd
+        if reuse:
+            ins, lens_in, plans = [d_in[:nd]], list(in_len[:nd]), list(plan_of[:nd])
+            codes, lens_out = [d_out[:nd]], [int(x) for x in out_len[:nd]]
+        else:
+            ins, lens_in, plans, codes, lens_out = [], [], [], [], []
+        dec_blocks = blocks if reuse else None          # (host copies for the CPU baseline's sample)
+        from zpaq_amd import corpus, corpus_torch
+        done = 0
+        while done < extra:
+            part = min(1024, extra - done)              # (a batch the encoder holds in one residency round)
+            f0 = corpus.BASE_SEED + first + (nb + done if reuse else done)
+            if kind == "text":
+                more = corpus_torch.text_blocks(part, bs, f0, dev).cpu().numpy()
             else:
-                more = make_corpus(a.kind, extra, bs, first=first + nb, dev=dev)
+                more = make_corpus(kind, part, bs, first=(first + nb + done if reuse else first + done), dev=dev)
+            if dec_blocks is None:
+                dec_blocks = more
             prep = coder_input_of(more)
             del more
             for h, _, _ in prep:
@@ -487,23 +567,24 @@ def main():
                     plan_cache[h] = z.Plan(h)
             lens2 = [len(pp) + len(st) for _, pp, st in prep]
             if max(lens2) > stride_in - 8:
-                return {"skipped": "a block of the second batch is longer than the first batch's row stride"}
+                return {"skipped": "a block of the decode leg is longer than the headline's row stride"}
             pl2 = [plan_cache[h] for h, _, _ in prep]
             d_in2 = torch.from_numpy(rows_of(prep, stride_in)).to(dev)
             del prep
-            d_out2 = torch.empty((extra, stride_out), dtype=torch.uint8, device=dev)
-            r1 = torch.zeros((extra, 4), dtype=torch.int32, device=dev)
-            rc = L.zpq_code_device_multi(0, (C.c_void_p * extra)(*[p._h for p in pl2]), C.c_void_p(d_in2.data_ptr()),
-                                         (C.c_uint64 * extra)(*[i * stride_in for i in range(extra)]), (C.c_uint32 * extra)(*lens2),
-                                         extra, C.c_void_p(d_out2.data_ptr()), (C.c_uint64 * extra)(*[i * stride_out for i in range(extra)]),
-                                         (C.c_uint32 * extra)(*[cap] * extra), C.c_void_p(r1.data_ptr()), None, 1)
+            d_out2 = torch.empty((part, stride_out), dtype=torch.uint8, device=dev)
+            r1 = torch.zeros((part, 4), dtype=torch.int32, device=dev)
+            rc = L.zpq_code_device_multi(0, (C.c_void_p * part)(*[p._h for p in pl2]), C.c_void_p(d_in2.data_ptr()),
+                                         (C.c_uint64 * part)(*[i * stride_in for i in range(part)]), (C.c_uint32 * part)(*lens2),
+                                         part, C.c_void_p(d_out2.data_ptr()), (C.c_uint64 * part)(*[i * stride_out for i in range(part)]),
+                                         (C.c_uint32 * part)(*[cap] * part), C.c_void_p(r1.data_ptr()), None, 1)
             if rc:
                 raise RuntimeError(L.zpq_last_error().decode())
             r1h = r1.cpu().numpy()
             if not (r1h[:, 2] == 0).all():
-                return {"skipped": "coding the second batch failed"}
+                return {"skipped": "coding the decode leg's blocks failed"}
             ins.append(d_in2); codes.append(d_out2)
             lens_in += lens2; plans += pl2; lens_out += [int(x) for x in r1h[:, 0]]
+            done += part
         src = torch.cat(ins) if len(ins) > 1 else ins[0]
         code = torch.cat(codes) if len(codes) > 1 else codes[0].clone()
         del ins, codes
@@ -533,8 +614,12 @@ def main():
         algo = float(sum(p.algo_bytes_per_byte * n for p, n in zip(plans, lens_in)))
         code_s = tm[1] / 1e3
         note2 = C.create_string_buffer(512)
-        kk = sorted({int(L.zpq_plan_kernel_kind4(p._h, 1, nd, max(lens_in), note2, 512)) for p in set(plans)})
-        org = note2.value.decode(errors="replace")
+        kk, by_chain = set(), {}
+        for p_ in set(plans):          # which decoder each chain of the batch got
+            kk.add(int(L.zpq_plan_kernel_kind4(p_._h, 1, nd, max(lens_in), note2, 512)))
+            by_chain[f"n={p_.ncomp}"] = note2.value.decode(errors="replace")
+        kk = sorted(kk)
+        org = " | ".join(f"{k_}: {v_}" for k_, v_ in sorted(by_chain.items()))
         kn = "zpq_spec_decode"
         for tag, nm in (("zpq_spec_decode3", "zpq_spec_decode3 (row / mixer wavefronts, blocks of a workgroup in lockstep)"),
                         ("zpq_spec_decode2", "zpq_spec_decode2 (two blocks per wavefront)")):
@@ -545,7 +630,8 @@ def main():
                          f"wave of the 8-GPU archive on one GPU)",
                # like the headline: inputs resident in HBM, state buffers in place -- Predictor::init + the decoding launch; the
                # wall time of this first decode call of the process also grows the engine's arena pool from 1024 to nd blocks
-               "value": float(nd) * bs / 1e6 / ((tm[0] + tm[1]) / 1e3), "unit": "MB/s", "blocks": nd, "block_bytes": bs, "corpus": a.kind,
+               "value": float(nd) * bs / 1e6 / ((tm[0] + tm[1]) / 1e3), "unit": "MB/s", "blocks": nd, "block_bytes": bs, "corpus": kind,
+               "ncomp": sorted({p.ncomp for p in set(plans)}),
                "ms": {"init_arena": tm[0], "code": tm[1], "wall_first_call": wall * 1e3},
                "every_byte_verified": good,
                "roofline": {"bound": "hbm", "achieved": algo / 1e9 / code_s if code_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -554,7 +640,7 @@ def main():
                             "algo_bytes_per_launch": algo, "kernel_s_per_launch": code_s},
                "cpu_baseline": None}
         if a.cpu_seconds > 0:
-            base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
+            base = cpu_decode_baseline(dec_blocks, a.method, a.cpu_seconds)
             obj["cpu_baseline"] = base
             obj["vs_cpu"] = obj["value"] / base["value"] if base and base["value"] else None
         return obj
@@ -631,9 +717,9 @@ def main():
 
     # product-path self check: round-trip a few blocks through the device decoder
     verified = 0
-    nv = min(a.verify_blocks, nb)
+    nv = nb if a.verify_blocks < 0 else min(a.verify_blocks, nb)
     if ok and nv:
-        vb = min(min(in_len[:nv]) - 1, a.verify_bytes) + 1      # "decode first k bytes" (Decompresser::decompress(n))
+        vb = (min(min(in_len[:nv]) - 1, a.verify_bytes) + 1) if a.verify_bytes > 0 else max(in_len[:nv]) + 8      # "decode first k bytes" (Decompresser::decompress(n)) or everything
         coded = d_out[:nv].clone()
         lens = [int(out_len[i]) for i in range(nv)]
         for k, ln in enumerate(lens):           # append the 4-zero terminator the container adds
@@ -651,11 +737,13 @@ def main():
         if rc:
             raise RuntimeError(L.zpq_last_error().decode())
         r2h = r2.cpu().numpy()
-        for k in range(nv):
-            good = r2h[k, 2] == 0 and r2h[k, 0] == vb and bool((back[k, :vb] == d_in[k, :vb]).all())
-            verified += int(good)
-            ok = ok and good
-        del back, coded
+        want = np.array([vb if vb < in_len[k] else in_len[k] for k in range(nv)], np.int64)
+        cols = torch.arange(stride_in, device=dev)[None, :] < torch.from_numpy(want).to(dev)[:, None]
+        same_rows = (((back == d_in[:nv]) | ~cols).all(dim=1)).cpu().numpy()
+        good_rows = (r2h[:, 2] == 0) & (r2h[:, 0] == want) & same_rows
+        verified = int(good_rows.sum())
+        ok = ok and bool(good_rows.all())
+        del back, coded, cols
 
     # which kernel coded the blocks (4 pipelined encoder, 3 per-header wavefront kernel, 2 generic wave, 1 generic one-lane)
     note = C.create_string_buffer(512)
@@ -664,8 +752,12 @@ def main():
     kname = {4: "zpq_pipe_{hcomp,rows,light,icm,isse,mix}: one launch of each per step, concurrent",
              3: "zpq_spec_" + ("decode" if dec else "encode"), 2: "code_wave_kernel", 1: "code_serial_kernel"}.get(kinds[-1], "?")
     origin = note.value.decode(errors="replace")
-    if dec and "zpq_spec_decode2" in origin:
+    if dec and "zpq_spec_decode3" in origin:
+        kname = "zpq_spec_decode3 (row / mixer wavefronts, blocks of a workgroup in lockstep)"
+    elif dec and "zpq_spec_decode2" in origin:
         kname = "zpq_spec_decode2 (two blocks per wavefront)"
+    if not dec and persistent and kinds[-1] == 4:
+        kname = "zpq_pipe_persist: ONE launch per chain for the whole sequence (unit wavefronts waiting on progress counters)"
     # HBM traffic per launch from the committed rocprofv3 PMC passes -- only when THIS workload was profiled with THIS
     # code object (the cache key is part of kernel_origin); a stale entry is refused
     traffic = None
@@ -743,9 +835,30 @@ def main():
         # coded payloads of the timed run, for the identity check against the reference
         ncmp = min(nb, 512)
         host_out = d_out[:ncmp].cpu().numpy()
+        # ... and EVERY block of the headline corpus against what the reference made of it, frozen in tests/golden/headline_sha1.json
+        # (tests/golden/make_headline_golden.py: the unmodified libzpaq, run where /root/reference exists; nothing of this library
+        # or of the oracle is involved): SHA-1 of the coded payload + terminator of the timed, device-resident run
+        golden = None
+        gpath = os.path.join(ROOT, "tests", "golden", "headline_sha1.json")
+        if a.mode == "encode" and a.kind == "text" and a.method == "5" and bs == (1 << 20) and first == 0 and os.path.exists(gpath):
+            gj = json.load(open(gpath))["blocks"]
+            ng = min(nb, len(gj))
+            bad = []
+            for b0 in range(0, ng, 256):
+                part = d_out[b0:min(b0 + 256, ng)].cpu().numpy()
+                for j in range(part.shape[0]):
+                    i = b0 + j
+                    n = int(out_len[i])
+                    if n != gj[i]["coded_len"] or hashlib.sha1(part[j, :n].tobytes() + b"\0\0\0\0").hexdigest() != gj[i]["payload_sha1"]:
+                        bad.append(i)
+                del part
+            golden = {"blocks_compared": ng, "identical": not bad, "first_mismatches": bad[:8],
+                      "what": "SHA-1 of every block's coded payload + terminator (timed device-resident run) against the reference's, "
+                              "frozen in tests/golden/headline_sha1.json"}
+            line["reference_identity"] = golden
         if a.mode == "encode" and world == 1 and a.decode_blocks > 0 and ok:
             try:
-                line["decode"] = decode_leg(a.decode_blocks)
+                line["decode"] = decode_leg(a.decode_blocks, a.decode_kind or "mixed")
             except Exception as e:            # the headline line must survive a failing side leg
                 line["decode"] = {"error": str(e)[:500]}
         del d_out
@@ -765,6 +878,13 @@ def main():
                 L.zpq_last_api_timing(ph)
                 if first_ms is None:
                     first_ms = ph[0]
+            if golden is not None:      # the archives the drop-in API returned: whole-archive SHA-1 against the reference's
+                gj = json.load(open(gpath))["blocks"]
+                na = min(napi, len(gj))
+                badw = [i for i in range(na) if len(api_archives[i]) != gj[i]["len"] or hashlib.sha1(api_archives[i]).hexdigest() != gj[i]["sha1"]]
+                golden["api_archives_compared"] = na
+                golden["api_archives_identical"] = not badw
+                golden["identical"] = golden["identical"] and not badw
             line["api"] = {"value": napi * bs / 1e6 / (ph[0] / 1e3) if ph[0] else None, "unit": "MB/s", "blocks": napi,
                            "what": "zpq_compress_blocks on host buffers: SHA-1 + method expansion + header assembly, "
                                    "staging + H2D, Predictor init + coding kernels, D2H, archive framing",

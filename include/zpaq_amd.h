@@ -51,6 +51,8 @@ const char* zpq_version(void);
  * reference's two table checksums (1759-1760) on the host. */
 int zpq_init(int device);
 int zpq_device_count(void);
+/* Engines zpq_init() configured: 1, or one per device named by zpq_init(-1) / ZPAQ_AMD_DEVICES (a device named twice gets two). */
+int zpq_engine_count(void);
 /* How a host-buffer batch of n blocks is split when the engine drives several GPUs (zpq_init(-1) or
  * ZPAQ_AMD_DEVICES=all|0,1,..): shard k of `parts` codes blocks [lo, hi) -- contiguous ranges, so archive order is
  * kept; one engine and one host thread per device, no collective (blocks are independent, libzpaq.h:57-59). */

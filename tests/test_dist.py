@@ -115,3 +115,20 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env2)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_dry_run_is_the_whole_rank_flow_on_cpu():
+    """`bench.py --gpus 2 --dry-run`: what a multi-GPU run adds around the hot path, on CPU (gloo, two ranks, a method
+    without a model): the corpus made on rank 0 and scattered in uneven contiguous ranges, every rank coding its range with
+    no collective, the timed region between barriers with the maximum over the ranks, the archives gathered in block
+    order and decoded back on rank 0, ONE JSON line that carries n_gpus and dist_ms."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] and d["all_status_ok"] and d["archives_in_block_order_and_round_trip"]
+    assert d["config"]["blocks_total"] == 25 and d["dist_ms"]["scatter_bytes"] == 25 * 65536 and d["dist_ms"]["gather_bytes"] > 0

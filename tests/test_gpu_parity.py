@@ -608,6 +608,70 @@ def test_two_engines_shard_one_batch(gpu):
     assert "DIGEST %s 37" % hashlib.sha1(b"".join(alone)).hexdigest() in r.stdout
 
 
+def test_eight_engines_on_one_gpu_shard_an_uneven_batch(gpu):
+    """The in-library path of an 8-GPU node (zpq_init(-1): one engine, one host thread and one contiguous block range per
+    configured device) with the one GPU of this box named eight times: 1027 blocks -- not a multiple of 8, so the ranges are
+    uneven -- of four kinds and ragged lengths, coded by eight engines side by side (their persistent launches take turns on
+    the shared device).  Archives in block order, identical to the single-engine result, and they decode back."""
+    import subprocess
+    code = ("import os, sys, hashlib\n"
+            "sys.path.insert(0, %r)\n"
+            "import zpaq_amd as z\n"
+            "from zpaq_amd import corpus\n"
+            "n = 1027\n"
+            "blocks = [corpus.block(['text', 'lcg', 'records', 'zeros'][i %% 4], 1500 + (i * 37) %% 2500, 900 + i) for i in range(n)]\n"
+            "z.init(-1 if os.environ.get('ZPAQ_AMD_DEVICES') else 0)\n"
+            "arch = z.compress_blocks(blocks, '5')\n"
+            "assert z.decompress(b''.join(arch[:40])) == b''.join(b.tobytes() for b in blocks[:40])\n"
+            "print('DIGEST', hashlib.sha1(b''.join(arch)).hexdigest(), len(arch), z.device_count())\n" % ROOT)
+    outs = []
+    for devs in (None, "0,0,0,0,0,0,0,0"):
+        env = {k: v for k, v in os.environ.items() if k != "ZPAQ_AMD_DEVICES"}
+        if devs:
+            env["ZPAQ_AMD_DEVICES"] = devs
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0].split())
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2] == "1027"
+    assert outs[1][3] == "8", outs
+
+
+def test_persistent_launch_gives_up_and_the_step_kernels_take_over(gpu, oracle, monkeypatch):
+    """The persistent encoder launch (device/pipe_persist.h) spins on progress counters, so it carries a watchdog: a poller
+    that sees no progress for ZPAQ_AMD_PERSIST_TIMEOUT_MS raises the abort word, every unit exits, and the engine codes the
+    batch again with the step kernels on re-initialised arenas.  With a 1 ms limit the coder (which waits for the whole
+    pipeline to fill) gives up for certain: the archives must still be the oracle's, byte for byte."""
+    blocks = [corpus.block(["text", "records", "lcg"][i % 3], 150_000 + 911 * i, 70 + i) for i in range(40)]
+    want = gpu.compress_blocks(blocks, "5")
+    assert gpu.lib().zpq_last_persistent() == 1
+    monkeypatch.setenv("ZPAQ_AMD_PERSIST_TIMEOUT_MS", "1")
+    got = gpu.compress_blocks(blocks, "5")
+    assert gpu.lib().zpq_last_persistent() == 0, "the watchdog did not fire"
+    monkeypatch.delenv("ZPAQ_AMD_PERSIST_TIMEOUT_MS")
+    assert got == want
+    again = gpu.compress_blocks(blocks, "5")
+    assert gpu.lib().zpq_last_persistent() == 1 and again == want
+    monkeypatch.setenv("ZPAQ_AMD_PIPE_PERSIST", "0")
+    assert gpu.compress_blocks(blocks, "5") == want and gpu.lib().zpq_last_persistent() == 0
+    f = parse_block(want[0])
+    coded = oracle.encode(f["header"], b"\0" + blocks[0].tobytes())
+    assert want[0][f["payload_start"]:f["payload_start"] + len(coded)] == coded
+
+
+def test_input_tail_copied_behind_the_first_steps(gpu, monkeypatch):
+    """A batch of 64 or more equally long blocks of 512 KiB or more from pinned staging has only the first 64 KiB of every block
+    on the device when the step kernels start; the rest follows behind the first steps (engine.cpp LateInput: step s reads
+    input below (s + 1) x chunk only -- PipeLane::byte_at never looks ahead of its chunk).  Same archives with the split off."""
+    blocks = [corpus.block(["text", "lcg"][i % 2], 512 << 10, 40 + i) for i in range(64)]
+    monkeypatch.setenv("ZPAQ_AMD_PIPE_PERSIST", "0")         # (the persistent launch waits for the whole input)
+    split = gpu.compress_blocks(blocks, "5")
+    monkeypatch.setenv("ZPAQ_AMD_SPLIT_COPY", "0")
+    whole = gpu.compress_blocks(blocks, "5")
+    assert split == whole
+    monkeypatch.delenv("ZPAQ_AMD_PIPE_PERSIST")
+    assert gpu.compress_blocks(blocks, "5") == whole
+
+
 def test_suffix_arrays_on_the_device(gpu, ref):
     """The sort inside the byte-aligned LZ77 and BWT pre-processors (reference: divsufsort, libzpaq.cpp:4658-6434), for a
     whole batch in one device call (device/sa_kernels.hip: prefix doubling, one radix sort per round over every block).

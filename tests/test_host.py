@@ -611,3 +611,33 @@ def test_host_suffix_sorter_against_the_references_divsufsort(zlib_, ref):
         got = np.empty(max(n, 1), np.uint32)
         assert L.zpq_suffix_array_host(b.ctypes.data_as(u8p), n, got.ctypes.data_as(u32p)) == 0
         assert (got[:n].astype(np.int64) == ref.divsufsort(b.tobytes()).astype(np.int64)).all(), (kinds[i % 5], n)
+
+
+def test_device_preprocessing_hands_the_buffers_back_as_they_came(zlib_):
+    """zpq_preprocess_blocks_device applies E8E9 to the CALLER's buffers before the device sorts them (compressBlock does the same,
+    libzpaq.cpp:7715); when the device then declines (here: no GPU) the buffers must come back unfiltered -- a caller that falls
+    back to zpq_preprocess_block would otherwise filter twice and write a stream nothing restores.  Also: a null token buffer
+    with a non-zero capacity is refused."""
+    import ctypes as C
+    if zlib_.device_count() > 0:
+        pytest.skip("a GPU is present: the device does not decline")
+    L = zlib_.lib()
+    L.zpq_preprocess_blocks_device.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    rng = np.random.default_rng(3)
+    bufs = []
+    for i in range(3):
+        b = rng.integers(0, 256, 200000, dtype=np.uint8)
+        b[::37] = 0xE8; b[4::37] = 0; b[100::53] = 0xE9; b[104::53] = 0xFF; b[3::37] = 0xE8      # (overlapping candidates too)
+        bufs.append(b)
+    orig = [b.copy() for b in bufs]
+    outs = [np.empty(400000, np.uint8) for _ in bufs]
+    n = len(bufs)
+    rc = L.zpq_preprocess_blocks_device(b"x0,6,12,0,7,21,1c0,0,511i2", (C.c_void_p * n)(*[b.ctypes.data for b in bufs]),
+                                        (C.c_uint32 * n)(*[b.size for b in bufs]), n, (C.c_void_p * n)(*[o.ctypes.data for o in outs]),
+                                        (C.c_size_t * n)(*[o.size for o in outs]), (C.c_size_t * n)())
+    assert rc != 0
+    assert all((a == b).all() for a, b in zip(bufs, orig))
+    L.zpq_lz77_tokens_host.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    cnt = C.c_size_t(0)
+    assert L.zpq_lz77_tokens_host(b"x0,2,12,0,7,21,1", bufs[0].ctypes.data, 1000, None, 16, C.byref(cnt)) != 0

@@ -302,6 +302,7 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
   ZPQ_CATCH
 }
 
+int zpq_engine_count(void) { return engine_count(); }
 int zpq_last_persistent(void) { return engine_last_persistent() ? 1 : 0; }
 
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks) {
@@ -450,7 +451,7 @@ static void lz_args(const char* xmethod, int args[9]) {
 // The host's parse of one block (data is E8E9-filtered in place first when the method says so).
 int zpq_lz77_tokens_host(const char* xmethod, uint8_t* data, uint32_t n, uint32_t* tokens4, size_t cap, size_t* count) {
   ZPQ_TRY
-  if ((!data && n) || !count) fail(ZPQ_E_ARG, "null argument");
+  if ((!data && n) || !count || (!tokens4 && cap)) fail(ZPQ_E_ARG, "null argument");
   int args[9];
   lz_args(xmethod, args);
   if (args[1] > 4) e8e9_forward(data, n);
@@ -495,7 +496,15 @@ int zpq_preprocess_blocks_device(const char* xmethod, uint8_t* const* data, cons
   }
   std::vector<SortOut> outs;
   std::string note;
-  if (!engine_sort_preprocess(jobs, outs, note)) fail(ZPQ_E_UNSUPPORTED, "pre-processing on the device unavailable: " + note);
+  bool done = false;
+  std::exception_ptr err;
+  try { done = engine_sort_preprocess(jobs, outs, note); } catch (...) { err = std::current_exception(); }
+  if (!done) {
+    // the caller's buffers go back as they came: a caller that falls back to zpq_preprocess_block would filter them twice
+    if (args[1] > 4) for (uint32_t i = 0; i < n; ++i) e8e9_inverse(data[i], len[i]);
+    if (err) std::rethrow_exception(err);
+    fail(ZPQ_E_UNSUPPORTED, "pre-processing on the device unavailable: " + note);
+  }
   for (uint32_t i = 0; i < n; ++i) {
     std::vector<U8> pre;
     if (len[i] == 0) (void)preprocess_block(data[i], 0, args, pre, nullptr, true);

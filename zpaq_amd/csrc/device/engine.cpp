@@ -270,6 +270,12 @@ void engine_init(int device) {
   { Engine& e = eng(); bind_device(e); }
 }
 
+int engine_count() {
+  DeviceSet& ds = devset();
+  std::lock_guard<std::mutex> g(ds.mu);
+  return (int)ds.ids.size();
+}
+
 int engine_device_count() {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) return 0;
@@ -605,8 +611,17 @@ static uint32_t persist_capacity(Engine& e, PipeRun& r) {
   return r.k->persist_wg_per_cu > 0 ? (uint32_t)r.k->persist_wg_per_cu * (uint32_t)e.cus : 0u;
 }
 
+// Engines that drive the SAME physical device (ZPAQ_AMD_DEVICES=0,0,..: how the sharding path runs on a one-GPU box) must not
+// have persistent launches in flight together: each is sized to the whole device, and two half-resident launches would wait
+// for each other's compute units until the watchdog ends both.
+static std::mutex& persist_device_mutex(int device) {
+  static std::mutex mu[64];
+  return mu[(unsigned)device % 64u];
+}
+
 static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, bool* aborted, std::string* what) {
   *aborted = false;
+  std::lock_guard<std::mutex> device_turn(persist_device_mutex(e.device >= 0 ? e.device : e.slot));
   // what the device holds
   uint64_t need_wg = 0;
   std::vector<uint32_t> cap(runs.size());
@@ -1128,6 +1143,13 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
       const auto now = std::chrono::steady_clock::now();
       if (now - t0 >= cap) break;
       if (b.approaching == 0 && now - b.last_arrival[d] >= gap) break;
+      // a batch that fills the machine already (a bulk zpq_compress_blocks / decode_archive call, or a pool that has queued
+      // that much) gains nothing from company: go at once unless somebody is announced
+      {
+        uint64_t queued = 0;
+        for (const Ticket* t : b.queue[d]) queued += t->blocks->size();
+        if (b.approaching == 0 && queued >= (uint64_t)4 * (uint64_t)g_cus_hint) break;
+      }
       b.cv.wait_for(lk, std::chrono::microseconds(500));
     }
     std::vector<Ticket*> batch;

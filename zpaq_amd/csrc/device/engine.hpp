@@ -34,6 +34,7 @@ void engine_init(int device);
 // contiguous share [lo, hi) of n blocks for shard k of `parts` (how host batches are split over devices)
 void engine_shard_range(uint64_t n, uint32_t parts, uint32_t k, uint64_t* lo, uint64_t* hi);
 int engine_device_count();
+int engine_count();                      // engines configured by zpq_init (one per device named; a device may be named twice)
 void engine_shutdown();
 void engine_set_budget(uint64_t bytes);
 void engine_set_kernel(int which);

@@ -27,6 +27,10 @@
 namespace zpq {
 
 static const uint32_t kLzMaxMatch = (1u << 14) * 3, kLzMaxLiteral = (1u << 14) / 4;
+// the decision word of a position packs (match length - literals) in bits 0..15, the literals in front in bits 16..23 and the
+// "take it" flag in bit 31 (lz77_search_body / lz77_walk_body): the kernel's contract, checked where the words are made
+static_assert(kLzMaxMatch < 65536u, "an LZ77 match length must fit 16 bits of the decision word");
+static const uint32_t kLzMaxLookahead = 255u;      // literals in front of a match: 8 bits
 
 typedef unsigned long long __attribute__((aligned(1))) lz_u64u;
 
@@ -88,7 +92,7 @@ __device__ __forceinline__ void lz_search(const uint8_t* in, uint32_t n, const u
     const uint32_t need = B.min_match + (B.kind == 2 ? (uint32_t)(off >= (1u << 16)) + (uint32_t)(off >= (1u << 24)) : 0u);
     const bool take = off > 0 && bscore[v] > 0 && blen[v] - blit[v] >= need;
     r[v].x = take ? off : 0u;
-    r[v].y = take ? ((blen[v] - blit[v]) | blit[v] << 16 | 1u << 31) : 0u;
+    r[v].y = take ? ((blen[v] - blit[v]) | (blit[v] & kLzMaxLookahead) << 16 | 1u << 31) : 0u;     // (the engine refuses a larger look-ahead: engine_sort_preprocess)
   }
   r0 = r[0];
   r1 = r[1];

@@ -146,8 +146,8 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen, bool list_only) {
   PlanHeader ph;
   memset(&ph, 0, sizeof(ph));
   ph.n = n;
-  ph.hmask = (1u << hh) - 1;
-  ph.mmask = (1u << hm) - 1;
+  ph.hmask = (uint32_t)((1ull << hh) - 1);        // (hh / hm = 32 is legal when only memory() is asked for: no shift by the type's width)
+  ph.mmask = (uint32_t)((1ull << hm) - 1);
   ph.prog_len = prog_len;
   ph.off_H = seg(4ull << hh, F_ZERO, 0);
   ph.off_M = seg(align_up(1ull << hm, 16), F_ZERO, 0);

@@ -410,7 +410,7 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
   }
   for (size_t ti = 0; ti < tries.size() * 2; ++ti) {
     const int wpg = tries[ti / 2];
-    const bool best_fit = (ti & 1) == 0;
+    const bool best_fit = (ti & 1) == 1;          // (spread the tables when that works: the units that own them are LDS-bound together)
     const int W = std::min(8, total);
     struct Bin { std::vector<int> s; int lds = 0; float cost = 0; };
     std::vector<Bin> bins(wpg);

@@ -85,6 +85,7 @@ std::string make_config(const std::string& xmethod, int args[9]);
 
 // ---- preproc.cpp: compression-side pre-processors (libzpaq.cpp:6450-6883) ----
 void e8e9_forward(U8* buf, U32 n);
+void e8e9_inverse(U8* buf, U32 n);
 std::vector<U32> suffix_array(const U8* in, U32 n);
 // false: the (possibly E8E9-filtered, in place) input itself is coded; true: `out` holds the LZ77 / BWT stream
 // sa = the suffix array of the (E8E9-filtered) block when the caller already has it (built on the device for a whole

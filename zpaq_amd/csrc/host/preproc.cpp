@@ -173,6 +173,19 @@ void e8e9_forward(U8* buf, U32 n) {
   }
 }
 
+// ... and back (what the E8E9 post-processor does, libzpaq.cpp:7302-7324): scans forward, in place.  Used where a filtered
+// caller buffer has to be handed back as it came (zpq_preprocess_blocks_device when the device declines).
+void e8e9_inverse(U8* buf, U32 n) {
+  for (long i = 0; i + 4 < (long)n; ++i) {
+    if ((buf[i] & 254) == 0xe8 && ((buf[i + 4] + 1) & 254) == 0) {
+      const unsigned a = (buf[i + 1] | buf[i + 2] << 8 | buf[i + 3] << 16) - (unsigned)i;
+      buf[i + 1] = (U8)a;
+      buf[i + 2] = (U8)(a >> 8);
+      buf[i + 3] = (U8)(a >> 16);
+    }
+  }
+}
+
 namespace {
 
 // One block through LZ77 (level 1: bit-packed codes, level 2: byte-aligned codes).
