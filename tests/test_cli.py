@@ -50,6 +50,41 @@ def _roundtrip(tmp_path, methods):
             assert _same(src, os.path.join(out, "src")), (m, to)
 
 
+BATCH = os.path.join(ROOT, "oracle", "_ref", "zpaq_amd_cli_batch")
+
+
+def _batch_roundtrip(tmp_path, methods, files=40):
+    """patches/zpaq_batch.patch: `add` hands CompressJob's whole queue to libzpaq::compressBlocks, `extract` decodes every
+    READY block with one libzpaq::decompress call.  Same archive size as the reference's, and each extracts the other's."""
+    if not (os.path.exists(BATCH) and os.path.exists(REF)):
+        pytest.skip("oracle/_ref CLIs not built (no /root/reference here)")
+    src = str(tmp_path / "src")
+    os.makedirs(src)
+    for i in range(files):
+        open(os.path.join(src, f"f{i:03d}.bin"), "wb").write(corpus.block(["text", "lcg", "records", "zeros"][i % 4], 90000 + 7001 * i, 7 + i).tobytes())
+    open(os.path.join(src, "empty"), "wb").write(b"")
+    for m in methods:
+        ours, ref = str(tmp_path / f"batch{m}.zpaq"), str(tmp_path / f"ref{m}.zpaq")
+        for exe, arc in ((BATCH, ours), (REF, ref)):
+            r = subprocess.run([exe, "add", arc, "src", "-method", m, "-threads", "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=1800)
+            assert r.returncode == 0, r.stderr[-2000:]
+        assert os.path.getsize(ours) == os.path.getsize(ref), m
+        for exe, arc, to in ((REF, ours, f"ref_from_batch{m}"), (BATCH, ref, f"batch_from_ref{m}")):
+            out = str(tmp_path / to)
+            r = subprocess.run([exe, "extract", arc, "-to", out, "-threads", "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=1800)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert _same(src, os.path.join(out, "src")), (m, to)
+
+
+def test_patched_archiver_hands_its_queues_to_the_batch_api_host_methods(tmp_path, zlib_):
+    _batch_roundtrip(tmp_path, ["10", "2"])
+
+
+@pytest.mark.gpu
+def test_patched_archiver_hands_its_queues_to_the_batch_api_modelled_methods(tmp_path, gpu):
+    _batch_roundtrip(tmp_path, ["30", "50"], files=24)
+
+
 def test_reference_archiver_on_this_library_host_methods(tmp_path, zlib_):
     """-m0, -m1, -m2 have no context model: the whole path runs on the host (LZ77 + framing)."""
     _roundtrip(tmp_path, ["0", "1", "2"])

@@ -435,6 +435,24 @@ def test_lockstep_decoder(gpu, golden):
             gpu.set_kernel(0)
 
 
+def test_lockstep_decoder_on_the_mixed_corpus_at_its_operating_point(gpu):
+    """BASELINE configs[4] at a quarter of its block size: 2 048 blocks of 256 KiB of configs[3]'s mixed corpus (text, text, LCG,
+    records: two chains, n = 23 and the records blocks' chain with their detected periods) coded by the persistent encoder in
+    two rounds, decoded in ONE launch that fills the GPU -- the engine's own choice of decoders, then the lockstep decoder
+    forced -- every byte compared."""
+    mix = ("text", "text", "lcg", "records")
+    n, bs = 2048, 256 << 10
+    blocks = [corpus.block(mix[i % 4], bs, corpus.BASE_SEED + i) for i in range(n)]
+    want = hashlib.sha1(b"".join(b.tobytes() for b in blocks)).hexdigest()
+    arch = b"".join(gpu.compress_blocks(blocks, "5"))
+    for kernel in (0, 6):
+        gpu.set_kernel(kernel)
+        try:
+            assert hashlib.sha1(gpu.decompress(arch)).hexdigest() == want, kernel
+        finally:
+            gpu.set_kernel(0)
+
+
 def test_4_mib_zeros_known_answer(gpu):
     """4 MiB zeros, method 5 -> 410 B (175 MiB of model state per block)."""
     a, = gpu.compress_blocks([np.zeros(4 << 20, np.uint8)], "5")
@@ -483,14 +501,16 @@ def test_both_shapes_of_the_pipelined_encoder(gpu, oracle, golden, ref, monkeypa
     hipRTC knows run again: whichever shape the engine picks in production has coded every one of these cases on the
     MI355X, bit-identical to the oracle / the reference."""
     monkeypatch.setenv("ZPAQ_AMD_PIPE_MODE", shape)
-    test_encode_matches_oracle_and_golden(gpu, oracle, golden, 4)
     test_all_nine_component_types(gpu, oracle, golden, 4)
-    for idx in (0, 1, 2):
+    for idx in (1, 2):
         test_legacy_min_mid_max_models(gpu, golden, 4, idx)
     test_mixed_plans_in_one_batch_and_ragged_sizes(gpu, oracle)
-    test_large_batch_picks_its_own_kernels(gpu, oracle)
     test_mixed_corpus_batch_against_the_reference(gpu, ref)
-    test_one_mib_records_block_with_detected_periods(gpu, ref)
+    # ... and both launch forms of the forced shape (the persistent launch is the default; the step kernels are what it
+    # falls back to): the golden vectors through the step kernels
+    monkeypatch.setenv("ZPAQ_AMD_PIPE_PERSIST", "0")
+    test_encode_matches_oracle_and_golden(gpu, oracle, golden, 4)
+    monkeypatch.delenv("ZPAQ_AMD_PIPE_PERSIST")
     note = __import__("ctypes").create_string_buffer(256)
     e = golden["config_cases"][0]
     assert gpu.lib().zpq_plan_kernel_kind3(gpu.Plan(bytes.fromhex(e["header"]))._h, 0, 4, note, 256) == 4

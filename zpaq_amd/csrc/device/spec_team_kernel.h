@@ -121,6 +121,18 @@ __device__ __forceinline__ int sp_squash(const TeamTables& T, int p) {         /
 #endif
 constexpr bool team_far_table(unsigned long long bytes) { return bytes > (256u << 10); }   // tables the caches do not hold
 
+// Where a bit-history row lives in THIS decoder's hash tables.  Predictor::find's three candidates of a context are the rows
+// h0, h0 ^ 16, h0 ^ 32 of one 64-byte line (libzpaq.cpp:2072-2088); which line is the decoder's own business as long as it is
+// a bijection on lines (the tables start zeroed and nobody else reads them: the predictions depend on the rows' contents
+// only).  The second nibble of a byte is looked up under c8 = 16 + high nibble, and the lockstep decoder fetches the lines
+// of BOTH values of the nibble's last bit while that bit is decoded: 256 bytes apart in the reference's layout -- two
+// random lines.  With address bits 6 and 8 exchanged they are the two halves of ONE aligned 128-byte line: one DRAM row
+// activation instead of two for 18 of the ~100 lines a decoded byte asks for (profiles/r05: FETCH_SIZE of the decoder).
+__device__ __forceinline__ unsigned team_row_line(unsigned h0, unsigned rmask) {
+  const unsigned t = ((h0 >> 6) ^ (h0 >> 8)) & 1u;
+  return rmask >= 511u ? h0 ^ (t << 6 | t << 8) : h0;
+}
+
 template <int N>
 struct TeamMap {
   int nrows;
@@ -292,7 +304,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         TEAM_PROF_VM((B == 0 ? 8 : 11));                      // what is still in flight from before (B = 4: the early rows)
         const unsigned cx = h + 16u * (unsigned)c8;
         const unsigned chk = (cx >> (sizebits & 31u)) & 255u;
-        const unsigned h0 = (cx * 16u) & (rmask - 15u);
+        const unsigned h0 = team_row_line((cx * 16u) & (rmask - 15u), rmask);
 #if ZPQ_TEAM_EARLY2
         uint4 r0, r1, r2;
         if constexpr (B == 4) {                               // both candidate lines have been on their way since bit 3's [A]
@@ -388,12 +400,12 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         // the second nibble's row will be one of two lines: pull both towards this XCD's L2 now
         const unsigned cxa = h + 16u * (unsigned)c8a, cxb = h + 16u * (unsigned)c8b;
 #if ZPQ_TEAM_EARLY2
-        const unsigned ha = (cxa * 16u) & (rmask - 15u), hb = (cxb * 16u) & (rmask - 15u);
+        const unsigned ha = team_row_line((cxa * 16u) & (rmask - 15u), rmask), hb = team_row_line((cxb * 16u) & (rmask - 15u), rmask);
         ea0 = G128(roff + ha); ea1 = G128(roff + (ha ^ 16u)); ea2 = G128(roff + (ha ^ 32u));
         eb0 = G128(roff + hb); eb1 = G128(roff + (hb ^ 16u)); eb2 = G128(roff + (hb ^ 32u));
 #else
-        touch_a = G32(roff + ((cxa * 16u) & (rmask - 15u)));
-        touch_b = G32(roff + ((cxb * 16u) & (rmask - 15u)));
+        touch_a = G32(roff + team_row_line((cxa * 16u) & (rmask - 15u), rmask));
+        touch_b = G32(roff + team_row_line((cxb * 16u) & (rmask - 15u), rmask));
 #endif
       }
       if constexpr (Chain::ANY_GLOBAL_SIDE && B != 3 && B != 7) {

@@ -195,8 +195,11 @@ void parallel_blocks(size_t n, F&& fn) {
 
 void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool dosha1,
                      std::vector<std::vector<U8>>& archives) {
-  if (!method || !method[0]) fail(ZPQ_E_ARG, "empty method");
   const size_t nb = in.size();
+  for (size_t b = 0; b < nb; ++b) {
+    const char* m = in[b].method ? in[b].method : method;
+    if (!m || !m[0]) fail(ZPQ_E_ARG, "empty method");
+  }
   struct Work {
     std::vector<U8> pp, header;
     RawBytes coded;
@@ -224,7 +227,7 @@ void compress_blocks(const char* method, const std::vector<BlockInput>& in, bool
     Front& f = front[b];
     const U32 n = in[b].n;
     if ((U64)n > 0x7FFFF000ull) fail(ZPQ_E_ARG, "block too large");
-    const std::string xm = expand_method(method, in[b].data, n);
+    const std::string xm = expand_method(in[b].method ? in[b].method : method, in[b].data, n);
     const std::string cfg = make_config(xm, f.args);
     f.as = assemble(cfg.c_str(), f.args);
     // The segment trailer carries the SHA-1 of the ORIGINAL block.  A modelled block that is coded as it is goes to the

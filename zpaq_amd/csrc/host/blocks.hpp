@@ -13,6 +13,7 @@ struct BlockInput {
   U32 n;
   const char* filename;   // may be null
   const char* comment;    // may be null; appended to the decimal size
+  const char* method = nullptr;   // this block's own method (null: the call's)
 };
 
 // Wall-clock phases of the last compress_blocks call of this process (the end-to-end figure SURVEY section 8(d)

@@ -110,6 +110,26 @@ void compressBlocks(StringBuffer* const* in, Writer* const* out, int n, const ch
   }
 }
 
+// ... with a method per block (what an archiver's block queue holds: zpaq.cpp gives every block its own redundancy / type hints)
+void compressBlocks(StringBuffer* const* in, Writer* const* out, int n, const char* const* methods,
+                    const char* const* filename, const char* const* comment, bool dosha1) {
+  if (n <= 0) return;
+  if (!methods) error("compressBlocks: no methods");
+  std::vector<zpq::BlockInput> inputs((size_t)n);
+  for (int i = 0; i < n; ++i)
+    inputs[i] = zpq::BlockInput{in[i]->data(), (U32)in[i]->size(), filename ? filename[i] : 0, comment ? comment[i] : 0, methods[i]};
+  std::vector<std::vector<U8>> archives;
+  guarded([&] { zpq::compress_blocks(nullptr, inputs, dosha1, archives); });
+  for (int i = 0; i < n; ++i) {
+    size_t pos = 0;
+    while (pos < archives[i].size()) {
+      const size_t k = std::min<size_t>(archives[i].size() - pos, 1u << 30);
+      out[i]->write((const char*)archives[i].data() + pos, (int)k);
+      pos += k;
+    }
+  }
+}
+
 // compress (reference libzpaq.cpp:3008-3031): the stream is cut into blocks of
 // 2^(20+B)-4096 bytes; here up to kBatch blocks are gathered per device batch.
 void compress(Reader* in, Writer* out, const char* method, const char* filename, const char* comment,
