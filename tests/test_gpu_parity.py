@@ -639,11 +639,11 @@ def test_eight_engines_on_one_gpu_shard_an_uneven_batch(gpu):
             "import zpaq_amd as z\n"
             "from zpaq_amd import corpus\n"
             "n = 1027\n"
-            "blocks = [corpus.block(['text', 'lcg', 'records', 'zeros'][i %% 4], 1500 + (i * 37) %% 2500, 900 + i) for i in range(n)]\n"
+            "blocks = [corpus.block(['text', 'lcg', 'pattern', 'zeros'][i %% 4], 1500 + (i * 37) %% 2500, 900 + i) for i in range(n)]\n"
             "z.init(-1 if os.environ.get('ZPAQ_AMD_DEVICES') else 0)\n"
             "arch = z.compress_blocks(blocks, '5')\n"
             "assert z.decompress(b''.join(arch[:40])) == b''.join(b.tobytes() for b in blocks[:40])\n"
-            "print('DIGEST', hashlib.sha1(b''.join(arch)).hexdigest(), len(arch), z.device_count())\n" % ROOT)
+            "print('DIGEST', hashlib.sha1(b''.join(arch)).hexdigest(), len(arch), z.lib().zpq_engine_count())\n" % ROOT)
     outs = []
     for devs in (None, "0,0,0,0,0,0,0,0"):
         env = {k: v for k, v in os.environ.items() if k != "ZPAQ_AMD_DEVICES"}

@@ -284,6 +284,11 @@ static int precompile_in_processes(const std::vector<JitItem>& todo, int procs, 
 
 int spec_precompile(const std::vector<const zpq_plan*>& plans, bool pipe, int variant, int max_compiles, int threads,
                     std::string* log, const std::vector<int>* modes) {
+  // one caller at a time in the whole process: every call starts up to `threads` helper processes (hipRTC + the code
+  // generator's libraries each), and the engines of a multi-device process all come here at once with the same chains --
+  // whoever waited finds them in the in-process store afterwards
+  static std::mutex one_at_a_time;
+  std::lock_guard<std::mutex> turn(one_at_a_time);
   std::vector<JitItem> todo;
   std::vector<std::string> seen;
   for (size_t pi = 0; pi < plans.size(); ++pi) {
