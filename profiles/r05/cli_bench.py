@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05", "cli.json"))
     ap.add_argument("--unpatched-threads", default="64")
     ap.add_argument("--timeout", type=float, default=240.0)
+    ap.add_argument("--keep", action="store_true", help="leave the work directory (the tree of files) behind")
+    ap.add_argument("--quick", action="store_true", help="only the patched archiver (add twice, extract), with the library's one line per device batch (ZPAQ_AMD_LOG)")
     a = ap.parse_args()
     import torch
     from zpaq_amd import corpus, corpus_torch
@@ -45,7 +47,8 @@ def main():
     def run(exe, args, label, threads, check_tree=None):
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([exe] + args + ["-threads", str(threads)], cwd=a.work, capture_output=True, text=True, timeout=a.timeout)
+            env = dict(os.environ, ZPAQ_AMD_LOG="1", ZPAQ_AMD_PERSIST_PROF=os.path.join(os.path.dirname(a.out), "cli_prof_%d.bin" % len(rows))) if a.quick else None
+            r = subprocess.run([exe] + args + ["-threads", str(threads)], cwd=a.work, capture_output=True, text=True, timeout=a.timeout, env=env)
         except subprocess.TimeoutExpired:
             rows.append({"what": label, "threads": threads, "timeout_s": a.timeout})
             print(json.dumps(rows[-1]), flush=True); save()
@@ -54,6 +57,9 @@ def main():
         row = {"what": label, "threads": threads, "wall_s": wall, "MBps": total / 1e6 / wall, "rc": r.returncode}
         if r.returncode:
             row["stderr"] = r.stderr[-600:]
+        if a.quick:
+            row["library_log"] = [l for l in r.stderr.splitlines() if l.startswith("[zpaq_amd]")]
+            row["archiver_says"] = [l for l in (r.stdout + r.stderr).splitlines() if "seconds" in l][-2:]
         if check_tree and os.path.isdir(os.path.join(check_tree, "tree")):
             c = filecmp.dircmp(tree, os.path.join(check_tree, "tree"))
             _, mism, errs = filecmp.cmpfiles(tree, os.path.join(check_tree, "tree"), c.common_files, shallow=False)
@@ -67,6 +73,11 @@ def main():
     run(batch, ["add", A("w.zpaq"), "tree", "-method", "50"], "zpaq_amd_cli_batch add -method 50 (first call of the box: code objects, page-locked buffers)", 4)
     run(batch, ["add", A("batch.zpaq"), "tree", "-method", "50"], "zpaq_amd_cli_batch add -method 50", 4)
     rows[-1]["archive_bytes"] = os.path.getsize(A("batch.zpaq")) if os.path.exists(A("batch.zpaq")) else None
+    if a.quick:
+        run(batch, ["extract", A("batch.zpaq"), "-to", A("x_batch")], "zpaq_amd_cli_batch extract (its own archive)", 4, A("x_batch"))
+        save()
+        if not a.keep: shutil.rmtree(a.work, ignore_errors=True)
+        return
     run(ref, ["add", A("ref.zpaq"), "tree", "-method", "50"], "zpaq_ref_cli add -method 50", 16)
     rows[-1]["archive_bytes"] = os.path.getsize(A("ref.zpaq")) if os.path.exists(A("ref.zpaq")) else None
     for T in [int(x) for x in a.unpatched_threads.split(",") if x]:

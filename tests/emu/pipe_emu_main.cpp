@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
     l.a.prog = prog.data(); l.a.group_chunks = gchunks.data(); l.a.ctl = ctl.data();
     l.a.group0 = 0; l.a.ngroups_here = ngroups; l.a.timeout_ticks = 200000;
     l.a.spread = ngroups > 1 ? 2 : 1;          // (the device spreads over its 8 XCDs: here two, so that the mapping is exercised)
-    emu::run_grid(kernel_thunk, &l, 64 * waves, l.a.spread * ((ngroups + l.a.spread - 1) / l.a.spread) * wpg, 0);
+    emu::run_grid(kernel_thunk, &l, 64 * waves, ngroups * wpg, 0);
     if (ctl[0]) { fprintf(stderr, "pipe_emu_run: the persistent launch aborted (slot %u, chunk %u)\n", ctl[1], ctl[2]); return 4; }
   } else {
   const unsigned grids[6] = {(nb + hl - 1) / hl, nrows * ngroups, nlight * ngroups, nicm * ngroups, nisse * ngroups, mixw * ngroups};

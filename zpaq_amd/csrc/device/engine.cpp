@@ -623,19 +623,28 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
   *aborted = false;
   std::lock_guard<std::mutex> device_turn(persist_device_mutex(e.device >= 0 ? e.device : e.slot));
   // what the device holds
-  uint64_t need_wg = 0;
   std::vector<uint32_t> cap(runs.size());
   for (size_t i = 0; i < runs.size(); ++i) {
     PipeRun& r = runs[i];
     cap[i] = persist_capacity(e, r);
-    need_wg += (uint64_t)r.ngroups * r.ps_wpg;
     if (cap[i] < r.ps_wpg) return false;
   }
-  // several runs: only side by side (a second round costs a whole block's serial time whatever it holds)
+  // Several runs: only side by side (a second round costs a whole block's serial time whatever it holds).  The dispatcher deals
+  // the workgroups of a launch round-robin over the 8 XCDs and does not look for room elsewhere, so what has to fit is every
+  // XCD's share of every run.  (Measured with the archiver's batch of 14 + 2 groups, calls 24-27: sized against the device as a
+  // whole -- 238 of 256 compute units -- the short run found 2 free compute units per XCD on six XCDs where it needed 3-4,
+  // sat half resident until the long one ended, and the batch took the sum of both: 3.2 s instead of 1.7.)
+  auto per_xcd = [](const PipeRun& r, uint32_t spread) {
+    if (spread >= 8) return (r.ngroups / 8) * r.ps_wpg + ((r.ngroups % 8) * r.ps_wpg + 7) / 8;
+    return (r.ngroups * r.ps_wpg + 7) / 8;
+  };
   if (runs.size() > 1) {
-    uint32_t c = cap[0];
-    for (uint32_t x : cap) c = std::min(c, x);
-    if (need_wg > c) return false;
+    uint32_t share = 0, room = 0xFFFFFFFFu;
+    for (size_t i = 0; i < runs.size(); ++i) {
+      share += per_xcd(runs[i], runs[i].ngroups >= 8 ? 8u : 1u);
+      room = std::min(room, cap[i] / 8);
+    }
+    if (share > room) return false;
   }
   // control block per run: [ctl 4 words][group_chunks ngroups][prog ngroups * nunit]
   uint64_t words = 0;
@@ -657,9 +666,11 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
   unsigned long long* d_prof = nullptr;
   uint64_t prof_words = 0;
   uint32_t prof_nslot = 0;
+  size_t prof_run = 0;                               // ZPAQ_AMD_PERSIST_PROF_RUN: which run of the batch (default the first)
+  if (const char* v = getenv("ZPAQ_AMD_PERSIST_PROF_RUN")) prof_run = std::min<size_t>((size_t)atoi(v), runs.empty() ? 0 : runs.size() - 1);
   if (prof_path && prof_path[0] && !runs.empty()) {
-    prof_nslot = runs[0].ps_nslot;
-    prof_words = 4ull * runs[0].ngroups * prof_nslot;
+    prof_nslot = runs[prof_run].ps_nslot;
+    prof_words = 4ull * runs[prof_run].ngroups * prof_nslot;
     HIP_CHECK(hipMalloc((void**)&d_prof, prof_words * 8));
     HIP_CHECK(hipMemset(d_prof, 0, prof_words * 8));
   }
@@ -689,8 +700,9 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
       a.ngroups_here = std::min(per_round, r.ngroups - g0);
       a.timeout_ticks = timeout;
       a.spread = a.ngroups_here >= 8 ? 8u : 1u;
-      a.trace = i == 0 ? d_prof : nullptr;
-      const uint32_t grid = a.spread * ((a.ngroups_here + a.spread - 1) / a.spread) * r.ps_wpg;
+      if (const char* v = getenv("ZPAQ_AMD_PERSIST_SPREAD")) a.spread = atoi(v) == 8 ? 8u : 1u;      // (experiments)
+      a.trace = i == prof_run ? d_prof : nullptr;
+      const uint32_t grid = a.ngroups_here * r.ps_wpg;
       void* args[1] = {(void*)&a};
       HIP_CHECK(hipModuleLaunchKernel(r.k->persist, grid, 1, 1, 64u * r.ps_waves, 1, 1, 0, rs, args, nullptr));
     }
@@ -706,7 +718,7 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
     HIP_CHECK(hipMemcpy(hp.data(), d_prof, prof_words * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_prof);
     if (FILE* f = fopen(prof_path, "wb")) {
-      const unsigned long long hdr[4] = {runs[0].ngroups, prof_nslot, runs[0].ps_waves, runs[0].ps_wpg};
+      const unsigned long long hdr[4] = {runs[prof_run].ngroups, prof_nslot, runs[prof_run].ps_waves, runs[prof_run].ps_wpg};
       fwrite(hdr, 8, 4, f);
       fwrite(hp.data(), 8, prof_words, f);
       fclose(f);
@@ -929,6 +941,18 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     }
   }
   e.last_persist = coded;
+  if (getenv("ZPAQ_AMD_LOG") && !runs.empty()) {
+    std::string d;
+    for (PipeRun& r : runs)
+    {
+      uint32_t longest = 0;
+      for (uint32_t c : r.group_chunks) longest = std::max(longest, c);
+      d += " [" + std::to_string(r.ngroups) + " groups x " + std::to_string(r.ps_wpg) + " workgroups, device holds " +
+           std::to_string(r.k->persist ? persist_capacity(e, r) : 0u) + ", longest group " + std::to_string(longest) + " chunks]";
+    }
+    fprintf(stderr, "[zpaq_amd] pipelined encoder: %zu chain(s)%s -> %s\n", runs.size(), d.c_str(),
+            coded ? "one persistent launch each, side by side" : "step kernels");
+  }
   if (!coded) launch_pipe(e, runs, st, late);
   for (size_t k = 0; k < nside; ++k) {          // join the side streams back into `st`
     Event done;

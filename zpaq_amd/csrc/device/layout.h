@@ -160,7 +160,8 @@ struct PipeArgs {
   uint32_t* ctl;                  // [0] abort flag (zero at launch), [1] the slot whose watchdog fired, [2] its chunk
   uint32_t group0, ngroups_here;  // the groups this launch serves
   uint32_t timeout_ticks;         // 100 MHz ticks a poller waits without progress before it raises the abort flag
-  uint32_t spread;                // workgroup b serves group group0 + b % spread + spread * (b / spread / PS_WPG): 8 = one XCD per group
+  uint32_t spread;                // 8: the workgroups of a group share an XCD (workgroup b of the first 8 * (ngroups / 8) groups serves group
+                                  // b % 8 + 8 * (b / 8 / PS_WPG); the other groups' workgroups follow one after the other); 1: group b / PS_WPG
 };
 
 // LDS plan of the specialised kernel (spec_kernel.h), known to the host code

@@ -1338,16 +1338,36 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
   typedef __attribute__((address_space(1))) SegRange g_seg;
   g_seg* const segs = (g_seg*)L.segs;
   if (multi) seg_end = segs[seg].in_end;
+  // coded bytes leave through a small buffer: {ob_hi, ob_lo} holds the last n - nf bytes (the newest in the lowest place),
+  // four go out in one store.  A byte store per coded byte was most of the shift-out loop -- which every lane of the
+  // wavefront sits through whenever one of them has a byte to emit -- and the coder is the slowest unit of a short chain.
+  // Lanes flush together once per input byte; inside a byte only a lane about to run out of room (rare) does.
+  typedef unsigned __attribute__((aligned(1))) u32u;
+  typedef __attribute__((address_space(1))) u32u g_u32u;
+  unsigned ob_hi = 0, ob_lo = 0;
+  unsigned nf = n;
+  auto flush4 = [&]() __attribute__((always_inline)) {
+    const unsigned sh = 8u * (n - nf - 4u);                                  // 0 .. 32: the four oldest bytes start there
+    const unsigned w4 = sh >= 32u ? ob_hi : (unsigned)((((unsigned long long)ob_hi << 32) | ob_lo) >> sh);
+    if (nf + 4u <= L.out_cap) *(g_u32u*)(L.out + nf) = __builtin_bswap32(w4);  // (the oldest byte is the top one)
+    else for (unsigned i = 0; i < 4u; ++i) if (nf + i < L.out_cap) L.out[nf + i] = (unsigned char)(w4 >> (24u - 8u * i));
+    nf += 4u;
+  };
+  auto flush_all = [&]() __attribute__((always_inline)) {
+    if (n - nf >= 4u) flush4();
+    for (; nf < n; ++nf) if (nf < L.out_cap) L.out[nf] = (unsigned char)(ob_lo >> (8u * (n - nf - 1u)));
+  };
   auto encode = [&](int y, unsigned pr) __attribute__((always_inline)) {
     const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
     if (y) high = mid; else low = mid + 1;
     while ((high ^ low) < 0x1000000u) {
-      if (n < L.out_cap) L.out[n] = (unsigned char)(high >> 24);
+      ob_hi = (ob_hi << 8) | (ob_lo >> 24);
+      ob_lo = (ob_lo << 8) | (high >> 24);
       ++n;
       high = high << 8 | 255u;
-      low = low << 8;
-      low += (low == 0);
+      low = max(low << 8, 1u);                 // (low << 8, and 1 where that is 0)
     }
+    if (n - nf > 4u) flush4();                 // (an encode emits at most 4 bytes and finds at most 4 waiting: the buffer holds 8)
   };
   if (L.nb) {
     unsigned byte = L.byte_at(0);
@@ -1371,7 +1391,10 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
       for (int B = 0; B < 8; ++B) prs[B] = (unsigned)squash(sp_clamp2k(pipe_p_get(v, B))) * 2u + 1u;
       encode(0, 0);
 #pragma unroll
-      for (int B = 0; B < 8; ++B) encode(pipe_y(byte, B), prs[B]);
+      for (int B = 0; B < 8; ++B) {
+        encode(pipe_y(byte, B), prs[B]);
+      }
+      if (n - nf >= 4u) flush4();
       byte = byten; v = vn;
     }
   }
@@ -1381,12 +1404,14 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
       while (seg + 1 < L.nseg) { encode(1, 0); segs[seg].out_end = n; ++seg; }     // trailing empty segments
     }
     if (!status) encode(1, 0);
+    flush_all();
     if (multi) segs[seg].out_end = n;
     if (!status && n > L.out_cap) status = 3;
     BlockResult r;
     r.out_len = n; r.consumed = L.len; r.status = status; r.steps = 8u * L.len;
     a.res[L.rslot] = r;
   } else {
+    flush_all();
     L.state(sw + 0) = low; L.state(sw + 1) = high; L.state(sw + 2) = n; L.state(sw + 3) = seg;
   }
 }

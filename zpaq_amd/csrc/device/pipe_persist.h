@@ -27,8 +27,8 @@
 // kernels).  Should a workgroup nevertheless not get a CU, the pollers give up after PipeArgs::timeout_ticks without
 // progress, raise the abort word and exit; the engine then codes the batch with the six kernels.  The launch cannot hang.
 //
-// Blocks-to-XCD: workgroup b serves group (b % 8) + 8 * (b / 8 / PS_WPG) (PipeArgs::spread = 8), so the workgroups of a group share an XCD (and
-// its L2) when the dispatcher deals workgroups round-robin over the XCDs, as it is observed to do.  A speed choice only.
+// Blocks-to-XCD: with PipeArgs::spread = 8 the workgroups of a group are 8 apart in the grid, so they share an XCD (and its L2)
+// when the dispatcher deals workgroups round-robin over the XCDs, as it is observed to do (pipe_persist_body).  A speed choice only.
 #pragma once
 #include "pipe_kernel.h"
 
@@ -247,10 +247,17 @@ __device__ __forceinline__ void pipe_persist_body(const PipeArgs& a) {
   ro.squash.load(a.tb, tid);
   ro.stretch.load(a.tb, tid);
   __syncthreads();
-  // workgroup -> (group, flavour): the workgroups of a group on one XCD when workgroups are dealt round-robin
-  const unsigned b = blockIdx.x, nx = a.spread ? a.spread : 1u;
-  const unsigned x = b % nx, j = b / nx;
-  const unsigned g = a.group0 + x + nx * (j / (unsigned)Chain::PS_WPG), flavour = j % (unsigned)Chain::PS_WPG;
+  // workgroup -> (group, flavour).  The dispatcher deals the workgroups of a launch round-robin over the XCDs (from where the
+  // launch before left off: which XCD a residue class lands on is not known, that a class shares one is): with spread = 8 the
+  // workgroups of a group are one class, for as many groups as make whole sets of 8; the remaining groups' workgroups follow
+  // one after the other, so that every XCD gets the same number of workgroups of a launch whatever its group count (a second
+  // run beside this one finds the same room everywhere) and the grid has no idle workgroups.
+  const unsigned b = blockIdx.x, nx = a.spread ? a.spread : 1u, W = (unsigned)Chain::PS_WPG;
+  const unsigned whole = a.ngroups_here - a.ngroups_here % nx;
+  unsigned g, flavour;
+  if (b < whole * W) { const unsigned j = b / nx; g = b % nx + nx * (j / W); flavour = j % W; }
+  else { const unsigned r = b - whole * W; g = whole + r / W; flavour = r % W; }
+  g += a.group0;
   if (g >= a.group0 + a.ngroups_here) return;
   const int slot = (int)flavour * Chain::PS_WAVES + wave;
   static_for<0, Chain::PS_NSLOT>([&](auto sc) __attribute__((always_inline)) {
