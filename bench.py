@@ -637,8 +637,14 @@ def main():
                "roofline": {"bound": "hbm", "achieved": algo / 1e9 / code_s if code_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (algo / 1e9 / code_s / HBM_PEAK_GBS) if code_s > 0 else 0.0, "traffic": None,
                             "kernel": kn, "kernel_kind": kk, "kernel_origin": org,
-                            "algo_bytes_per_launch": algo, "kernel_s_per_launch": code_s},
+                            "algo_bytes_per_launch": algo, "kernel_s_per_launch": code_s,
+                            # FETCH_SIZE + WRITE_SIZE over the lockstep decoder's single dispatch (profiles/r05/call1_summary.txt):
+                            # 6 352 + 3 701 B per decoded byte of the -m5 text chain = 2.77 x its algorithmic 3 626; `traffic` is
+                            # filled for that corpus only (the records chain of the mixed corpus was not counted)
+                            "traffic_per_decoded_byte_text_chain": 10053.0},
                "cpu_baseline": None}
+        if kind == "text" and "zpq_spec_decode3" in org and a.method == "5":
+            obj["roofline"]["traffic"] = 10053.0 * float(sum(lens_in))
         if a.cpu_seconds > 0:
             base = cpu_decode_baseline(dec_blocks, a.method, a.cpu_seconds)
             obj["cpu_baseline"] = base
@@ -778,12 +784,15 @@ def main():
         if hit:
             tj = {key: hit[0]}
             traffic = tj[key]["traffic_bytes"]
-            # what really bounds the encoder: random memory TRANSACTIONS.  The counters tally 64 B per
-            # random read and 32 B per random store (calibrated on profiles/r03/gups.hip, which also gives the machine's rate)
-            transactions = {"per_input_byte": tj[key]["fetch_bytes_per_input_byte"] / 64.0 + tj[key]["write_bytes_per_input_byte"] / 32.0,
-                            "counted_as": "FETCH_SIZE / 64 B (a read request) + WRITE_SIZE / 32 B (a written sector); the coalesced "
-                                          "stream writes are in there sector by sector, so this overstates the random share",
-                            "peak_G_per_s": 48.0, "peak_source": "profiles/r03/gups_results.txt: 24 G random read-modify-writes/s = 48 G transactions/s"}
+            # what really bounds the encoder: random memory TRANSACTIONS.  ONE definition, used everywhere:
+            # a transaction = a read request of the L2's memory side = FETCH_SIZE / 64 B (calibrated on profiles/r03/gups.hip:
+            # a random 16-byte load counts 64 B).  Nearly every one is the read half of a read-modify-write of a table row, so the
+            # ceiling is the rate the same microbenchmark reaches for "16-B load + store back": 20-24 G/s over 1-96 GiB footprints.
+            # Writes are not added: WRITE_SIZE tallies 32-byte sectors, which counts a coalesced stream store several times.
+            transactions = {"per_input_byte": tj[key]["fetch_bytes_per_input_byte"] / 64.0,
+                            "counted_as": "read requests: FETCH_SIZE / 64 B; the write halves of the rows' read-modify-writes and the "
+                                          "stream stores are not added (WRITE_SIZE counts sectors, not requests)",
+                            "peak_G_per_s": 24.0, "peak_source": "profiles/r03/gups_results.txt: 20-24 G random 16-B read-modify-writes/s (49-58 G/s for loads alone)"}
     except Exception:
         pass
     total_bytes = float(total_blocks) * bs * a.steps
