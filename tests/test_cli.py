@@ -17,10 +17,10 @@ REF = os.path.join(ROOT, "oracle", "_ref", "zpaq_ref_cli")
 
 def _tree(root):
     os.makedirs(os.path.join(root, "sub"))
-    open(os.path.join(root, "a.txt"), "wb").write(corpus.block("text", 900000, 1).tobytes())
+    open(os.path.join(root, "a.txt"), "wb").write(corpus.block("text", 300000, 1).tobytes())
     open(os.path.join(root, "b.bin"), "wb").write(corpus.block("lcg", 150000, 2).tobytes())
-    open(os.path.join(root, "sub", "c.rec"), "wb").write(corpus.block("records", 400000, 3).tobytes())
-    open(os.path.join(root, "sub", "d.txt"), "wb").write(corpus.block("text", 70000, 4).tobytes() * 3)
+    open(os.path.join(root, "sub", "c.rec"), "wb").write(corpus.block("records", 160000, 3).tobytes())
+    open(os.path.join(root, "sub", "d.txt"), "wb").write(corpus.block("text", 40000, 4).tobytes() * 3)
     open(os.path.join(root, "sub", "empty"), "wb").write(b"")
 
 
