@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05", "cli.json"))
     ap.add_argument("--unpatched-threads", default="64")
     ap.add_argument("--timeout", type=float, default=240.0)
+    ap.add_argument("--skip-unpatched-extract", action="store_true", help="the unpatched archiver's extract takes ~85 s of GPU time: leave it out")
     ap.add_argument("--keep", action="store_true", help="leave the work directory (the tree of files) behind")
     ap.add_argument("--quick", action="store_true", help="only the patched archiver (add twice, extract), with the library's one line per device batch (ZPAQ_AMD_LOG)")
     a = ap.parse_args()
@@ -84,7 +85,7 @@ def main():
         run(ours, ["add", A(f"ours{T}.zpaq"), "tree", "-method", "50"], "zpaq_amd_cli (unpatched) add -method 50", T)
     run(batch, ["extract", A("ref.zpaq"), "-to", A("x_batch")], "zpaq_amd_cli_batch extract (the reference's archive)", 4, A("x_batch"))
     run(ref, ["extract", A("batch.zpaq"), "-to", A("x_ref")], "zpaq_ref_cli extract (the batch archiver's archive)", 16, A("x_ref"))
-    for T in [int(x) for x in a.unpatched_threads.split(",") if x]:
+    for T in [] if a.skip_unpatched_extract else [int(x) for x in a.unpatched_threads.split(",") if x]:
         run(ours, ["extract", A("ref.zpaq"), "-to", A("x_ours")], "zpaq_amd_cli (unpatched) extract (the reference's archive)", max(T, 256), A("x_ours"))
     save()
     shutil.rmtree(a.work, ignore_errors=True)
