@@ -96,6 +96,7 @@ struct Engine {
   hipStream_t stream = nullptr;
   DeviceTables* d_tables = nullptr;
   uint64_t budget = 0;
+  unsigned sharers = 1;          // engines configured on this engine's physical device (ZPAQ_AMD_DEVICES may name one twice)
   int kernel_choice = 0;
   DevBuf arena, io_in, io_out, jobs, results;
   DevBuf segs;                         // segment tables of multi-segment blocks
@@ -217,8 +218,12 @@ void engine_init_device(Engine& e, int slot, int device) {
   HIP_CHECK(hipMemcpy(e.d_tables, &host_tb, sizeof(DeviceTables), hipMemcpyHostToDevice));
   size_t free_b = 0, total_b = 0;
   HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); e.budget = d.budget_override; e.kernel_choice = d.kernel_choice; }
-  if (!e.budget) e.budget = (uint64_t)(free_b * 0.85);
+  // engines that share one physical device (ZPAQ_AMD_DEVICES=0,0,..) share its memory: each budgets its part of what is free
+  unsigned sharers = 0;
+  { DeviceSet& d = devset(); std::lock_guard<std::mutex> g(d.mu); e.budget = d.budget_override; e.kernel_choice = d.kernel_choice;
+    for (int x : d.dev_of) sharers += x == device; }
+  e.sharers = sharers ? sharers : 1u;
+  if (!e.budget) e.budget = (uint64_t)(free_b * 0.85 / e.sharers);
   e.device = device;
   e.slot = slot;
   e.ready = true;
@@ -289,7 +294,7 @@ void engine_shutdown() {
     if (!e.ready) continue;
     (void)hipSetDevice(e.device);
     (void)hipStreamSynchronize(e.stream);
-    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release(); e.pin_in.release(); e.pin_out.release();
+    e.arena.release(); e.io_in.release(); e.io_out.release(); e.jobs.release(); e.results.release(); e.pipe.release(); e.sha_jobs.release(); e.sha_out.release(); e.segs.release(); e.pin_in.release(); e.pin_out.release(); e.pipe_ctl.release();
     for (auto& ps : e.pstream) { if (ps) (void)hipStreamDestroy(ps); ps = nullptr; }
     for (auto& ss : e.side) (void)hipStreamDestroy(ss);
     e.side.clear();
@@ -311,7 +316,7 @@ void engine_set_budget(uint64_t bytes) {
     if (bytes) { e.budget = bytes; continue; }
     size_t free_b = 0, total_b = 0;
     if (hipSetDevice(e.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      e.budget = (uint64_t)((free_b + e.arena.cap + e.pipe.cap + e.io_in.cap + e.io_out.cap) * 0.85);     // (what the engine holds itself counts as free)
+      e.budget = (uint64_t)((free_b / e.sharers + e.arena.cap + e.pipe.cap + e.io_in.cap + e.io_out.cap) * 0.85);     // (what the engine holds itself counts as free)
   }
 }
 void engine_set_kernel(int which) {
