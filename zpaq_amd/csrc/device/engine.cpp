@@ -374,6 +374,12 @@ static const uint32_t kLongStepBytes = 128u << 10;       // latency shape: block
 // 256 MB Infinity Cache instead of HBM.  Measured (profiles/r03/call10_summary.txt): -m3's n = 2 chain on 256 blocks
 // (29 MB per step) 483 -> 440 ms; -m5 (588 B per byte) +4 % at 64 blocks (77 MB), +6 % at 512 (616 MB), -20 % at 640.
 static const uint64_t kLongStepStreamBytes = 96ull << 20;
+// Workgroups of a persistent launch of `groups` groups x `wpg` workgroups that one XCD gets (the dispatcher deals a launch's
+// workgroups round-robin over the 8 XCDs; pipe_persist.h maps whole sets of 8 groups one group per XCD, the rest in launch order)
+static uint32_t persist_xcd_share(uint64_t groups, uint64_t wpg) {
+  if (groups >= 8) return (uint32_t)((groups / 8) * wpg + ((groups % 8) * wpg + 7) / 8);
+  return (uint32_t)((groups * wpg + 7) / 8);
+}
 static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte, const zpq_plan* plan = nullptr) {
   bool latency = blocks_of_plan <= kLatencyModeBlocks;
   // With the persistent launch the shapes differ in how many workgroups a group of blocks needs (-m5: 14 against 8): the
@@ -639,14 +645,10 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
   // XCD's share of every run.  (Measured with the archiver's batch of 14 + 2 groups, calls 24-27: sized against the device as a
   // whole -- 238 of 256 compute units -- the short run found 2 free compute units per XCD on six XCDs where it needed 3-4,
   // sat half resident until the long one ended, and the batch took the sum of both: 3.2 s instead of 1.7.)
-  auto per_xcd = [](const PipeRun& r, uint32_t spread) {
-    if (spread >= 8) return (r.ngroups / 8) * r.ps_wpg + ((r.ngroups % 8) * r.ps_wpg + 7) / 8;
-    return (r.ngroups * r.ps_wpg + 7) / 8;
-  };
   if (runs.size() > 1) {
     uint32_t share = 0, room = 0xFFFFFFFFu;
     for (size_t i = 0; i < runs.size(); ++i) {
-      share += per_xcd(runs[i], runs[i].ngroups >= 8 ? 8u : 1u);
+      share += persist_xcd_share(runs[i].ngroups, runs[i].ps_wpg);
       room = std::min(room, cap[i] / 8);
     }
     if (share > room) return false;
@@ -1012,7 +1014,7 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
   // that frees the most first, until the batch fits
   const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
   if (cnt.size() > 1 && !(pp && !strcmp(pp, "0")) && !getenv("ZPAQ_AMD_PIPE_MODE")) {
-    struct Need { const zpq_plan* p; uint64_t lat, thr; };
+    struct Need { const zpq_plan* p; uint64_t lat, thr; };      // what an XCD has to hold of the chain in either shape
     std::vector<Need> need;
     bool all = true;
     for (auto& kv : cnt) {
@@ -1020,13 +1022,13 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
       std::string why;
       if (!pipe_layout(*kv.first, pipe_options(0), L0, why) || !L0.persist_ok || !pipe_layout(*kv.first, pipe_options(1), L1, why) || !L1.persist_ok) { all = false; break; }
       const uint64_t groups = (kv.second.first + (uint32_t)L0.G - 1) / (uint32_t)L0.G;
-      need.push_back(Need{kv.first, groups * (uint64_t)L1.ps_wpg, groups * (uint64_t)L0.ps_wpg});
+      need.push_back(Need{kv.first, persist_xcd_share(groups, (uint64_t)L1.ps_wpg), persist_xcd_share(groups, (uint64_t)L0.ps_wpg)});
     }
     if (all) {
       for (;;) {
         uint64_t total = 0;
         for (const Need& n : need) total += mode[n.p] == 0 ? n.thr : n.lat;
-        if (total <= (uint64_t)g_cus_hint) break;
+        if (total <= (uint64_t)g_cus_hint / 8) break;             // (launch_pipe_persist's rule: every XCD's share of every run fits)
         const Need* best = nullptr;
         for (const Need& n : need)
           if (mode[n.p] != 0 && n.lat > n.thr && (!best || n.lat - n.thr > best->lat - best->thr)) best = &n;
