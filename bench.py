@@ -345,7 +345,9 @@ def main():
                          "mixed on several (configs[3]: text, text, LCG, records by block index mod 4)")
     ap.add_argument("--method", default="5")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=None,
+                    help="wall budget of the cpu_baseline leg (0 = skip; default 15 on one GPU, 0 on several: the contract asks for the "
+                         "CPU baseline on rank 0 at N = 1 only)")
     ap.add_argument("--api-blocks", type=int, default=-1,
                     help="blocks of the end-to-end API leg on host buffers (-1 = the whole batch, 0 = skip)")
     ap.add_argument("--verify-blocks", type=int, default=-1, help="blocks decoded back on the device (-1: every block of the batch)")
@@ -369,6 +371,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="the N-rank flow on CPU: gloo, a method without a model (scatter, code, gather, one line with dist_ms); no GPU needed")
     a = ap.parse_args()
+    if a.cpu_seconds is None:
+        a.cpu_seconds = 15.0 if a.gpus == 1 else 0.0
     if a.dry_run:
         return dry_run_bench(a)
     if a.blocks is None:
