@@ -232,6 +232,39 @@ def in_library_bench(a, torch, z):
 
 
 
+def configs1_leg(cpu_seconds, timeout_s=150.0):
+    """BASELINE configs[1] beside the headline: method "3" (LZ77 through the suffix array + the n = 2 chain ICM, ISSE) over
+    256 x 256 KiB LCG blocks, by THIS script in a child process (its own engine; what this process holds stays where it is):
+    device-resident `value`, the end-to-end `api` figure, roofline, the reference on the host cores.  A failing child leaves
+    an {"error": ...} object: the headline line must survive its side legs."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--method", "3", "--kind", "lcg", "--blocks", "256", "--block-bytes", "262144",
+           "--decode-blocks", "0", "--configs1", "0", "--cpu-seconds", str(cpu_seconds)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode or not lines:
+            return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-400:]}
+        d = json.loads(lines[-1])
+        keep = ("metric", "value", "unit", "ms_per_step", "all_status_ok", "roundtrip_verified_blocks", "kernel_ms",
+                "persistent_launch", "ratio", "vs_cpu")
+        obj = {k: d.get(k) for k in keep}
+        obj["config"] = {"workload": (d.get("config") or {}).get("workload")}
+        rf = d.get("roofline") or {}
+        obj["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_s_per_launch", "algo_bytes_per_launch")}
+        api = d.get("api") or {}
+        obj["api"] = {"value": api.get("value"), "unit": api.get("unit"), "ms": api.get("ms")}
+        cb = d.get("cpu_baseline")
+        obj["cpu_baseline"] = ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "bit_identical_vs_reference", "compared_blocks")}
+                               if isinstance(cb, dict) else None)
+        return obj
+    except subprocess.TimeoutExpired:
+        return {"error": "child did not finish in %.0f s" % timeout_s}
+    except Exception as e:
+        return {"error": str(e)[:400]}
+
+
 def dry_run_bench(a):
     """--dry-run: the N-rank flow of `bench.py --gpus N` WITHOUT GPUs -- torch.distributed over gloo on 127.0.0.1, CPU tensors,
     a method that has no model (LZ77 on the host: the library needs no device for it).  What it exercises is everything
@@ -356,6 +389,9 @@ def main():
     ap.add_argument("--decode-blocks", type=int, default=2048,
                     help="blocks of the `decode` leg of an encode run on one GPU (BASELINE configs[4]'s operating point: one "
                          "residency wave of the 8192-block archive = 2048 x 1 MiB), outside the timed region; 0 = skip")
+    ap.add_argument("--configs1", type=int, default=None,
+                    help="1: BASELINE configs[1] (-m3 over 256 x 256 KiB LCG blocks) as a side object of the line, run by a child "
+                         "process after the other legs; default: on for the default headline run on one GPU, off otherwise")
     ap.add_argument("--decode-kind", default=None,
                     help="corpus of the decode leg: default 'mixed' (BASELINE configs[4] decodes configs[3]'s archive); the same as --kind reuses the timed run's payloads")
     ap.add_argument("--mode", choices=["encode", "decode"], default="encode",
@@ -904,6 +940,10 @@ def main():
                            "ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3],
                                   "kernel_init": ph[4], "kernel_code": ph[5], "python_wall": wall * 1e3,
                                   "library_total_first_call": first_ms}}
+        want_c1 = a.configs1 if a.configs1 is not None else int(world == 1 and a.mode == "encode" and a.method == "5" and a.kind == "text"
+                                                                and nb == 1024 and bs == (1 << 20))
+        if want_c1 and world == 1:
+            line["configs1"] = configs1_leg(min(a.cpu_seconds, 6.0))
         if a.cpu_seconds > 0 and a.mode == "decode":
             base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
             line["cpu_baseline"] = base
