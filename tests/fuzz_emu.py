@@ -5,8 +5,9 @@ that header -- the per-header wavefront coder (encode and decode, spec_kernel.h)
 wavefront (spec_dual_kernel.h) and the pipelined encoder in its shapes (pipe_kernel.h) -- are run by the wavefront
 emulator (tests/emu) on a few small blocks.  Every coded stream must be the oracle's, every decode must return the input.  No GPU; about 20 s of compilation per model.
 
-    python tests/fuzz_emu.py [models] [seed] [--big]      (--big: 9..24 components, the 8-block workgroup shape, the
-                                                           latency shapes of the pipelined encoder)
+    python tests/fuzz_emu.py [models] [seed] [--big] [--pipe-only]      (--big: 9..24 components, the 8-block workgroup shape, the
+                                                           latency shapes of the pipelined encoder; --pipe-only: only the pipelined
+                                                           encoder, step kernels and persistent launch)
 """
 from __future__ import annotations
 
@@ -46,7 +47,7 @@ def random_model(rng: random.Random, big: bool = False) -> str:
     return "\n".join(lines)
 
 
-def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
+def run(models: int, seed: int, verbose: bool = True, big: bool = False, pipe_only: bool = False) -> int:
     """0: every model agreed with the oracle; 1: a mismatch (printed with the config)."""
     import emu
     import zpaq_amd as z
@@ -55,6 +56,7 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
     rng = random.Random(seed)
     orc = Oracle()
     done = skipped = 0
+    npersist = [0]
     t0 = time.time()
     while done < models:
         cfg = random_model(rng, big)
@@ -90,36 +92,46 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
             continue
         try:
             waves = 8 if big else 4
-            enc = emu.run(header, inputs, waves=waves)
-            for w, (coded, status, consumed), i in zip(want, enc, inputs):
-                assert status == 0 and consumed == len(i) and coded == w, ("spec encode", status, consumed, len(i))
-            dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=waves, out_cap=max(len(x) for x in inputs))
-            for i, (plain, status, consumed) in zip(inputs, dec):
-                assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
-            # the decoder with two blocks per wavefront (chains of up to 32 components whose MIX inputs fit a half)
-            try:
-                emu.dual_source(header)
-                has_dual = True
-            except RuntimeError:
-                has_dual = False
-            if has_dual:
-                dec2 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), dual=True)
-                for i, (plain, status, consumed) in zip(inputs, dec2):
-                    assert status == 0 and plain == i, ("dual decode", status, len(plain), len(i))
-            # the lockstep decoder (chains whose ISSEs are fed by the ICM / ISSE before them)
-            try:
-                emu.team_source(header)
-                has_team = True
-            except RuntimeError:
-                has_team = False
-            if has_team:
-                dec3 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), team=True)
-                for i, (plain, status, consumed) in zip(inputs, dec3):
-                    assert status == 0 and plain == i, ("lockstep decode", status, len(plain), len(i))
+            if not pipe_only:
+                enc = emu.run(header, inputs, waves=waves)
+                for w, (coded, status, consumed), i in zip(want, enc, inputs):
+                    assert status == 0 and consumed == len(i) and coded == w, ("spec encode", status, consumed, len(i))
+                dec = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, waves=waves, out_cap=max(len(x) for x in inputs))
+                for i, (plain, status, consumed) in zip(inputs, dec):
+                    assert status == 0 and plain == i, ("spec decode", status, len(plain), len(i))
+                # the decoder with two blocks per wavefront (chains of up to 32 components whose MIX inputs fit a half)
+                try:
+                    emu.dual_source(header)
+                    has_dual = True
+                except RuntimeError:
+                    has_dual = False
+                if has_dual:
+                    dec2 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), dual=True)
+                    for i, (plain, status, consumed) in zip(inputs, dec2):
+                        assert status == 0 and plain == i, ("dual decode", status, len(plain), len(i))
+                # the lockstep decoder (chains whose ISSEs are fed by the ICM / ISSE before them)
+                try:
+                    emu.team_source(header)
+                    has_team = True
+                except RuntimeError:
+                    has_team = False
+                if has_team:
+                    dec3 = emu.run(header, [c + b"\0\0\0\0" for c in want], decode=True, out_cap=max(len(x) for x in inputs), team=True)
+                    for i, (plain, status, consumed) in zip(inputs, dec3):
+                        assert status == 0 and plain == i, ("lockstep decode", status, len(plain), len(i))
             for mode in ((1, 2) if big else (0, 1)):
                 out = emu.pipe_run(header, inputs, mode=mode, group=rng.choice([None, None, None, 8, 16]))
                 for w, (coded, status, _consumed), i in zip(want, out, inputs):
                     assert status == 0 and coded == w, ("pipe mode %d" % mode, status)
+            # the persistent launch (device/pipe_persist.h): the packer's plan for THIS chain -- units, dependencies, LDS regions
+            # -- run as a grid of live workgroups (modes 0 and 1; the long-step shape has none)
+            for mode in (0, 1):
+                if "PS_WPG" not in emu.pipe_source(header, 64, mode=mode):
+                    continue
+                out = emu.pipe_run(header, inputs, mode=mode, chunk=64, group=rng.choice([None, 8, 16]), persist=True)
+                for w, (coded, status, _consumed), i in zip(want, out, inputs):
+                    assert status == 0 and coded == w, ("persistent launch, mode %d" % mode, status)
+                npersist[0] += 1
         except AssertionError as ex:
             print("MISMATCH", ex.args, "\n" + cfg, flush=True)
             return 1
@@ -130,13 +142,13 @@ def run(models: int, seed: int, verbose: bool = True, big: bool = False) -> int:
         if verbose:
             print("model %d ok (%d comps, %.0f s)" % (done, header[6], time.time() - t0), flush=True)
     if verbose:
-        print("models", done, "skipped", skipped)
+        print("models", done, "skipped", skipped, "persistent launches run", npersist[0])
     return 0
 
 
 def main():
     pos = [a for a in sys.argv[1:] if not a.startswith("--")]
-    return run(int(pos[0]) if pos else 10, int(pos[1]) if len(pos) > 1 else 1, big="--big" in sys.argv)
+    return run(int(pos[0]) if pos else 10, int(pos[1]) if len(pos) > 1 else 1, big="--big" in sys.argv, pipe_only="--pipe-only" in sys.argv)
 
 
 if __name__ == "__main__":
