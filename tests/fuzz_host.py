@@ -5,7 +5,7 @@ and the method-string expander.  Nothing here may crash, hang or read out of bou
 result.  Meant to run against the sanitizer build:
 
     make -C zpaq_amd/csrc ASAN=1
-    LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so):$(gcc -print-file-name=libstdc++.so) \
       ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
       ZPAQ_AMD_LIB=libzpaq_amd_asan.so python tests/fuzz_host.py [iterations] [seed]
 
