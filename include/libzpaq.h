@@ -197,7 +197,7 @@ void compressBlock(StringBuffer* in, Writer* out, const char* method, const char
 void compressBlocks(StringBuffer* const* in, Writer* const* out, int n, const char* method,
                     const char* const* filename = 0, const char* const* comment = 0, bool dosha1 = true);
 // ... the same with a method per block: what an archiver's queue of blocks holds (zpaq.cpp gives every block its own
-// redundancy / type hints, zpaq.cpp:2399-2471); patches/zpaq_batch.patch hands CompressJob's whole queue to it.
+// redundancy / type hints: the method string is built per block, zpaq.cpp:2501-2504, from the statistics of 2399-2471); patches/zpaq_batch.patch hands CompressJob's whole queue to it.
 void compressBlocks(StringBuffer* const* in, Writer* const* out, int n, const char* const* methods,
                     const char* const* filename = 0, const char* const* comment = 0, bool dosha1 = true);
 // Every block and segment of `in`, concatenated, to `out`.
