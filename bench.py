@@ -880,6 +880,16 @@ def main():
                                            frac=transactions["per_input_byte"] * float(nb) * bs / 1e9 / code_s / transactions["peak_G_per_s"])
                                       if transactions and code_s > 0 else None)},
     }
+    if world > 1 and a.kind == "mixed" and a.scaling == "weak" and std:
+        # The N = 1 line of a scaling series is configs[2] (text corpus), the N > 1 lines are configs[3]'s corpus (mixed: a second,
+        # longer chain for a quarter of the blocks): efficiency against the N = 1 line mixes two workloads.  The one-GPU figure
+        # of THIS workload, measured with `python bench.py --kind mixed`, is carried along for whoever computes the ratio.
+        try:
+            one = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_mixed.json")))
+            line["one_gpu_same_workload"] = {"value": one["value"], "unit": "MB/s", "source": "profiles/r05_bench_mixed.json",
+                                             "workload": one["config"]["workload"]}
+        except Exception:
+            pass
     if rank == 0:
         # coded payloads of the timed run, for the identity check against the reference
         ncmp = min(nb, 512)
