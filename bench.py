@@ -132,7 +132,8 @@ def cpu_baseline(blocks, method, budget_s):
         wall, lens, archives = ref.compress_blocks_mt(blocks[:sample], method, threads, deadline_s=budget_s, keep=True)
         done = [i for i, v in enumerate(lens) if v >= 0]
         return {"value": len(done) * bs / 1e6 / wall, "unit": "MB/s", "cores": threads, "kind": "reference",
-                "sample": f"{len(done)} x {bs} B blocks of the same corpus, libzpaq::compressBlock(\"{method}\") "
+                "sample": f"{len(done)} x {bs} B blocks of the same corpus, " +
+                          (f"libzpaq::Compressor::startBlock({method[1:]}) " if method.startswith("L") else f"libzpaq::compressBlock(\"{method}\") ") +
                           f"(reference built {ref.build_flags()} with its x86 JIT) from a {threads}-thread work queue "
                           f"(nproc={os.cpu_count()}, usable={cores}: the box's CPU quota, a full host would be about "
                           f"{os.cpu_count() / max(cores, 1):.0f}x this); 1 thread alone: {bs / 1e6 / t1:.3f} MB/s",
@@ -265,6 +266,41 @@ def configs1_leg(cpu_seconds, timeout_s=150.0):
         return {"error": str(e)[:400]}
 
 
+def legacy_leg(level, cpu_seconds, timeout_s=240.0):
+    """SURVEY 8(d) C2 / C3 beside the headline: the reference's LEGACY built-in models at BASELINE scale -- level 2 (mid.cfg, n = 8)
+    over configs[1]'s 256 x 256 KiB LCG blocks, level 3 (max.cfg, n = 22; ~246 MB of state per block: 1024 blocks do not fit the HBM
+    together, the engine codes them in residency rounds) over configs[2]'s 1024 x 1 MiB text blocks -- by THIS script in a child
+    process: device-resident `value`, roofline, every coded payload against the reference's startBlock(level) output (frozen in
+    tests/golden/legacy_sha1.json), every block decoded back on the device, the reference on the host cores."""
+    import subprocess
+    shape = {2: ["--kind", "lcg", "--blocks", "256", "--block-bytes", "262144"],
+             3: ["--kind", "text", "--blocks", "1024", "--block-bytes", "1048576"]}[level]
+    cmd = [sys.executable, os.path.abspath(__file__), "--legacy-level", str(level)] + shape + \
+          ["--decode-blocks", "0", "--configs1", "0", "--legacy", "0", "--cpu-seconds", str(cpu_seconds)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode or not lines:
+            return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-400:]}
+        d = json.loads(lines[-1])
+        keep = ("metric", "value", "unit", "ms_per_step", "all_status_ok", "roundtrip_verified_blocks", "kernel_ms",
+                "persistent_launch", "ratio", "vs_cpu", "reference_identity")
+        obj = {k: d.get(k) for k in keep}
+        cfg = d.get("config") or {}
+        obj["config"] = {"workload": cfg.get("workload"), "ncomp": cfg.get("ncomp"), "state_GiB_per_gpu": cfg.get("state_GiB_per_gpu")}
+        rf = d.get("roofline") or {}
+        obj["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_s_per_launch", "algo_bytes_per_launch")}
+        cb = d.get("cpu_baseline")
+        obj["cpu_baseline"] = ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "bit_identical_vs_reference", "compared_blocks")}
+                               if isinstance(cb, dict) else None)
+        return obj
+    except subprocess.TimeoutExpired:
+        return {"error": "child did not finish in %.0f s" % timeout_s}
+    except Exception as e:
+        return {"error": str(e)[:400]}
+
+
 def dry_run_bench(a):
     """--dry-run: the N-rank flow of `bench.py --gpus N` WITHOUT GPUs -- torch.distributed over gloo on 127.0.0.1, CPU tensors,
     a method that has no model (LZ77 on the host: the library needs no device for it).  What it exercises is everything
@@ -377,6 +413,13 @@ def main():
                     help="text | lcg | zeros | records | pattern | mixed; default: text on one GPU (BASELINE configs[2]), "
                          "mixed on several (configs[3]: text, text, LCG, records by block index mod 4)")
     ap.add_argument("--method", default="5")
+    ap.add_argument("--legacy-level", type=int, default=0,
+                    help="1 / 2 / 3: code every block with the reference's built-in model of that level (Compressor::startBlock(int): "
+                         "min.cfg / mid.cfg / max.cfg, libzpaq.cpp:2793-2839) instead of a compressBlock method -- SURVEY 8(d) C2 / C3: "
+                         "level 2 on configs[1]'s data, level 3 on configs[2]'s")
+    ap.add_argument("--legacy", type=int, default=None,
+                    help="1: both legacy configurations (mid.cfg over 256 x 256 KiB LCG, max.cfg over 1024 x 1 MiB text) as side objects "
+                         "`legacy2` / `legacy3` of the line, each run by a child process; default: on for the default headline run on one GPU")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-seconds", type=float, default=None,
                     help="wall budget of the cpu_baseline leg (0 = skip; default 15 on one GPU, 0 on several: the contract asks for the "
@@ -411,6 +454,11 @@ def main():
         a.cpu_seconds = 15.0 if a.gpus == 1 else 0.0
     if a.dry_run:
         return dry_run_bench(a)
+    if a.legacy_level:
+        if a.legacy_level not in (1, 2, 3):
+            sys.exit("bench.py: --legacy-level takes 1, 2 or 3")
+        a.method = "L%d" % a.legacy_level       # (the label used below; the reference shim understands it as startBlock(level))
+        a.api_blocks = 0                        # no batch entry point takes a level: Compressor::startBlock(int) is per block
     if a.blocks is None:
         a.blocks = 2048 if a.mode == "decode" else 1024
     if a.kind is None:
@@ -501,6 +549,8 @@ def main():
 
     def coder_input_of(arr):
         def one(b):
+            if a.legacy_level:      # Compressor::postProcess(NULL): a 0 byte, then the data, through the built-in model
+                return z.builtin_model_header(a.legacy_level), b"\x00", arr[b]
             xm = z.expand_method(a.method, arr[b])
             h, pc, _ = z.method_to_header(xm)
             pp = (b"\x01" + pc) if pc else b"\x00"
@@ -852,10 +902,17 @@ def main():
         which_config = f" = BASELINE configs[3]'s corpus and per-GPU load on {world} of its 8 GPUs"
     elif a.mode == "decode" and a.method == "5" and bs == (1 << 20) and nb == 2048 and world == 1:
         which_config = " = one residency wave of BASELINE configs[4]"
+    if a.legacy_level == 2 and a.kind == "lcg" and nb == 256 and bs == (1 << 18):
+        which_config = " = SURVEY 8(d) C2: BASELINE configs[1]'s data through Compressor::startBlock(2) (mid.cfg)"
+    elif a.legacy_level == 3 and a.kind == "text" and nb == 1024 and bs == (1 << 20):
+        which_config = " = SURVEY 8(d) C3: BASELINE configs[2]'s data through Compressor::startBlock(3) (max.cfg)"
+    elif a.legacy_level:
+        which_config = f" through Compressor::startBlock({a.legacy_level})"
     line = {
         # BASELINE.json's metric, spelled with the method / batch shape of THIS run (the default is its -m5, 1024 x 1 MiB)
         "metric": ("compress" if a.mode == "encode" else "decompress") +
-                  f" MB/s + bit-identical ratio, -m{a.method} over {a.blocks}x{_size_name(bs)} blocks",
+                  f" MB/s + bit-identical ratio, " + (f"built-in model {a.legacy_level} ({['min', 'mid', 'max'][a.legacy_level - 1]}.cfg)" if a.legacy_level else f"-m{a.method}") +
+                  f" over {a.blocks}x{_size_name(bs)} blocks",
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed * 1e3 / max(a.steps, 1), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -915,6 +972,25 @@ def main():
                       "what": "SHA-1 of every block's coded payload + terminator (timed device-resident run) against the reference's, "
                               "frozen in tests/golden/headline_sha1.json"}
             line["reference_identity"] = golden
+        lpath = os.path.join(ROOT, "tests", "golden", "legacy_sha1.json")
+        if a.mode == "encode" and a.legacy_level and first == 0 and os.path.exists(lpath):
+            lj = json.load(open(lpath))["levels"].get(str(a.legacy_level))
+            if lj and lj["block_bytes"] == bs and lj["corpus"].startswith(f"zpaq_amd.corpus.block('{a.kind}'"):
+                gj = lj["blocks"]
+                ng = min(nb, len(gj))
+                bad = []
+                for b0 in range(0, ng, 256):
+                    part = d_out[b0:min(b0 + 256, ng)].cpu().numpy()
+                    for j in range(part.shape[0]):
+                        i = b0 + j
+                        n = int(out_len[i])
+                        if n != gj[i]["coded_len"] or hashlib.sha1(part[j, :n].tobytes() + b"\0\0\0\0").hexdigest() != gj[i]["payload_sha1"]:
+                            bad.append(i)
+                    del part
+                line["reference_identity"] = {"blocks_compared": ng, "identical": not bad, "first_mismatches": bad[:8],
+                                              "what": f"SHA-1 of every block's coded payload + terminator (timed device-resident run) against what the "
+                                                      f"reference's Compressor::startBlock({a.legacy_level}) made of the same block, frozen in "
+                                                      f"tests/golden/legacy_sha1.json (tests/golden/make_legacy_golden.py)"}
         if a.mode == "encode" and world == 1 and a.decode_blocks > 0 and ok:
             try:
                 line["decode"] = decode_leg(a.decode_blocks, a.decode_kind or "mixed")
@@ -954,7 +1030,14 @@ def main():
                                                                 and nb == 1024 and bs == (1 << 20))
         if want_c1 and world == 1:
             line["configs1"] = configs1_leg(min(a.cpu_seconds, 6.0))
-        if a.cpu_seconds > 0 and a.mode == "decode":
+        want_legacy = a.legacy if a.legacy is not None else int(world == 1 and a.mode == "encode" and a.method == "5" and a.kind == "text"
+                                                                 and nb == 1024 and bs == (1 << 20))
+        if want_legacy and world == 1:
+            line["legacy2"] = legacy_leg(2, min(a.cpu_seconds, 4.0))
+            line["legacy3"] = legacy_leg(3, min(a.cpu_seconds, 6.0))
+        if a.cpu_seconds > 0 and a.mode == "decode" and a.legacy_level:
+            line["cpu_baseline"] = None
+        elif a.cpu_seconds > 0 and a.mode == "decode":
             base = cpu_decode_baseline(blocks, a.method, a.cpu_seconds)
             line["cpu_baseline"] = base
             line["vs_cpu"] = value / base["value"] if base and base["value"] else None

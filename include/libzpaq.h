@@ -215,7 +215,8 @@ class Decompresser {
   void readComment(Writer* comment = 0);
   void setOutput(Writer* out) { out_ = out; }
   void setSHA1(SHA1* s) { sha1_ = s; }
-  bool decompress(int n = -1);               // n more OUTPUT bytes (-1: to end of segment); false at end.  (The reference
+  bool decompress(int n = -1);               // n more OUTPUT bytes (-1: to end of segment); false at end.  A first call with a
+                                             // small n decodes only the segment's first 64 KiB on the device.  (The reference
                                              // counts n bytes into the post-processor and flushes its output every 64 KiB:
                                              // same totals, different pieces for LZ77 / BWT blocks.)
   bool pcomp(Writer* out2);
@@ -226,6 +227,8 @@ class Decompresser {
   void operator=(const Decompresser&);
   int getc();
   void decode_segment();
+  void try_prefix();
+  void peek_block_payloads(std::vector<std::vector<U8> >& payloads);
   Reader* in_;
   Writer* out_;
   SHA1* sha1_;
@@ -241,6 +244,8 @@ class Decompresser {
   void* pp_;                 // PostProcessor of the current block (first segment carries the PP header)
   std::vector<std::vector<U8> > block_cache_;   // modelled block of several segments: all of them, decoded together
   bool skipped_in_block_;
+  std::vector<U8> prefix_;   // decompress(n) with a small n: the first bytes of the segment, decoded without the rest
+  bool prefix_tried_, prefix_active_;
   int peek(size_t off);      // byte at rpos_ + off without consuming it (-1 at EOF)
   enum { BLOCK, FILENAME, COMMENT, DATA, SEGEND } state_;
 };

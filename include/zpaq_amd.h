@@ -211,6 +211,11 @@ int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
 /* 1 when the pipelined encoder of the last timed call ran as persistent launches (one launch per chain for the whole
  * sequence, device/pipe_persist.h), 0 when it ran step by step (or the call had no pipelined group). */
 int zpq_last_persistent(void);
+/* When a persistent launch of the last timed call was given up (its workgroups did not become resident together -- something
+ * else held compute units -- or a unit's watchdog fired) and the step kernels coded the batch instead: milliseconds from the
+ * launch until the engine knew; 0 when none was given up.  The arrival handshake bounds it to ~50 ms
+ * (ZPAQ_AMD_PERSIST_ARRIVE_MS) and leaves the model state untouched. */
+double zpq_last_persist_abort_ms(void);
 /* SHA-1 (libzpaq::SHA1, libzpaq.cpp:106-177) of n buffers ON THE DEVICE, one lane per buffer, 20 bytes each into
  * out20n.  zpq_compress_blocks uses the same kernel for blocks that reach the device unchanged (methods without
  * pre-processing): the digest for the segment trailer is computed beside the coder instead of on a host thread. */
@@ -268,6 +273,11 @@ int zpq_expand_method(const char* method, const uint8_t* data, uint32_t n, char*
  * model (len16 + code, empty if none); args9 receives $1..$9. */
 int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t hcap,
                          size_t* hlen, uint8_t* pcomp, size_t pcap, size_t* plen);
+/* The stored block header of built-in model `level` (1 min.cfg, 2 mid.cfg, 3 max.cfg): what
+ * Compressor::startBlock(int level) writes (libzpaq.cpp:2793-2839).  Feed it to zpq_plan_create to code blocks
+ * with the legacy models through the batch entry points (the coder's input is then a 0 byte + the data:
+ * Compressor::postProcess(NULL), libzpaq.cpp:2853-2870). */
+int zpq_builtin_model_header(int level, uint8_t* hcomp, size_t hcap, size_t* hlen);
 /* The pre-processing half of compressBlock for an explicit "x.." method (libzpaq.cpp:7709-7716; LZ77 / BWT /
  * E8E9, host/preproc.cpp): writes the stream the coder will see (the input itself when the method does not
  * transform it).  E8E9 methods rewrite `data` in place, as the reference rewrites its input buffer. */

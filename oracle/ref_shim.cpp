@@ -235,8 +235,10 @@ double ref_compress_blocks_mt(const unsigned char* in, size_t block_bytes, int n
       unsigned char* dst; size_t cap;
       if (out) { dst = out + (size_t)b * out_stride; cap = out_stride; }
       else { tmp.resize(block_bytes + block_bytes / 2 + 4096); dst = tmp.data(); cap = tmp.size(); }
-      long long r = ref_compress_block(in + (size_t)b * block_bytes, block_bytes, method,
-                                       0, 0, 1, dst, cap);
+      // method "L1" / "L2" / "L3": the built-in models through Compressor::startBlock(int level) (min / mid / max.cfg)
+      long long r = (method && method[0] == 'L')
+          ? ref_compress_level(in + (size_t)b * block_bytes, block_bytes, method[1] - '0', 0, 0, 1, dst, cap)
+          : ref_compress_block(in + (size_t)b * block_bytes, block_bytes, method, 0, 0, 1, dst, cap);
       if (r < 0) failed = 1;
       if (out_len) out_len[b] = r;
     }

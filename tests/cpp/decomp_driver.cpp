@@ -6,9 +6,11 @@
 //
 //   decomp_driver <archive> <piece> <mode>
 //     piece: decompress(piece) until false; -1 = decompress() once
-//     mode:  0 read everything, 1 skip every second segment (no decompress call), 2 stop reading a segment half way
+//     mode:  0 read everything, 1 skip every second segment (no decompress call), 2 stop reading a segment half way,
+//            3 stop after the FIRST decompress(piece) call of every segment and say how long it took (stderr: not compared)
 #include <libzpaq.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -94,7 +96,12 @@ int main(int argc, char** argv) {
             d.decompress();
           } else {
             int calls = 0;
+            const auto t0 = std::chrono::steady_clock::now();
             while (d.decompress(piece)) {
+              if (mode == 3) {
+                fprintf(stderr, "first_call_ms=%.1f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                break;
+              }
               if (mode == 2 && ++calls == 2) break;
             }
           }

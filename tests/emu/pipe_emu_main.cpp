@@ -23,6 +23,7 @@ extern "C" void zpq_pipe_icm(zpq::PipeArgs a);
 extern "C" void zpq_pipe_isse(zpq::PipeArgs a);
 extern "C" void zpq_pipe_mix(zpq::PipeArgs a);
 extern "C" void zpq_pipe_persist(zpq::PipeArgs a);
+extern "C" void zpq_pipe_repack(zpq::PipeArgs a);
 
 namespace {
 
@@ -47,6 +48,7 @@ void kernel_thunk(void* p) {
     case 3: zpq_pipe_icm(l->a); break;
     case 4: zpq_pipe_isse(l->a); break;
     case 6: zpq_pipe_persist(l->a); break;
+    case 7: zpq_pipe_repack(l->a); break;
     default: zpq_pipe_mix(l->a); break;
   }
 }
@@ -138,6 +140,11 @@ int main(int argc, char** argv) {
     if (ins[b].size() > maxlen) maxlen = (unsigned)ins[b].size();
   }
   const unsigned nchunks = maxlen ? (maxlen + C - 1) / C : 1;
+  {
+    // MIX tables the chain keeps as packed rows are rewritten from Predictor::init's pattern, as the engine does before the first launch
+    Launch l{7, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, 0, 0u}};
+    for (unsigned b = 0; b < nb; ++b) emu::run_workgroup(kernel_thunk, &l, 256, b);
+  }
   if (persist) {
     const unsigned wpg = (unsigned)lay[14], waves = (unsigned)(lay[15] & 0xFFFF), nunit = (unsigned)(lay[15] >> 16);
     if (!wpg) { fprintf(stderr, "pipe_emu_run: this chain has no persistent launch\n"); return 2; }
@@ -150,6 +157,7 @@ int main(int argc, char** argv) {
     Launch l{6, zpq::PipeArgs{jobs.data(), res.data(), nb, &tb, pipe, 0, 0u}};
     l.a.prog = prog.data(); l.a.group_chunks = gchunks.data(); l.a.ctl = ctl.data();
     l.a.group0 = 0; l.a.ngroups_here = ngroups; l.a.timeout_ticks = 200000;
+    l.a.arrive_need = ngroups * wpg; l.a.arrive_ticks = 200000;      // (the arrival handshake: every workgroup of the grid is alive here)
     l.a.spread = ngroups > 1 ? 2 : 1;          // (the device spreads over its 8 XCDs: here two, so that the mapping is exercised)
     emu::run_grid(kernel_thunk, &l, 64 * waves, ngroups * wpg, 0);
     if (ctl[0]) { fprintf(stderr, "pipe_emu_run: the persistent launch aborted (slot %u, chunk %u)\n", ctl[1], ctl[2]); return 4; }

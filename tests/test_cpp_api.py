@@ -104,6 +104,55 @@ def test_blocks_of_several_segments(tmp_path, gpu, ref):
         assert gpu.decompress(ours) == b"".join(parts)
 
 
+@pytest.mark.gpu
+def test_decompress_n_decodes_a_prefix_on_the_device(tmp_path, gpu):
+    """Decompresser::decompress(n) (libzpaq.cpp:2315-2343; zpaq.cpp:2859-2866 stops once it has the fragments it wants): the
+    first 16 KiB of a 1 MiB -m5 block must not cost the whole block's decode.  tests/cpp/decomp_driver.cpp, mode 3: one
+    decompress(16384) call, then readSegmentEnd -- the bytes are the input's first 16 KiB and the call takes a fraction of
+    what decompress() to the end takes; read on in 16 KiB pieces (mode 0) the hand-over from the decoded prefix to the whole
+    segment leaves no seam: every byte, the segment's SHA-1 and the trailer agree."""
+    import hashlib
+    import re
+    import time
+    from zpaq_amd import corpus
+    drv = os.path.join(ROOT, "tests", "cpp", "decomp_driver.cpp")
+    exe = str(tmp_path / "decomp_mine")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", drv, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "zpaq_amd"), "-lzpaq_amd",
+                        "-Wl,-rpath," + os.path.join(ROOT, "zpaq_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    data = corpus.block("text", 1 << 20, 77).tobytes()
+    path = str(tmp_path / "one.zpaq")
+    open(path, "wb").write(gpu.compress_blocks([data], "5")[0])
+
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+
+    def run(piece, mode):
+        t0 = time.time()
+        p = subprocess.run([exe, path, str(piece), str(mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0 and "error" not in p.stdout, (p.stdout[-400:], p.stderr[-400:])
+        return p.stdout, p.stderr, time.time() - t0
+
+    run(-1, 0)                                              # (first process on this box: code object load, buffers)
+    out, err, _ = run(16384, 3)
+    first_ms = float(re.search(r"first_call_ms=([0-9.]+)", err).group(1))
+    assert f"data n=16384 fnv={fnv(data[:16384])}" in out, out
+    out, err, _ = run(-1, 3)                                # decompress() to the end in one call, timed the same way ...
+    whole = re.search(r"first_call_ms=([0-9.]+)", err)
+    if whole is None:                                       # (... it returns false at the end of the segment: time the process instead)
+        t0 = time.time(); out, err, _ = run(-1, 0); whole_ms = (time.time() - t0) * 1e3
+    else:
+        whole_ms = float(whole.group(1))
+    assert f"data n={len(data)} fnv={fnv(data)}" in out, out
+    assert first_ms < 0.35 * whole_ms, (first_ms, whole_ms)
+    out, err, _ = run(16384, 0)                             # pieces across the end of the prefix
+    assert f"data n={len(data)} fnv={fnv(data)} sha_n={len(data)} sha={hashlib.sha1(data).hexdigest()}" in out, out
+    print(f"first 16 KiB: {first_ms:.0f} ms, whole block: {whole_ms:.0f} ms")
+
+
 def _build_both(tmp_path, source, name):
     """One driver source against this library's libzpaq.h + .so, and against the reference's libzpaq.h + libzpaq.cpp."""
     ref_dir = "/root/reference"

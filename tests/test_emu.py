@@ -294,6 +294,38 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
     _pipe_check(oracle, header, [b"\0" + d for d in fit] + [d[:1023] for d in fit], chunk=128, mode=0, persist=True)
 
 
+MATCH_RING_CFG = """
+comp 2 0 0 0 1
+  0 match 10 9
+hcomp
+  b=a a=*d a<<= 8 a+=b *d=a halt
+end
+"""
+
+
+def test_match_unit_near_the_end_of_its_history_ring(zlib_, oracle):
+    """update0 compares backwards from a candidate with indices modulo the buffer size (libzpaq.cpp:1995-1998): behind a
+    candidate near the block's start that is the END of the ring, zero only while nothing has been written there.  A block
+    within 255 bytes of the buffer size must therefore go through the buffer in the arena, not through the input
+    (pipe_match_any; the advisor's case of round 5: 508 bytes against a 512-byte buffer, a zero run near the end, the bytes
+    that follow the block's first bytes repeated behind it).  Lengths around both thresholds, every launch form."""
+    header, _ = zlib_.assemble(MATCH_RING_CFG)
+    Y, X = 0x59, 0x58
+
+    def case(n):
+        d = bytearray(np.random.default_rng(n).integers(1, 256, n, dtype=np.uint8).tobytes())
+        d[1:3] = bytes([Y, X])
+        d[n - 24] = X
+        d[n - 23:n - 10] = bytes(13)
+        d[n - 10:n - 8] = bytes([Y, X])
+        return bytes(d)
+
+    datas = [case(n) for n in (508, 512, 300, 258, 257, 256, 511, 400)]
+    for mode in (0, 1):
+        _pipe_check(oracle, header, datas, chunk=64, mode=mode)
+    _pipe_check(oracle, header, datas, chunk=64, mode=0, persist=True)
+
+
 def test_persistent_launch_of_the_pipelined_encoder(zlib_, oracle, golden):
     """The same units inside ONE launch (device/pipe_persist.h): every workgroup of the grid alive at once in the emulator,
     the units waiting for each other through their progress counters, streams stored through the write-through accessors,

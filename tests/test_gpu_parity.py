@@ -119,6 +119,32 @@ def test_legacy_min_mid_max_models(gpu, golden, kernel, idx):
         gpu.set_kernel(0)
 
 
+@pytest.mark.parametrize("level,kind,nblocks,bs", [(2, "lcg", 64, 1 << 18), (3, "text", 16, 1 << 20)])
+def test_legacy_models_at_baseline_block_sizes(gpu, level, kind, nblocks, bs):
+    """mid.cfg on configs[1]'s 256 KiB LCG blocks, max.cfg on configs[2]'s 1 MiB text blocks
+    (Compressor::startBlock(2 | 3), libzpaq.cpp:2793-2839) -- coded through the PERSISTENT launch of the pipelined encoder,
+    every coded payload against what the reference made of the same block (tests/golden/legacy_sha1.json, written by
+    tests/golden/make_legacy_golden.py from oracle/_ref), decoded back by the lockstep decoder."""
+    import json
+    gj = json.load(open(os.path.join(ROOT, "tests", "golden", "legacy_sha1.json")))["levels"][str(level)]
+    assert gj["block_bytes"] == bs and f"'{kind}'" in gj["corpus"]
+    blocks = [corpus.block(kind, bs, corpus.BASE_SEED + b).tobytes() for b in range(nblocks)]
+    hdr = gpu.builtin_model_header(level)
+    plan = gpu.Plan(hdr)
+    coded = gpu.encode_batch([plan] * nblocks, [b"\0" + d for d in blocks])
+    assert gpu.lib().zpq_last_persistent() == 1, "the built-in model's chain did not take the persistent launch"
+    for b, c in enumerate(coded):
+        assert len(c) == gj["blocks"][b]["coded_len"], (level, b)
+        assert hashlib.sha1(c + b"\0\0\0\0").hexdigest() == gj["blocks"][b]["payload_sha1"], (level, b)
+    gpu.set_kernel(6)                      # the lockstep decoder, whatever the batch size
+    try:
+        back = gpu.decode_batch([plan] * nblocks, [c + b"\0\0\0\0" for c in coded], [len(d) + 9 for d in blocks])
+    finally:
+        gpu.set_kernel(0)
+    for b, (d, consumed) in enumerate(back):
+        assert d == b"\0" + blocks[b], (level, b)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_decode_reference_archives(gpu, golden, kernel):
     gpu.set_kernel(kernel)
@@ -688,6 +714,43 @@ def test_persistent_launch_gives_up_and_the_step_kernels_take_over(gpu, oracle, 
     f = parse_block(want[0])
     coded = oracle.encode(f["header"], b"\0" + blocks[0].tobytes())
     assert want[0][f["payload_start"]:f["payload_start"] + len(coded)] == coded
+
+
+def test_foreign_kernel_on_the_device_makes_the_persistent_launch_step_aside(gpu, tmp_path):
+    """The persistent launch needs all its workgroups resident together; what the library cannot know about -- a second
+    process's kernel, here tests/cpp/gpu_hog.hip holding 200 of the 256 compute units with 140 KiB of LDS each -- leaves
+    some of them in the queue.  The arrival handshake (pipe_persist.h pipe_arrived) notices within ZPAQ_AMD_PERSIST_ARRIVE_MS
+    (50 ms) that the count has stopped short, nothing has been touched, and the step kernels code the batch beside the foreign
+    kernel: same archives, given up in well under 100 ms instead of after the 3 s watchdog."""
+    import ctypes as C
+    import subprocess
+    import time
+    hog = str(tmp_path / "gpu_hog")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tests", "cpp", "gpu_hog.hip"), "-o", hog],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    blocks = [corpus.block(["text", "records"][i % 2], 32768 + 64 * i, 300 + i) for i in range(256)]
+    L = gpu.lib()
+    L.zpq_last_persist_abort_ms.restype = C.c_double
+    want = gpu.compress_blocks(blocks, "5")
+    assert L.zpq_last_persistent() == 1 and L.zpq_last_persist_abort_ms() == 0.0
+    p = subprocess.Popen([hog, "200", "6000"], stdout=subprocess.PIPE, text=True)
+    try:
+        assert "holding" in p.stdout.readline()
+        time.sleep(0.3)                                  # (the foreign workgroups are on their compute units)
+        t0 = time.time()
+        got = gpu.compress_blocks(blocks, "5")
+        wall = time.time() - t0
+        gave_up_ms = L.zpq_last_persist_abort_ms()
+        assert p.poll() is None, "the foreign kernel ended before the batch was coded: nothing was tested"
+        assert L.zpq_last_persistent() == 0, "the persistent launch ran although 200 compute units were taken"
+        assert 0.0 < gave_up_ms < 100.0, gave_up_ms
+        assert got == want
+        print(f"given up after {gave_up_ms:.1f} ms, batch coded by the step kernels in {wall:.2f} s beside the foreign kernel")
+    finally:
+        p.kill()
+        p.wait()
+    assert gpu.compress_blocks(blocks, "5") == want and L.zpq_last_persistent() == 1
 
 
 def test_input_tail_copied_behind_the_first_steps(gpu, monkeypatch):

@@ -301,6 +301,14 @@ def method_to_header(xmethod: str):
     return h, p, list(args)
 
 
+def builtin_model_header(level: int) -> bytes:
+    """Compressor::startBlock(int level): the stored header of min.cfg / mid.cfg / max.cfg (level 1 / 2 / 3)."""
+    h = np.empty(4096, np.uint8)
+    hl = C.c_size_t(0)
+    _check(lib().zpq_builtin_model_header(C.c_int(level), _p(h), C.c_size_t(h.size), C.byref(hl)))
+    return h[:hl.value].tobytes()
+
+
 def assemble(config: str, args: Optional[Iterable[int]] = None):
     """Compiler: ZPAQL source -> (stored header bytes, pcomp bytes)."""
     a9 = (C.c_int * 9)(*(list(args or []) + [0] * 9)[:9])

@@ -12,6 +12,8 @@
 #include "host/blocks.hpp"
 #include "host/container.hpp"
 
+namespace zpq { std::vector<U8> builtin_model(int level); }      // libzpaq_compat.cpp: the stored headers of min / mid / max.cfg
+
 namespace zpq {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -304,6 +306,7 @@ int zpq_code_device_multi(int decode, const zpq_plan* const* plans, const void* 
 
 int zpq_engine_count(void) { return engine_count(); }
 int zpq_last_persistent(void) { return engine_last_persistent() ? 1 : 0; }
+double zpq_last_persist_abort_ms(void) { return engine_last_persist_abort_ms(); }
 
 int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks) {
   Timing t = engine_last_timing();
@@ -408,6 +411,19 @@ int zpq_method_to_header(const char* xmethod, int* args9, uint8_t* hcomp, size_t
   const std::string cfg = make_config(xmethod ? xmethod : "", args);
   if (args9) memcpy(args9, args, sizeof(args));
   return copy_assembled(assemble(cfg.c_str(), args), hcomp, hcap, hlen, pcomp, pcap, plen);
+  ZPQ_CATCH
+}
+
+// the stored header of one of the reference's three built-in models (Compressor::startBlock(int level), libzpaq.cpp:2793-2839:
+// min.cfg, mid.cfg, max.cfg) -- what a block coded at that level carries; the batch entry points take it like any other header
+int zpq_builtin_model_header(int level, uint8_t* hcomp, size_t hcap, size_t* hlen) {
+  ZPQ_TRY
+  const std::vector<U8> h = builtin_model(level);
+  if (h.empty()) fail(ZPQ_E_ARG, "built-in models are levels 1, 2 and 3");
+  if (hlen) *hlen = h.size();
+  if (h.size() > hcap || !hcomp) fail(ZPQ_E_OVERFLOW, "header buffer too small");
+  memcpy(hcomp, h.data(), h.size());
+  return ZPQ_OK;
   ZPQ_CATCH
 }
 

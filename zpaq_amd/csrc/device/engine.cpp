@@ -110,6 +110,7 @@ struct Engine {
   Timing last{};
   int last_kind = 0;
   bool last_persist = false;           // the last batch's pipelined groups ran as persistent launches
+  double last_persist_abort_ms = 0.0;  // ... or: how long it took until a persistent launch of the last batch was given up (0: none was)
   int jit_left = 0;                    // hipRTC compilations still allowed in the current call
   int cus = 256;                       // compute units of the device
   hipEvent_t busy = nullptr;           // recorded after the last launch of a call that returned with work in flight
@@ -324,6 +325,7 @@ void engine_set_kernel(int which) {
   for (Engine& e : g_engines) { std::lock_guard<std::mutex> g(e.mu); e.kernel_choice = which; }
 }
 Timing engine_last_timing() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last; }
+double engine_last_persist_abort_ms() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last_persist_abort_ms; }
 bool engine_last_persistent() { Engine& e = eng(); std::lock_guard<std::mutex> g(e.mu); return e.last_persist; }
 
 static const uint8_t* plan_on_device(Engine& e, const zpq_plan* plan) {
@@ -603,6 +605,14 @@ static uint32_t persist_timeout_ticks() {
   return (uint32_t)std::min<uint64_t>((uint64_t)ms * 100000ull, 0xFFFFFFF0ull);      // s_memrealtime: 100 MHz
 }
 
+// ... and how long the workgroups of a launch may wait for each other to become resident (pipe_persist.h pipe_arrived) before the
+// launch is given up untouched: 50 ms without a new arrival (a full grid arrives within microseconds of its first workgroup)
+static uint32_t persist_arrive_ticks() {
+  uint32_t ms = 50;
+  if (const char* t = getenv("ZPAQ_AMD_PERSIST_ARRIVE_MS")) ms = (uint32_t)std::max(1, atoi(t));
+  return (uint32_t)std::min<uint64_t>((uint64_t)ms * 100000ull, 0xFFFFFFF0ull);
+}
+
 static bool persist_wanted(const std::vector<PipeRun>& runs, bool single_launch_batch) {
   const char* v = getenv("ZPAQ_AMD_PIPE_PERSIST");
   if (v && !strcmp(v, "0")) return false;
@@ -630,8 +640,9 @@ static std::mutex& persist_device_mutex(int device) {
   return mu[(unsigned)device % 64u];
 }
 
-static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, bool* aborted, std::string* what) {
+static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, bool* aborted, std::string* what, bool* untouched) {
   *aborted = false;
+  *untouched = false;
   std::lock_guard<std::mutex> device_turn(persist_device_mutex(e.device >= 0 ? e.device : e.slot));
   // what the device holds
   std::vector<uint32_t> cap(runs.size());
@@ -689,6 +700,7 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
   Event fork;
   if (runs.size() > 1) HIP_CHECK(hipEventRecord(fork, st));
   std::vector<std::unique_ptr<Event>> joins;
+  uint32_t rounds_max = 0;
   for (size_t i = 0; i < runs.size(); ++i) {
     PipeRun& r = runs[i];
     hipStream_t rs = i == 0 ? st : e.side[i - 1];
@@ -697,6 +709,8 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
     const uint32_t most = std::max<uint32_t>(1u, cap[i] / r.ps_wpg);                  // groups that are resident together
     const uint32_t rounds = (r.ngroups + most - 1) / most;
     const uint32_t per_round = (r.ngroups + rounds - 1) / rounds;                     // (rounds of equal size)
+    rounds_max = std::max(rounds_max, rounds);
+    uint32_t arrived_before = 0;                                                      // workgroups of the run's earlier rounds
     for (uint32_t g0 = 0; g0 < r.ngroups; g0 += per_round) {
       PipeArgs a = r.args;
       a.step = 0; a.wg0 = 0;
@@ -710,6 +724,9 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
       if (const char* v = getenv("ZPAQ_AMD_PERSIST_SPREAD")) a.spread = atoi(v) == 8 ? 8u : 1u;      // (experiments)
       a.trace = i == prof_run ? d_prof : nullptr;
       const uint32_t grid = a.ngroups_here * r.ps_wpg;
+      arrived_before += grid;
+      a.arrive_need = arrived_before;
+      a.arrive_ticks = persist_arrive_ticks();
       void* args[1] = {(void*)&a};
       HIP_CHECK(hipModuleLaunchKernel(r.k->persist, grid, 1, 1, 64u * r.ps_waves, 1, 1, 0, rs, args, nullptr));
     }
@@ -731,14 +748,20 @@ static bool launch_pipe_persist(Engine& e, std::vector<PipeRun>& runs, hipStream
       fclose(f);
     }
   }
+  size_t n_untouched = 0;
   for (size_t i = 0; i < runs.size(); ++i) {
     uint32_t c[4] = {0, 0, 0, 0};
     HIP_CHECK(hipMemcpy(c, (uint32_t*)e.pipe_ctl.p + base[i], sizeof c, hipMemcpyDeviceToHost));
     if (c[0]) {
       *aborted = true;
-      if (what) *what = "run " + std::to_string(i) + ": the unit in slot " + std::to_string(c[1]) + " gave up waiting at chunk " + std::to_string(c[2]);
+      n_untouched += c[0] == 2u;
+      if (what) *what = "run " + std::to_string(i) + (c[0] == 2u
+          ? ": only " + std::to_string(c[3]) + " of its workgroups became resident together (something else holds compute units)"
+          : ": the unit in slot " + std::to_string(c[1]) + " gave up waiting at chunk " + std::to_string(c[2]));
     }
   }
+  // every run stopped at the arrival handshake of its FIRST round: no arena, stream or result has been written
+  *untouched = n_untouched == runs.size() && rounds_max == 1;
   return true;
 }
 
@@ -900,6 +923,16 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     pipe_off += (uint64_t)ng * L.group_bytes;
     runs.push_back(r);
   }
+  // packed MIX rows: the tables of the runs that keep them so are rewritten from Predictor::init's pattern (pipe_repack_body)
+  auto repack_runs = [&]() {
+    for (PipeRun& r : runs) {
+      if (!r.k->any_packed) continue;
+      PipeArgs a = r.args;
+      void* args[1] = {(void*)&a};
+      HIP_CHECK(hipModuleLaunchKernel(r.k->repack, r.args.nblocks, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+    }
+  };
+  repack_runs();
   // Groups (one per kernel kind / plan) are independent: fan the single-launch ones out over side streams so a
   // batch mixing several chains does not serialise one launch after the other.
   size_t nsingle = 0;
@@ -926,6 +959,7 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
   // the persistent launch when every group of the batch is a pipelined one, the call waits for its results anyway, and the
   // groups are resident together (one round, or rounds that are nearly full: a round costs a block's serial time whatever it holds)
   bool coded = false;
+  e.last_persist_abort_ms = 0.0;
   if (timed && nsingle == 0 && persist_wanted(runs, true)) {
     bool fits = true;
     if (runs.size() == 1 && persist_capacity(e, runs[0]) >= runs[0].ps_wpg) {
@@ -935,14 +969,20 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     }
     if (fits) {
       if (late && late->from_byte) HIP_CHECK(hipStreamWaitEvent(st, late->arrive(), 0));
-      bool aborted = false;
+      bool aborted = false, untouched = false;
       std::string what;
-      if (launch_pipe_persist(e, runs, st, &aborted, &what)) {
+      const auto t_launch = std::chrono::steady_clock::now();
+      if (launch_pipe_persist(e, runs, st, &aborted, &what, &untouched)) {
         coded = !aborted;
         if (aborted) {
-          fprintf(stderr, "[zpaq_amd] persistent encoder launch gave up (%s): coding the batch with the step kernels\n", what.c_str());
-          for (uint32_t b0 = 0; b0 < nb; b0 += 65535u)
-            HIP_CHECK(launch_init_arena(d_jobs + b0, std::min(nb - b0, 65535u), e.d_tables, chunks, st));
+          e.last_persist_abort_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
+          fprintf(stderr, "[zpaq_amd] persistent encoder launch gave up after %.1f ms (%s): coding the batch with the step kernels\n",
+                  e.last_persist_abort_ms, what.c_str());
+          if (!untouched) {
+            for (uint32_t b0 = 0; b0 < nb; b0 += 65535u)
+              HIP_CHECK(launch_init_arena(d_jobs + b0, std::min(nb - b0, 65535u), e.d_tables, chunks, st));
+            repack_runs();
+          }
         }
       }
     }

@@ -40,6 +40,7 @@ void engine_set_budget(uint64_t bytes);
 void engine_set_kernel(int which);
 Timing engine_last_timing();
 bool engine_last_persistent();
+double engine_last_persist_abort_ms();
 void engine_plan_release(zpq_plan* p);
 // 4 pipelined encoder (compression only) / 3 specialised / 2 generic wave / 1 generic one-lane; note = origin of the specialised kernel or why not
 int engine_plan_kernel_kind(zpq_plan* p, std::string& note, bool decode = false, uint32_t nblocks = 0, uint32_t block_bytes = 0);   // nblocks = 0: a batch that fills the GPU

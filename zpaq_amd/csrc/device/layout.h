@@ -153,13 +153,17 @@ struct PipeArgs {
   // words per workgroup and launch, record index = trace_base + blockIdx.x; null otherwise
   unsigned long long* trace;
   uint32_t trace_base;
-  uint32_t reserved;
+  uint32_t arrive_need;           // persistent launch: ctl[3] counts the workgroups that have started; a unit begins only when it says
+                                  // this many (every workgroup of this launch and of the run's earlier rounds); 0: no handshake
   // The persistent launch (device/pipe_persist.h): one workgroup set per group of blocks for the whole sequence
   uint32_t* prog;                 // progress counters, PS_NUNIT per group, zero at launch
   const uint32_t* group_chunks;   // per group: chunks of its longest block (at least 1)
-  uint32_t* ctl;                  // [0] abort flag (zero at launch), [1] the slot whose watchdog fired, [2] its chunk
+  uint32_t* ctl;                  // [0] abort flag (zero at launch; 1: a unit's watchdog fired in mid-sequence, 2: the launch's workgroups
+                                  // never became resident together -- nothing was touched), [1] the slot whose watchdog fired, [2] its
+                                  // chunk, [3] workgroups that have started
   uint32_t group0, ngroups_here;  // the groups this launch serves
   uint32_t timeout_ticks;         // 100 MHz ticks a poller waits without progress before it raises the abort flag
+  uint32_t arrive_ticks;          // 100 MHz ticks without a new arrival before a waiting wavefront gives the launch up (flag 2)
   uint32_t spread;                // 8: the workgroups of a group share an XCD (workgroup b of the first 8 * (ngroups / 8) groups serves group
                                   // b % 8 + 8 * (b / 8 / PS_WPG); the other groups' workgroups follow one after the other); 1: group b / PS_WPG
 };

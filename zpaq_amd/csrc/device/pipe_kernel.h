@@ -930,12 +930,15 @@ __device__ __forceinline__ void pipe_match_in(PipeLane<Chain>& L, const PipeStre
   L.state(sw + 8) = pwin; L.state(sw + 9) = age;
 }
 
-// the MATCH unit: from the input when every block of the wavefront fits the history buffer (a property of the blocks'
-// lengths: the same choice at every chunk), through the buffer in the arena otherwise
+// the MATCH unit: from the input when the history ring of every block of the wavefront can never be read where it has
+// been written a lap earlier (a property of the blocks' lengths: the same choice at every chunk), through the buffer in
+// the arena otherwise.  update0 compares up to 255 bytes backwards from a candidate (libzpaq.cpp:1995-1998) with indices
+// taken modulo the buffer size: behind a candidate near the block's start that reaches the END of the ring, which
+// pipe_match_in takes for never written (zeros) -- true only while len + 255 <= buffer size.
 template <class Chain, int I, class DT2K>
 __device__ __forceinline__ void pipe_match_any(PipeLane<Chain>& L, const PipeStretch& stretch, const DT2K& dt2k) {
   constexpr CompK c = Chain::comp[I];
-  if (pipe_any(L.live && L.len > c.mask1 + 1u)) pipe_match<Chain, I>(L, stretch, dt2k);
+  if (pipe_any(L.live && L.len + 255u > c.mask1 + 1u)) pipe_match<Chain, I>(L, stretch, dt2k);
   else pipe_match_in<Chain, I>(L, stretch, dt2k);
 }
 
@@ -2017,6 +2020,197 @@ __device__ __forceinline__ void pipe_mix_unit(PipeLane<Chain>& L, unsigned q, un
   }
 }
 
+// ---- MIX with PACKED weight rows ------------------------------------------------------------------------------------
+// Requests, not bytes, bound the encoder at 1024 blocks, and a MIX touches one row per bit.  Weights are
+// clamped to +-2^19 (clamp512k, libzpaq.cpp:2028-2030; predict reads wt >> 8, 1913-1917), so four of them fit 3 dwords:
+//   d0 = w0 | w1 << 24      d1 = w1 >> 8 | w2 << 16      d2 = w2 >> 16 | w3 << 8          (24 bits each, two's complement)
+// and lane q's quad of a row sits at byte 12 q of it.  A row of up to 20 weights is then 60 bytes in a 64-byte stride where the
+// padded 32-bit form takes a 128-byte line (MIX_PSTRIDE: the next power of two that holds 12 bytes per weight quad) -- half the
+// bytes each way per touch -- and, packed, the rows of a SMALL table that a byte's first bits select fit the LDS:
+// rows [0, LROWS) of the mixer live there for the whole sequence inside the persistent launch (m8 of compressBlock's level 5:
+// the row is the partial byte c0, rows below 128 are bits 0 .. 6 of every byte -- 7 of the mixer's 8 row touches per byte
+// never leave the compute unit), as [dword][row][quad][block of the wavefront] so that what a wavefront reads in one
+// instruction is spread over the banks by the blocks' different rows.
+// The arena holds the table in this form from the start: zpq_pipe_repack (below) rewrites Predictor::init's 65536 / m
+// pattern once per block before the encoder runs; nothing but these units reads the table.
+// Same structure as pipe_mix_unit (NH = 1, the byte's 8 rows distinct): a byte's HBM rows are fetched one byte ahead and
+// patched by the forwarding rules there; LDS rows are read behind the previous byte's stores, in program order.
+struct PipeW3 { unsigned x, y, z; };
+typedef __attribute__((address_space(1))) PipeW3 g_w3;
+
+__device__ __forceinline__ int pipe_sext24(unsigned v) { return (int)(v << 8) >> 8; }
+__device__ __forceinline__ void pipe_unpack4(const PipeW3& d, int& w0, int& w1, int& w2, int& w3) {
+  w0 = pipe_sext24(d.x);
+  w1 = pipe_sext24((d.x >> 24) | (d.y << 8));
+  w2 = pipe_sext24((d.y >> 16) | (d.z << 16));
+  w3 = (int)d.z >> 8;
+}
+__device__ __forceinline__ PipeW3 pipe_pack4(int w0, int w1, int w2, int w3) {
+  PipeW3 d;
+  d.x = ((unsigned)w0 & 0xFFFFFFu) | ((unsigned)w1 << 24);
+  d.y = (((unsigned)w1 >> 8) & 0xFFFFu) | ((unsigned)w2 << 16);
+  d.z = (((unsigned)w2 >> 16) & 0xFFu) | ((unsigned)w3 << 8);
+  return d;
+}
+
+// bytes from one packed row to the next: 12 per weight quad, rounded up to a power of two (at most the padded 32-bit row)
+__device__ __forceinline__ constexpr unsigned pipe_mix_pstride(unsigned m) {
+  const unsigned need = 12u * ((m + 3u) / 4u);
+  unsigned p = 16u;
+  while (p < need) p *= 2u;
+  return p;
+}
+
+template <class Chain, class = void> struct PipeMixLdsRows { static constexpr int of(int) { return 0; } };
+template <class Chain> struct PipeMixLdsRows<Chain, decltype((void)Chain::MIX_LDS_ROWS)> { static constexpr int of(int r) { return Chain::MIX_LDS_ROWS[r]; } };
+
+// one chunk of MIX role r on packed rows.  q = the lane's weight quad, bl = the lane's block among the BPW of its wavefront;
+// lds = the unit's private region (LROWS > 0 only), stage = first chunk: copy rows [0, LROWS) from the arena
+template <class Chain, int r, int LROWS, int BPW, class SQ>
+__device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigned q, unsigned bl, unsigned* lds, bool stage, const SQ& squash) {
+  constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r];
+  constexpr CompK c = Chain::comp[I];
+  constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
+  constexpr int NQ = (m + 3) / 4;
+  constexpr unsigned PS = pipe_mix_pstride((unsigned)m);
+  static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "packed MIX rows: the 8 rows of a byte are distinct");
+  static_assert(PS <= 4u * c.stride, "a packed row fits the padded row's place");
+  if (!L.nb) return;
+  const bool act = q < (unsigned)NQ;                   // lanes that hold weights (the others: zero inputs, no stores)
+  const unsigned qoff = 12u * (act ? q : 0u);
+  bool have[4];
+  int tin[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int t = (int)q * 4 + x;
+    have[x] = t < m;
+    tin[x] = J + (have[x] ? t : 0);
+  }
+  // row index of bit b of a byte, and where its quad lives
+  auto row_of = [&](unsigned hh, unsigned bytev, int b) __attribute__((always_inline)) -> unsigned { return (hh + pipe_c8(bytev, b)) & c.mask0; };
+  auto addr_of = [&](unsigned row) __attribute__((always_inline)) -> unsigned { return (unsigned)c.t0 + row * PS + qoff; };
+  // LDS: [dword][row][quad][block]
+  auto lds_at = [&](unsigned row, unsigned w) __attribute__((always_inline)) -> unsigned {
+    return ((w * (unsigned)(LROWS > 0 ? LROWS : 1) + row) * (unsigned)NQ + (act ? q : 0u)) * (unsigned)BPW + bl;
+  };
+  if constexpr (LROWS > 0) {
+    if (stage && act)
+      for (unsigned row = 0; row < (unsigned)LROWS && row <= c.mask0; ++row) {
+        const PipeW3 d = *(g_w3*)(L.arena + addr_of(row));
+        lds[lds_at(row, 0)] = d.x; lds[lds_at(row, 1)] = d.y; lds[lds_at(row, 2)] = d.z;
+      }
+  }
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  const unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
+    const uint4 v = L.p(tin[x], kk);
+    const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
+    return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+  };
+  uint4 pv[4], pv1[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) { pv[x] = inputs(x, 0); pv1[x] = inputs(x, k1); }
+  // a row that lives in the LDS is not fetched from the arena: its request goes to the table's first line instead (a line
+  // this wavefront keeps in the L1: no branch around a request -- see pipe_match_in -- and no transaction at the L2)
+  auto in_lds = [&](unsigned row) __attribute__((always_inline)) -> bool { return LROWS > 0 && row < (unsigned)LROWS; };
+  auto fetch = [&](unsigned row) __attribute__((always_inline)) -> PipeW3 { return *(g_w3*)(L.arena + addr_of(in_lds(row) ? 0u : row)); };
+  PipeW3 w[8];
+  unsigned rowc[8];
+#pragma unroll
+  for (int B = 0; B < 8; ++B) { rowc[B] = row_of(h, byte, B); w[B] = fetch(rowc[B]); }
+  if constexpr (LROWS > 0) {
+#pragma unroll
+    for (int B = 0; B < 8; ++B)
+      if (in_lds(rowc[B])) { w[B].x = lds[lds_at(rowc[B], 0)]; w[B].y = lds[lds_at(rowc[B], 1)]; w[B].z = lds[lds_at(rowc[B], 2)]; }
+  }
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    uint4 pv2[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
+    unsigned rown[8];
+#pragma unroll
+    for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
+    // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint), forwarded
+    // below; contexts less than 256 apart -> any position may coincide: fetched after the stores
+    const bool same = h1 == h;
+    const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
+    PipeW3 wn[8], nw[8];
+    if (!late) {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) wn[B] = fetch(rown[B]);
+    }
+    PipeP8 out;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      int w0, w1, w2, w3;
+      pipe_unpack4(w[B], w0, w1, w2, w3);
+      const int p0 = pipe_p_get(pv[0], B), p1 = pipe_p_get(pv[1], B), p2 = pipe_p_get(pv[2], B), p3 = pipe_p_get(pv[3], B);
+      const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
+      const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
+      out.set(B, pr);
+      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
+      nw[B] = pipe_pack4(sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13)), sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13)),
+                         sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13)), sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13)));
+      if (act) {
+        if (in_lds(rowc[B])) { lds[lds_at(rowc[B], 0)] = nw[B].x; lds[lds_at(rowc[B], 1)] = nw[B].y; lds[lds_at(rowc[B], 2)] = nw[B].z; }
+        else *(g_w3*)(L.arena + addr_of(rowc[B])) = nw[B];
+      }
+    }
+    if (q == 0) L.put_p(I, k, out.get());
+    if (late) {
+#pragma unroll
+      for (int B = 0; B < 8; ++B) wn[B] = fetch(rown[B]);
+    }
+#pragma unroll
+    for (int B = 0; B < 8; ++B) {
+      const bool fw = same && rown[B] == rowc[B];
+      w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y; w[B].z = fw ? nw[B].z : wn[B].z;
+    }
+    if constexpr (LROWS > 0) {      // (behind this byte's LDS stores, in program order: no forwarding needed)
+#pragma unroll
+      for (int B = 0; B < 8; ++B)
+        if (in_lds(rown[B])) { w[B].x = lds[lds_at(rown[B], 0)]; w[B].y = lds[lds_at(rown[B], 1)]; w[B].z = lds[lds_at(rown[B], 2)]; }
+    }
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+#pragma unroll
+    for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
+  }
+}
+
+// which MIX roles of a chain keep packed rows (host/codegen.cpp decides: MIX_PACKED in the generated chain)
+template <class Chain, class = void> struct PipeMixPacked { static constexpr bool of(int) { return false; } };
+template <class Chain> struct PipeMixPacked<Chain, decltype((void)Chain::MIX_PACKED)> { static constexpr bool of(int r) { return Chain::MIX_PACKED[r] != 0; } };
+
+// Predictor::init wrote 65536 / m into every dword of a MIX table (libzpaq.cpp:1822-1826); the packed units want the same
+// weights as 24-bit quads.  One workgroup per block, before the encoder's first launch (engine.cpp; tests/emu does the same).
+template <class Chain>
+__device__ __forceinline__ void pipe_repack_body(const PipeArgs& a) {
+  const unsigned blk = blockIdx.x;
+  if (blk >= a.nblocks) return;
+  g_u8* const arena = (g_u8*)a.jobs[blk].arena;
+  static_for<0, Chain::NMIXR>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    if constexpr (PipeMixPacked<Chain>::of(r)) {
+      constexpr CompK c = Chain::comp[Chain::MIX_COMP[r]];
+      constexpr unsigned m = c.a3, PS = pipe_mix_pstride(m), NQ = (m + 3u) / 4u;
+      constexpr int v = (int)(65536u / m);
+      const PipeW3 d = pipe_pack4(v, v, v, v);
+      const unsigned per_row = PS / 4u;                                        // dwords
+      const unsigned long long words = (unsigned long long)(c.mask0 + 1u) * per_row;
+      for (unsigned long long i = threadIdx.x; i < words; i += blockDim.x) {
+        const unsigned j = (unsigned)(i % per_row);
+        const unsigned val = j < 3u * NQ ? (j % 3u == 0u ? d.x : (j % 3u == 1u ? d.y : d.z)) : 0u;
+        *(g_u32*)(arena + (unsigned long long)c.t0 + 4ull * i) = val;
+      }
+    }
+  });
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
   if constexpr (Chain::MIX_BITS != 0) {
@@ -2043,7 +2237,8 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
     if (bl >= (unsigned)BPW) { L.live = false; L.nb = 0; }          // lanes beyond this wavefront's blocks
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-    pipe_mix_unit<Chain, r, 1>(L, q, 0u, squash);
+    if constexpr (PipeMixPacked<Chain>::of(r)) pipe_mix_packed_unit<Chain, r, 0, 1>(L, q, 0u, nullptr, false, squash);
+    else pipe_mix_unit<Chain, r, 1>(L, q, 0u, squash);
   });
   }
 }

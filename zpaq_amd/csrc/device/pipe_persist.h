@@ -132,6 +132,31 @@ __device__ __forceinline__ bool pipe_wait(const PipeArgs& a, const unsigned* pro
   return true;
 }
 
+// Arrival handshake.  The units spin on each other, so a launch makes progress only if ALL its workgroups are resident at the
+// same time.  The engine sizes the grid from the occupancy API, but it cannot know what else holds compute units (another
+// process, the host application's own kernels): a workgroup left in the queue would let every unit that depends on it spin
+// until the watchdog (seconds), with the arenas half coded.  So every workgroup first says it is there (ctl[3]) and no
+// wavefront touches anything before all of them have: if the count stops short for arrive_ticks, the launch is given up
+// with flag 2 -- nothing has been written, the engine hands the batch to the step kernels at once (no re-initialisation).
+// false: do not start.
+__device__ __forceinline__ bool pipe_arrived(const PipeArgs& a, int lane) {
+  if (!a.arrive_need) return true;
+  unsigned seen = pipe_prog_load(a.ctl + 3);
+  if (seen >= a.arrive_need) return true;
+  unsigned long long t0 = pipe_clock();
+  for (;;) {
+    pipe_nap();
+    const unsigned now = pipe_prog_load(a.ctl + 3);
+    if (now >= a.arrive_need) return true;
+    if (pipe_prog_load(a.ctl) != 0u) return false;
+    if (now != seen) { seen = now; t0 = pipe_clock(); }
+    else if (pipe_clock() - t0 > (unsigned long long)a.arrive_ticks) {
+      if (lane == 0) pipe_flag_set(a.ctl, 2u);
+      return false;
+    }
+  }
+}
+
 template <class Chain>
 __device__ __forceinline__ void pipe_publish(unsigned* prog, int unit, int lane) {
   pipe_drain_stores();
@@ -151,7 +176,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
   const unsigned nchunks = a.group_chunks[g];
   unsigned char* const priv = lds + Chain::PS_LDS[SLOT];
   PipeLane<Chain> L;
-  unsigned q = 0, B = 0;
+  unsigned q = 0, B = 0, mix_bl = 0;
   // lane -> block
   if constexpr (kind == 0) {
     constexpr int HL = Chain::HCOMP_LANES < (int)G ? Chain::HCOMP_LANES : (int)G;
@@ -169,6 +194,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       constexpr int BPW = 64 / (QL * NH) < (int)G ? 64 / (QL * NH) : (int)G;       // all 64 lanes: 64 / (QL NH) blocks per wavefront
       const unsigned bl = (unsigned)lane / (QL * NH);
       q = (unsigned)lane % QL; B = ((unsigned)lane / QL) % NH;       // (B: the half)
+      mix_bl = bl;
       const bool okl = bl < (unsigned)BPW;
       L.bind(a, g, (unsigned)sub * BPW + (okl ? bl : 0u), okl);
     }
@@ -202,6 +228,11 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     } else if constexpr (kind == 5) {
       if (pipe_any(L.nb > 0)) {
         if constexpr (Chain::MIX_BITS != 0) pipe_mix_bits_unit<Chain, role>(L, q, B, ro.squash);
+        else if constexpr (PipeMixPacked<Chain>::of(role)) {
+          constexpr int QL = Chain::MIX_QL[role], BPW = 64 / QL < (int)G ? 64 / QL : (int)G;
+          static_assert(Chain::PS_MIX_NH == 1, "packed MIX rows: one lane group per block");
+          pipe_mix_packed_unit<Chain, role, PipeMixLdsRows<Chain>::of(role), BPW>(L, q, mix_bl < (unsigned)BPW ? mix_bl : 0u, (unsigned*)priv, c == 0, ro.squash);
+        }
         else pipe_mix_unit<Chain, role, Chain::PS_MIX_NH>(L, q, B, ro.squash);
       }
     } else {
@@ -246,6 +277,7 @@ __device__ __forceinline__ void pipe_persist_body(const PipeArgs& a) {
   for (int i = tid; i < 256; i += (int)blockDim.x) ((unsigned*)ro.ns)[i] = ((const unsigned*)a.tb->ns)[i];
   ro.squash.load(a.tb, tid);
   ro.stretch.load(a.tb, tid);
+  if (tid == 0 && a.arrive_need) pipe_prog_add(a.ctl + 3);
   __syncthreads();
   // workgroup -> (group, flavour).  The dispatcher deals the workgroups of a launch round-robin over the XCDs (from where the
   // launch before left off: which XCD a residue class lands on is not known, that a class shares one is): with spread = 8 the
@@ -260,6 +292,7 @@ __device__ __forceinline__ void pipe_persist_body(const PipeArgs& a) {
   g += a.group0;
   if (g >= a.group0 + a.ngroups_here) return;
   const int slot = (int)flavour * Chain::PS_WAVES + wave;
+  if (!pipe_arrived(a, lane)) return;
   static_for<0, Chain::PS_NSLOT>([&](auto sc) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value;
     if constexpr (Chain::PS_KIND[S] >= 0) {

@@ -449,6 +449,7 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit, bool* did_
   static const char* names[6] = {"zpq_pipe_hcomp", "zpq_pipe_rows", "zpq_pipe_light", "zpq_pipe_icm", "zpq_pipe_isse", "zpq_pipe_mix"};
   bool ok = hipModuleLoadData(&k->module, code.data()) == hipSuccess;
   for (int i = 0; ok && i < 6; ++i) ok = hipModuleGetFunction(&k->fn[i], k->module, names[i]) == hipSuccess;
+  ok = ok && hipModuleGetFunction(&k->repack, k->module, "zpq_pipe_repack") == hipSuccess;
   if (!ok) {
     plan->cur().pipe_note = "hipModuleLoadData failed for " + origin;
     if (k->module) (void)hipModuleUnload(k->module);
@@ -456,6 +457,11 @@ PipeKernel* pipe_kernel_for(zpq_plan* plan, int mode, bool allow_jit, bool* did_
     return nullptr;
   }
   if (hipModuleGetFunction(&k->persist, k->module, "zpq_pipe_persist") != hipSuccess) { (void)hipGetLastError(); k->persist = nullptr; }
+  {
+    PipeLayout PL;
+    std::string why2;
+    if (pipe_layout(*plan, pipe_options(mode), PL, why2)) for (int v : PL.mix_packed) k->any_packed = k->any_packed || v != 0;
+  }
   k->origin = origin;
   plan->cur().pipe[mode] = k;
   plan->cur().pipe_state[mode] = 1;

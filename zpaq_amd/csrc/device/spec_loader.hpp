@@ -36,6 +36,8 @@ void spec_kernel_release(zpq_plan* plan);
 struct PipeKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hcomp, rows, light, icm, isse, mix
+  hipFunction_t repack = nullptr;      // rewrites Predictor::init's MIX tables as packed rows where the chain keeps them so (pipe_repack_body)
+  bool any_packed = false;             // ... and whether it has anything to do
   hipFunction_t persist = nullptr;     // the persistent launch (device/pipe_persist.h), when the chain can be packed
   int persist_wg_per_cu = 0;           // workgroups of it a compute unit holds (occupancy API; 0: not asked yet)
   std::string origin;

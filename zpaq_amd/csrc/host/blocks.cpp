@@ -429,6 +429,26 @@ std::vector<U8> decode_payload(const std::vector<U8>& header, const U8* payload,
   return std::vector<U8>(decoded.begin(), decoded.end());
 }
 
+// The first `limit` bytes of ONE segment's coded stream (Decompresser::decompress(n), libzpaq.cpp:2315-2343: a caller may
+// stop there).  The device decodes from the block's first bit and stops at `limit` bytes or at the end of the segment,
+// whichever comes first: *complete says which.
+std::vector<U8> decode_payload_prefix(const std::vector<U8>& header, const std::vector<U8>& payload, U64 limit, bool* complete) {
+  PlanCache plans;
+  RawBytes decoded;
+  if (payload.size() > 0xFFFFFFF0ull || limit > 0xFFFFFFF0ull) fail(ZPQ_E_NOMEM, "segment too large");
+  decoded.resize(limit);
+  std::vector<HostBlock> hb(1, HostBlock{plan_for(plans, header), nullptr, 0, payload.data(), (U32)payload.size(), decoded.data(), (U32)limit});
+  std::vector<BlockResult> res;
+  engine_code_host(true, hb, res);
+  if (res[0].status == ZPQ_E_CORRUPT) fail(ZPQ_E_CORRUPT, "archive corrupted");
+  if (res[0].status == ZPQ_E_EOF) fail(ZPQ_E_EOF, "unexpected end of file");
+  if (res[0].status == ZPQ_E_VM) fail(ZPQ_E_VM, "ZPAQL execution error");
+  if (res[0].status) fail(res[0].status, "device decoder failed");
+  *complete = res[0].consumed != 0;                       // (0: the limit was reached before the end-of-segment code)
+  decoded.resize(std::min<U64>(res[0].out_len, limit));
+  return std::vector<U8>(decoded.begin(), decoded.end());
+}
+
 // The segments of ONE modelled block decoded together (model and coder state run on from segment to segment):
 // payloads[s] = coded bytes of segment s incl. its terminator; returns the decoded bytes per segment.
 std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& payloads, U64 hint) {

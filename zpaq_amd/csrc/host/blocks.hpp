@@ -42,6 +42,7 @@ std::vector<U8> encode_payload(const std::vector<U8>& header, const U8* pp, size
 // block): segments[0] starts with the PP header; returns each segment's coded bytes (its end-of-segment code included).
 std::vector<std::vector<U8>> encode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& segments);
 // ... and back: payloads[s] = coded bytes of segment s incl. terminator -> decoded bytes per segment (PP header in the first)
+std::vector<U8> decode_payload_prefix(const std::vector<U8>& header, const std::vector<U8>& payload, U64 limit, bool* complete);
 std::vector<std::vector<U8>> decode_payload_segments(const std::vector<U8>& header, const std::vector<std::vector<U8>>& payloads, U64 hint);
 
 // Decodes one modelled payload (coded bytes + zero terminator) to EOS on the

@@ -304,7 +304,14 @@ PipeOptions pipe_options(int variant) {
 // kernels then code it step by step.
 static const int kPersistRoBytes = 4096 + 512 + 2688 + (2016 * 4 + 512) + 1024;      // = sizeof(zpq::PipeRO) on the device
 static const int kPersistLdsCap = 163840 - 512;                                       // gfx950: 160 KiB per workgroup
-static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
+static uint32_t mix_pstride(uint32_t m) {              // = device pipe_mix_pstride
+  const uint32_t need = 12u * ((m + 3u) / 4u);
+  uint32_t p = 16u;
+  while (p < need) p *= 2u;
+  return p;
+}
+// lds_rows_wish: rows of a SMALL packed MIX table (up to 256 rows: the mixer selected by the partial byte alone) kept in the LDS
+static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wish) {
   const CompDesc* comp = plan.comps();
   const PlanHeader& ph = plan.hdr();
   const int n = L.n, G = L.G;
@@ -359,9 +366,21 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L) {
     }
     if (ok) L.ps_mix_nh = 2;
   }
+  L.mix_lds_rows.assign(L.mix.size(), 0);
   for (size_t r = 0; r < L.mix.size(); ++r) {
     const int nw = L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] * L.ps_mix_nh / 64);
-    for (int sub = 0; sub < nw; ++sub) add(5, (int)r, sub, p_unit[L.mix[r]], 0, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : 2.6f));
+    // packed rows of a small table: the first rows in the LDS of every wavefront of the unit (3 dwords per weight quad, row and
+    // block of the wavefront: pipe_mix_packed_unit)
+    int lds = 0;
+    const CompDesc& c = comp[L.mix[r]];
+    if (!L.mix_bits && L.ps_mix_nh == 1 && L.mix_packed[r] && c.mask0 + 1u <= 256u && lds_rows_wish > 0) {
+      const int rows = std::min<int>(lds_rows_wish, (int)(c.mask0 + 1u));
+      const int nq = ((int)c.a3 + 3) / 4, bpw = std::max(1, std::min(G, 64 / L.mix_ql[r]));
+      L.mix_lds_rows[r] = rows;
+      lds = 3 * rows * nq * bpw * 4;
+    }
+    for (int sub = 0; sub < nw; ++sub)
+      add(5, (int)r, sub, p_unit[L.mix[r]], lds, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : (lds ? 1.6f : 2.6f)));
   }
   // who reads whose streams
   std::vector<std::vector<int>> producers(nunit);
@@ -568,7 +587,32 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
   L.off_state = off; off += (uint64_t)L.nstate * G * 4;
   L.group_bytes = (off + 4095) & ~4095ull;
   if (L.group_bytes >= (1ull << 32)) { why_not = "stream buffer of a block group exceeds 4 GiB"; return false; }
-  plan_persistent(plan, L);
+  // packed MIX rows (device/pipe_kernel.h): a mixer whose rows are distinct per bit, with 3 .. 64 inputs, whose packed row is
+  // smaller than its padded one or whose table is small enough to be worth keeping in the LDS; not with a lane per bit position
+  L.mix_packed.assign(L.mix.size(), 0);
+  static const bool packed_off = [] { const char* v = getenv("ZPAQ_AMD_MIX_PACKED"); return v && v[0] == '0'; }();
+  for (size_t r = 0; r < L.mix.size(); ++r) {
+    const CompDesc& c = comp[L.mix[r]];
+    const uint32_t ps = mix_pstride(c.a3);
+    if (!packed_off && !L.mix_bits && c.a5 == 255u && c.mask0 >= 255u && c.a3 >= 3u && ps <= 4u * c.stride && (ps < 4u * c.stride || c.mask0 + 1u <= 256u))
+      L.mix_packed[r] = 1;
+  }
+  // the persistent launch: with as many of a small packed table's rows in the LDS as still pack into the same number of
+  // workgroups per group as none would (a ninth workgroup per group would cost the headline its one-round residency)
+  static const int rows_forced = [] { const char* v = getenv("ZPAQ_AMD_MIX_LDS_ROWS"); return v ? atoi(v) : -1; }();
+  plan_persistent(plan, L, 0);
+  if (L.persist_ok) {
+    const int wpg0 = L.ps_wpg;
+    for (int wish : {128, 64, 32}) {
+      if (rows_forced >= 0 && wish != rows_forced) continue;
+      PipeLayout T = L;
+      plan_persistent(plan, T, wish);
+      bool any = false;
+      for (int v : T.mix_lds_rows) any = any || v != 0;
+      if (!any) break;
+      if (T.persist_ok && T.ps_wpg <= wpg0) { L = T; break; }
+    }
+  }
   return true;
 }
 
@@ -636,6 +680,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
   arr("MIX_COMP", L.mix.data(), (int)L.mix.size());
   arr("MIX_QL", L.mix_ql.data(), (int)L.mix_ql.size());
   arr("MIX_FIRST", mf.data(), (int)mf.size());
+  arr("MIX_PACKED", L.mix_packed.data(), (int)L.mix_packed.size());
   const U8* prog = plan.blob.data() + ph.off_prog;
   if (!translate_hcomp(prog, (int)ph.prog_len, o)) { why_not = "HCOMP program too irregular to translate"; return false; }
   o << "};\n";
@@ -664,6 +709,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     arr("PS_DEP_UNIT", du.data(), (int)du.size());
     arr("PS_DEP_LAG", dl.data(), (int)dl.size());
     arr("PS_DEP_MULT", dm.data(), (int)dm.size());
+    arr("MIX_LDS_ROWS", L.mix_lds_rows.data(), (int)L.mix_lds_rows.size());
     o << "};\n";
   }
   o << "}  // namespace zpq_gen\n";
@@ -672,6 +718,8 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
          "  zpq::pipe_persist_body<zpq_gen::ChainP>(a);\n}\n";
   else
     o << "#ifdef ZPQ_EMU\nextern \"C\" void zpq_pipe_persist(zpq::PipeArgs) {}\n#endif\n";     // (the emulator's driver links against the name)
+  o << "extern \"C\" __global__ __launch_bounds__(256) void zpq_pipe_repack(zpq::PipeArgs a) {\n"      // one workgroup per block, before the first launch
+       "  zpq::pipe_repack_body<zpq_gen::Chain>(a);\n}\n";
   const char* names[6] = {"hcomp", "rows", "light", "icm", "isse", "mix"};
   for (int k = 0; k < 6; ++k)
     o << "extern \"C\" __global__ __launch_bounds__(64) void zpq_pipe_" << names[k] << "(zpq::PipeArgs a) {\n"   // launched with PIPE_G threads (hcomp, light, bit-lane mix: 64)

@@ -8,7 +8,7 @@
 
 namespace zpq {
 
-static const int kCodegenVersion = 5;
+static const int kCodegenVersion = 6;
 
 // Emits the specialised translation unit for `plan`.  Returns false (with a
 // reason) when the chain cannot be specialised (n > 64, MIX wider than a wave,
@@ -59,6 +59,8 @@ struct PipeLayout {
   bool hcomp_h_lds = false;    // H staged in LDS
   std::vector<std::pair<int, int>> light;   // (PipeKind, component): CONS, CM, MATCH, AVG, MIX2, SSE units and the coder
   std::vector<int> rows, icm, isse, mix, mix_ql;
+  std::vector<int> mix_packed;   // per MIX role: 1 = weight rows as 24-bit quads (device/pipe_kernel.h pipe_mix_packed_unit); the arena holds them so
+  std::vector<int> mix_lds_rows; // per MIX role, persistent launch: rows [0, n) of the packed table live in the unit's LDS (0: none)
   std::vector<int> light_sub;  // per light unit: which eighth of the group's blocks (units with a lane per bit position), else 0
   uint64_t off_ctx = 0, off_bh = 0, off_p = 0, off_state = 0, group_bytes = 0;
   // kernel-level dataflow (0 hcomp, 1 rows, 2 light, 3 icm, 4 isse, 5 mix): consumes[c][p] = some unit of kernel c reads a

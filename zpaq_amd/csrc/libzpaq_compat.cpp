@@ -251,7 +251,7 @@ void random(char* buf, int n) {
 // decompress() is called for it, and then served in the requested pieces.
 Decompresser::Decompresser()
     : in_(0), out_(0), sha1_(0), rpos_(0), plan_(0), dpos_(0), payload_end_(0), seg_decoded_(false),
-      segs_in_block_(0), pp_(0), skipped_in_block_(false), state_(BLOCK) {}
+      segs_in_block_(0), pp_(0), skipped_in_block_(false), prefix_tried_(false), prefix_active_(false), state_(BLOCK) {}
 Decompresser::~Decompresser() { delete (zpq::PostProcessor*)pp_; }
 
 int Decompresser::getc() {
@@ -363,6 +363,54 @@ void Decompresser::readComment(Writer* comment) {
   seg_decoded_ = false;
   decoded_.clear();
   dpos_ = 0;
+  prefix_tried_ = prefix_active_ = false;
+  prefix_.clear();
+}
+
+// The coded payloads of the block's remaining segments, read AHEAD of the input position without consuming anything: this
+// payload, its trailer and any further segments up to the end of the block.
+void Decompresser::peek_block_payloads(std::vector<std::vector<U8> >& payloads) {
+  size_t off = 0;
+  auto need = [&](size_t o) -> int { const int c = peek(o); if (c < 0) error("unexpected end of file"); return c; };
+  for (;;) {
+    std::vector<U8> pl;
+    U32 curr = 0;
+    int c = 0;
+    while (curr == 0) { c = need(off++); pl.push_back((U8)c); curr = (U32)c; }
+    while (curr) { c = need(off++); pl.push_back((U8)c); curr = curr << 8 | (U32)c; }
+    while ((c = peek(off)) == 0) { pl.push_back(0); ++off; }     // a flush byte of 00 puts a fifth zero in front
+    payloads.push_back(pl);
+    c = need(off++);                                             // trailer
+    if (c == 253) off += 20;
+    else if (c != 254) error("missing end of segment marker");
+    c = need(off++);
+    if (c != 1) break;                                           // 255: end of block
+    while (need(off++) != 0) {}                                  // filename
+    while (need(off++) != 0) {}                                  // comment
+    if (need(off++) != 0) error("missing reserved byte");
+  }
+}
+
+// Decompresser::decompress(n) with a small n (libzpaq.cpp:2315-2343; zpaq.cpp:2859-2866 stops as soon as it has the
+// fragments it wants): the device decodes a block from its first bit, and its time is the number of bits it decodes, so
+// the first call decodes a PREFIX -- kPrefixBytes of output, ~6 % of a 1 MiB block's decode time -- and hands out of that;
+// only a caller that asks for more pays for the whole block (decode_segment).  Taken for the first segment of a modelled
+// block that has no other segment and no PCOMP program (the prefix of a post-processed stream is not the prefix of its
+// output); nothing is consumed from the input and no state but prefix_ changes, so every other path goes on as if this
+// had not happened.
+static const size_t kPrefixBytes = 65536;
+void Decompresser::try_prefix() {
+  prefix_tried_ = true;
+  if (header_[6] == 0 || skipped_in_block_ || segs_in_block_ != 0 || pp_ == 0) return;
+  std::vector<std::vector<U8> > payloads;
+  peek_block_payloads(payloads);
+  if (payloads.size() != 1 || payloads[0].size() < 4096) return;          // (a short payload: the whole block costs little)
+  bool complete = false;
+  std::vector<U8> got;
+  guarded([&] { got = zpq::decode_payload_prefix(header_, payloads[0], kPrefixBytes + 1, &complete); });
+  if (complete || got.empty() || got[0] != 0) return;                     // ended inside the prefix / PCOMP follows: the ordinary way
+  prefix_.assign(got.begin() + 1, got.end());
+  prefix_active_ = true;
 }
 
 // Gathers this segment's payload from the input (up to and including the zero
@@ -374,28 +422,9 @@ void Decompresser::decode_segment() {
     if (skipped_in_block_) error("decompression after skipped segment");
     const int my_index = segs_in_block_++;
     if (my_index == 0) {
-      // The model and the coder run on from segment to segment, so the block's segments are decoded together: look
-      // ahead (without consuming) over this payload, its trailer and any further segments up to the end of the block
+      // The model and the coder run on from segment to segment, so the block's segments are decoded together
       std::vector<std::vector<U8> > payloads;
-      size_t off = 0;
-      auto need = [&](size_t o) -> int { const int c = peek(o); if (c < 0) error("unexpected end of file"); return c; };
-      for (;;) {
-        std::vector<U8> pl;
-        U32 curr = 0;
-        int c = 0;
-        while (curr == 0) { c = need(off++); pl.push_back((U8)c); curr = (U32)c; }
-        while (curr) { c = need(off++); pl.push_back((U8)c); curr = curr << 8 | (U32)c; }
-        while ((c = peek(off)) == 0) { pl.push_back(0); ++off; }     // a flush byte of 00 puts a fifth zero in front
-        payloads.push_back(pl);
-        c = need(off++);                                             // trailer
-        if (c == 253) off += 20;
-        else if (c != 254) error("missing end of segment marker");
-        c = need(off++);
-        if (c != 1) break;                                           // 255: end of block
-        while (need(off++) != 0) {}                                  // filename
-        while (need(off++) != 0) {}                                  // comment
-        if (need(off++) != 0) error("missing reserved byte");
-      }
+      peek_block_payloads(payloads);
       guarded([&] { block_cache_ = zpq::decode_payload_segments(header_, payloads, 0); });
     }
     if ((size_t)my_index >= block_cache_.size()) error("segment not found in its block");
@@ -432,7 +461,24 @@ bool Decompresser::decompress(int n) {
   // a segment of this block was left before its end (readSegmentEnd in the DATA state: Decoder::skip, decode_state = SKIP,
   // libzpaq.cpp:2346-2352): the reference refuses every later segment of the block, with or without a model (2300)
   if (skipped_in_block_) error("decompression after skipped segment");
-  if (!seg_decoded_) decode_segment();
+  if (!seg_decoded_) {
+    if (!prefix_tried_ && n >= 0 && (size_t)n < kPrefixBytes) try_prefix();
+    if (prefix_active_) {
+      if ((size_t)(n < 0 ? 0x7FFFFFFF : n) <= prefix_.size() - dpos_) {      // the prefix holds what is asked for
+        if (n) {
+          if (out_) out_->write((const char*)prefix_.data() + dpos_, n);
+          if (sha1_) sha1_->write((const char*)prefix_.data() + dpos_, (int64_t)n);
+          dpos_ += (size_t)n;
+        }
+        return true;
+      }
+      const size_t handed_out = dpos_;          // more than that: the whole segment, going on behind what was handed out
+      prefix_active_ = false;
+      prefix_.clear();
+      decode_segment();
+      dpos_ = handed_out;
+    } else decode_segment();
+  }
   size_t avail = decoded_.size() - dpos_;
   size_t take = (n < 0 || (size_t)n > avail) ? avail : (size_t)n;
   if (take) {
@@ -499,16 +545,27 @@ void Compressor::writeTag() {
   for (int i = 0; i < 13; ++i) out_->put(zpq::kBlockTag[i]);
 }
 
+}  // namespace libzpaq
+namespace zpq {
+// the stored header of built-in model `level` (1 .. 3); empty for any other level  (C ABI: zpq_builtin_model_header)
+std::vector<U8> builtin_model(int level) {
+  std::vector<U8> bytes;
+  if (level < 1 || level > 3) return bytes;
+  const char* hex = libzpaq::kBuiltinModels[level - 1];
+  for (size_t i = 0; hex[i] && hex[i + 1]; i += 2) {
+    auto nib = [](char ch) { return ch <= '9' ? ch - '0' : ch - 'a' + 10; };
+    bytes.push_back((U8)(nib(hex[i]) * 16 + nib(hex[i + 1])));
+  }
+  return bytes;
+}
+}  // namespace zpq
+namespace libzpaq {
+
 void Compressor::startBlock(int level) {
   if (level < 1) error("compression level must be at least 1");
   if (level > 3) error("compression level too high");
-  const char* hex = kBuiltinModels[level - 1];
-  std::vector<char> bytes;
-  for (size_t i = 0; hex[i] && hex[i + 1]; i += 2) {
-    auto nib = [](char ch) { return ch <= '9' ? ch - '0' : ch - 'a' + 10; };
-    bytes.push_back((char)(nib(hex[i]) * 16 + nib(hex[i + 1])));
-  }
-  startBlock(bytes.data());
+  const std::vector<zpq::U8> bytes = zpq::builtin_model(level);
+  startBlock((const char*)bytes.data());
 }
 
 void Compressor::startBlock(const char* hcomp) {
