@@ -505,31 +505,36 @@ int zpq_preprocess_blocks_device(const char* xmethod, uint8_t* const* data, cons
   int args[9];
   (void)make_config(xmethod, args);
   if (!preprocess_needs_suffix_array(args)) fail(ZPQ_E_ARG, "the method's pre-processor does not sort");
+  // E8E9 rewrites the caller's buffers in place (as the reference rewrites its input).  They keep the filter only when the call
+  // succeeds: on EVERY failure exit -- the device declines, something throws between the first filtered buffer and the last
+  // copied output, an output buffer is too small -- the buffers filtered so far go back as they came, so that a caller
+  // that falls back to zpq_preprocess_block (or calls again with larger buffers) never filters a block twice.
+  struct Unfilter {
+    uint8_t* const* data; const uint32_t* len; uint32_t done = 0; bool keep = false;
+    ~Unfilter() { if (!keep) for (uint32_t i = 0; i < done; ++i) e8e9_inverse(data[i], len[i]); }
+  } guard{data, len};
   std::vector<SortJob> jobs;
   for (uint32_t i = 0; i < n; ++i) {
-    if (args[1] > 4) e8e9_forward(data[i], len[i]);
+    if (args[1] > 4) { e8e9_forward(data[i], len[i]); guard.done = i + 1; }
     jobs.push_back(sort_job(data[i], len[i], args));
   }
   std::vector<SortOut> outs;
   std::string note;
-  bool done = false;
-  std::exception_ptr err;
-  try { done = engine_sort_preprocess(jobs, outs, note); } catch (...) { err = std::current_exception(); }
-  if (!done) {
-    // the caller's buffers go back as they came: a caller that falls back to zpq_preprocess_block would filter them twice
-    if (args[1] > 4) for (uint32_t i = 0; i < n; ++i) e8e9_inverse(data[i], len[i]);
-    if (err) std::rethrow_exception(err);
-    fail(ZPQ_E_UNSUPPORTED, "pre-processing on the device unavailable: " + note);
-  }
+  if (!engine_sort_preprocess(jobs, outs, note)) fail(ZPQ_E_UNSUPPORTED, "pre-processing on the device unavailable: " + note);
+  std::vector<std::vector<U8>> pres(n);
+  bool fits = true;
   for (uint32_t i = 0; i < n; ++i) {
-    std::vector<U8> pre;
+    std::vector<U8>& pre = pres[i];
     if (len[i] == 0) (void)preprocess_block(data[i], 0, args, pre, nullptr, true);
     else if (jobs[i].kind == 3) pre.swap(outs[i].bwt);
     else lz77_serialize(data[i], len[i], args, outs[i].toks.data(), outs[i].toks.size(), pre);
-    outlen[i] = pre.size();
-    if (pre.size() > cap[i]) fail(ZPQ_E_OVERFLOW, "output buffer too small");
-    if (!pre.empty()) memcpy(out[i], pre.data(), pre.size());
+    outlen[i] = pre.size();                               // (every size is reported, also when some buffer is too small)
+    fits = fits && pre.size() <= cap[i];
   }
+  if (!fits) fail(ZPQ_E_OVERFLOW, "output buffer too small");
+  for (uint32_t i = 0; i < n; ++i)
+    if (!pres[i].empty()) memcpy(out[i], pres[i].data(), pres[i].size());
+  guard.keep = true;
   return ZPQ_OK;
   ZPQ_CATCH
 }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <condition_variable>
@@ -86,7 +87,10 @@ struct Event {
   operator hipEvent_t() const { return ev; }
 };
 
-static int g_cus_hint = 256;              // compute units of the device the batches run on (set when an engine is created)
+// compute units of the device the batches run on (set when an engine is created; read without the engine's lock by the mode
+// choice and the submission queue: atomic.  Engines on devices of different sizes -- partition modes -- share the figure of
+// the one created last; a residency estimate that is off is caught by the arrival handshake of the persistent launch)
+static std::atomic<int> g_cus_hint{256};
 
 struct Engine {
   std::mutex mu;
@@ -395,7 +399,7 @@ static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32
       std::string why;
       if (pipe_layout(*plan, pipe_options(1), L1, why) && L1.persist_ok) {
         const uint64_t groups = (blocks_of_plan + (uint32_t)L1.G - 1) / (uint32_t)L1.G;
-        latency = groups * (uint64_t)L1.ps_wpg <= (uint64_t)g_cus_hint;
+        latency = groups * (uint64_t)L1.ps_wpg <= (uint64_t)g_cus_hint.load();
       }
     }
   }
@@ -1068,7 +1072,7 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
       for (;;) {
         uint64_t total = 0;
         for (const Need& n : need) total += mode[n.p] == 0 ? n.thr : n.lat;
-        if (total <= (uint64_t)g_cus_hint / 8) break;             // (launch_pipe_persist's rule: every XCD's share of every run fits)
+        if (total <= (uint64_t)g_cus_hint.load() / 8) break;             // (launch_pipe_persist's rule: every XCD's share of every run fits)
         const Need* best = nullptr;
         for (const Need& n : need)
           if (mode[n.p] != 0 && n.lat > n.thr && (!best || n.lat - n.thr > best->lat - best->thr)) best = &n;
@@ -1219,7 +1223,7 @@ void engine_code_host(bool decode, const std::vector<HostBlock>& blocks, std::ve
       {
         uint64_t queued = 0;
         for (const Ticket* t : b.queue[d]) queued += t->blocks->size();
-        if (b.approaching == 0 && queued >= (uint64_t)4 * (uint64_t)g_cus_hint) break;
+        if (b.approaching == 0 && queued >= (uint64_t)4 * (uint64_t)g_cus_hint.load()) break;
       }
       b.cv.wait_for(lk, std::chrono::microseconds(500));
     }
