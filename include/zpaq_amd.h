@@ -213,7 +213,7 @@ int zpq_last_timing(float* init_ms, float* code_ms, uint32_t* blocks);
 int zpq_last_persistent(void);
 /* When a persistent launch of the last timed call was given up (its workgroups did not become resident together -- something
  * else held compute units -- or a unit's watchdog fired) and the step kernels coded the batch instead: milliseconds from the
- * launch until the engine knew; 0 when none was given up.  The arrival handshake bounds it to ~50 ms
+ * launch until the engine knew; 0 when none was given up.  The arrival handshake bounds it to ~2 x 20 ms
  * (ZPAQ_AMD_PERSIST_ARRIVE_MS) and leaves the model state untouched. */
 double zpq_last_persist_abort_ms(void);
 /* SHA-1 (libzpaq::SHA1, libzpaq.cpp:106-177) of n buffers ON THE DEVICE, one lane per buffer, 20 bytes each into

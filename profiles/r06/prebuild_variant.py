@@ -19,7 +19,10 @@ if method.startswith("L"):
     h = z.builtin_model_header(int(method[1:]))
 else:
     h = z.method_to_header(z.expand_method(method, corpus.block(kind, bs, corpus.BASE_SEED)))[0]
-src, key = prebuild.pipe_source_and_key(h, mode)
+if mode == 3:       # the lockstep decoder of the chain (ZPAQ_AMD_TEAM_TAIL=0: without the tail wavefront)
+    src, key = prebuild.team_source_and_key(h)
+else:
+    src, key = prebuild.pipe_source_and_key(h, mode)
 assert src is not None, key
 L = z.lib()
 L.zpq_spec_cache_dir.restype = C.c_char_p

@@ -720,7 +720,7 @@ def test_foreign_kernel_on_the_device_makes_the_persistent_launch_step_aside(gpu
     """The persistent launch needs all its workgroups resident together; what the library cannot know about -- a second
     process's kernel, here tests/cpp/gpu_hog.hip holding 200 of the 256 compute units with 140 KiB of LDS each -- leaves
     some of them in the queue.  The arrival handshake (pipe_persist.h pipe_arrived) notices within ZPAQ_AMD_PERSIST_ARRIVE_MS
-    (50 ms) that the count has stopped short, nothing has been touched, and the step kernels code the batch beside the foreign
+    (20 ms) that the count has stopped short, nothing has been touched, and the step kernels code the batch beside the foreign
     kernel: same archives, given up in well under 100 ms instead of after the 3 s watchdog."""
     import ctypes as C
     import subprocess

@@ -610,9 +610,11 @@ static uint32_t persist_timeout_ticks() {
 }
 
 // ... and how long the workgroups of a launch may wait for each other to become resident (pipe_persist.h pipe_arrived) before the
-// launch is given up untouched: 50 ms without a new arrival (a full grid arrives within microseconds of its first workgroup)
+// launch is given up untouched: 20 ms without a new arrival (a full grid arrives within microseconds of its first workgroup;
+// measured with 200 of 256 compute units held by another process, profiles/r06: the engine knows ~2 x this after the launch --
+// the workgroups that were left in the queue still have to be dispatched, see the flag and leave)
 static uint32_t persist_arrive_ticks() {
-  uint32_t ms = 50;
+  uint32_t ms = 20;
   if (const char* t = getenv("ZPAQ_AMD_PERSIST_ARRIVE_MS")) ms = (uint32_t)std::max(1, atoi(t));
   return (uint32_t)std::min<uint64_t>((uint64_t)ms * 100000ull, 0xFFFFFFF0ull);
 }

@@ -175,7 +175,9 @@ constexpr int kTeamRun = kTeamX + 132;                       // block still deco
 template <class Chain>
 constexpr int team_row_lanes() { return team_map<Chain>().nrows <= 16 ? 16 : 32; }
 template <class Chain>
-constexpr int team_threads() { return 64 * (kTeamBlocks / (64 / team_row_lanes<Chain>()) + kTeamBlocks / 2); }
+constexpr bool team_tail_ok();            // (below: chains whose scalar work moves to ONE tail wavefront)
+template <class Chain>
+constexpr int team_threads() { return 64 * (kTeamBlocks / (64 / team_row_lanes<Chain>()) + kTeamBlocks / 2 + (team_tail_ok<Chain>() ? 1 : 0)); }
 
 // =====================================================================================================================
 // ROW wavefront
@@ -415,6 +417,7 @@ __device__ __forceinline__ void team_rows(const TT& T, lds_u8* const lds0, const
         scb0 = G32(soff + 4u * eb); scb1 = G32(soff + 4u * eb + 4u);
       }
       TEAM_PROF(2);
+      if constexpr (team_tail_ok<Chain>()) ZPQ_TEAM_BARRIER();   // [A2] the mix wavefronts hand the MIX outputs to the tail (nothing to do here)
       ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
       TEAM_PROF(3);
       TEAM_PROF_BIT();
@@ -1072,6 +1075,626 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
 }
 
 // =====================================================================================================================
+// Round 6: the TAIL wavefront.  A mixer wavefront above serves two blocks and runs the WHOLE stream of everything that is
+// not an ICM / ISSE -- CM, MATCH, the MIX dot products, MIX2, SSE, squash, the arithmetic coder, HCOMP -- so the compute unit
+// issues that stream four times per bit for its 8 blocks, and the profile of round 4 says the bit is bound by issue slots
+// (per SIMD a row and a mixer wavefront: ~150 + ~440 instructions, ~2 400 of a bit's ~2 650 cycles).  What needs 32 lanes per
+// block is only the MIX dot product (lane t = weight t).  Everything else is a handful of scalars per block.  So, for chains
+// with at least one MIX and at most 8 CM / MATCH components (TeamTailMap):
+//
+//   MIX wavefronts (4)  two blocks each, lane = weight index: the candidate rows of the next bit, the dot products (inputs from
+//                       the exchange words X in LDS, outputs back into X), the weights' training.  ~110 instructions per bit.
+//   TAIL wavefront (1)  lane = (block, role), 8 lanes per block: role r owns the r-th CM / MATCH of the chain (its table word,
+//                       candidates, training); AVG / MIX2 / SSE, squash, the coder and HCOMP are computed by all 8 lanes of a
+//                       block alike (values every lane has: nothing to broadcast; an SSE row's 32 entries sit 4 per lane and
+//                       the two the prediction needs come through ds_bpermute).  ONE stream for the 8 blocks.
+//
+//     rows predict, tail: CM / MATCH predict -> [A] -> mix: dot products -> [A2] -> tail: MIX2, SSE, squash, decode -> [B] -> update
+//
+// One more barrier per bit, ~970 instead of ~1 840 wave-instructions per bit and compute unit.  The model arithmetic is the
+// mixers' above, statement for statement.
+#ifndef ZPQ_TEAM_TAIL
+#define ZPQ_TEAM_TAIL 1
+#endif
+
+template <class Chain>
+struct TeamTailMap {
+  int nrole;              // CM / MATCH components
+  int role_comp[8];       // chain index of role r's component (-1: none)
+  bool ok;
+};
+template <class Chain>
+constexpr TeamTailMap<Chain> team_tail_map() {
+  TeamTailMap<Chain> m{};
+  m.nrole = 0;
+  m.ok = ZPQ_TEAM_TAIL != 0 && Chain::NMIX > 0;
+  for (int i = 0; i < 8; ++i) m.role_comp[i] = -1;
+  for (int i = 0; i < Chain::N; ++i) {
+    const unsigned t = Chain::comp[i].type;
+    if (t == C_CM || t == C_MATCH) {
+      if (m.nrole < 8) m.role_comp[m.nrole] = i;
+      ++m.nrole;
+    }
+  }
+  if (m.nrole > 8) m.ok = false;
+  // the mix wavefronts run BEFORE the tail's dependent components: a MIX may take row components, CM, MATCH, CONS and earlier
+  // MIXes as inputs (every chain compressBlock's methods and the legacy models make), not an AVG / MIX2 / SSE
+  for (int i = 0; i < Chain::N; ++i) {
+    if (Chain::comp[i].type != C_MIX) continue;
+    for (unsigned t = 0; t < Chain::comp[i].a3; ++t) {
+      const unsigned ty = Chain::comp[Chain::comp[i].a2 + t].type;
+      if (ty == C_AVG || ty == C_MIX2 || ty == C_SSE) m.ok = false;
+    }
+  }
+  return m;
+}
+template <class Chain>
+constexpr bool team_tail_ok() { return team_tail_map<Chain>().ok; }
+
+// ---- MIX wavefront: two blocks, lane = (block, weight index) ----------------------------------------------------------
+template <class Chain, class TT>
+__device__ __forceinline__ void team_mix(const TT& T, lds_u8* const lds0, const BlockJob* jobs, unsigned nblocks, int tw, int lane) {
+  constexpr int N = Chain::N;
+  constexpr int NMIX = Chain::NMIX > 0 ? Chain::NMIX : 1;
+  constexpr int kRegion = team_block_lds_bytes();
+  const int ci = lane & 31;
+  const bool upper = lane >= 32;
+  const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
+  const unsigned bw = (unsigned)tw * 2u + (upper ? 1u : 0u);
+  const unsigned b = wg0 + bw;
+  const bool live = b < nblocks;
+  const BlockJob job0 = jobs[wg0];
+  const BlockJob job = jobs[live ? b : wg0];
+  g_u8* const arena = (g_u8*)sp_uni64((unsigned long long)job0.arena);
+  const unsigned long long delta64 = (unsigned long long)job.arena - (unsigned long long)job0.arena;
+  const unsigned hoff = live ? (unsigned)delta64 : 0u;
+  lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
+  const unsigned dummy = (unsigned)Chain::OFF_RUN;
+  auto G32 = [&](unsigned off) __attribute__((always_inline)) -> g_u32& { return *(g_u32*)(arena + off); };
+  auto L32 = [&](unsigned off) __attribute__((always_inline)) -> lds_u32& { return *(lds_u32*)(wl + off); };
+  lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
+  auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
+    unsigned m = x ? 0xFFFFFFFFu : 0u;
+    ZPQ_OPAQUE(m);
+    return m;
+  };
+  int mixw[NMIX], mixp[NMIX], mixc0[NMIX], mixc1[NMIX], rsq[NMIX];
+  unsigned mixrow[NMIX], mixbase[NMIX], mixst[NMIX], mixin[NMIX], mixx[NMIX], hmix[NMIX];
+#pragma unroll
+  for (int k = 0; k < NMIX; ++k) { mixw[k] = 0; mixp[k] = 0; mixc0[k] = 0; mixc1[k] = 0; rsq[k] = 0; mixrow[k] = 0; mixbase[k] = dummy; mixst[k] = dummy; mixin[k] = 0; mixx[k] = (unsigned)kTeamX; hmix[k] = 0; }
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr CompK c = Chain::comp[i];
+    if constexpr (c.type == C_MIX) {
+      static_assert(c.a2 + c.a3 <= 32, "MIX inputs must sit inside one half");
+      mixbase[c.slot] = (unsigned)c.t0 + hoff + 4u * (unsigned)min(ci, (int)c.a3 - 1);
+      ZPQ_OPAQUE(mixbase[c.slot]);
+      mixin[c.slot] = lane_mask(ci < (int)c.a3 && live);
+      mixst[c.slot] = (ci < (int)c.a3 && live) ? (unsigned)c.t0 + hoff + 4u * (unsigned)ci : dummy;
+      ZPQ_OPAQUE(mixst[c.slot]);
+      mixx[c.slot] = (unsigned)kTeamX + 4u * (unsigned)(((int)c.a2 + min(ci, (int)c.a3 - 1)) & 31);     // the input this lane multiplies
+    }
+  });
+  int c8 = 1, ylast = 0;
+  auto any_running = [&]() __attribute__((always_inline)) -> bool {
+    unsigned r = 0;
+    for (int i = 0; i < kTeamBlocks; ++i) r |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
+    return r != 0;
+  };
+  ZPQ_TEAM_BARRIER();                                        // [S]
+  bool any = any_running();
+  while (any) {
+    static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
+      constexpr int B = decltype(bitc)::value;
+      const int c8a = c8 * 2, c8b = c8 * 2 + 1;
+      // ---- before [A]: this bit's rows (fetched a bit ago as candidates), the next bit's candidates
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+        if constexpr (c.type == C_MIX) {
+          const unsigned hi = hmix[c.slot];
+          mixrow[c.slot] = ((hi + (unsigned)(c8 & (int)c.a5)) & c.mask0) * c.stride;
+          if constexpr (mix_pf(c)) {
+            if constexpr (B > 0) mixw[c.slot] = ylast ? mixc1[c.slot] : mixc0[c.slot];
+            else mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
+            mixc0[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8a & 255)) & c.mask0) * c.stride));
+            mixc1[c.slot] = (int)G32(mixbase[c.slot] + 4u * (((hi + (unsigned)(c8b & 255)) & c.mask0) * c.stride));
+          } else {
+            mixw[c.slot] = (int)G32(mixbase[c.slot] + 4u * mixrow[c.slot]);
+          }
+        }
+      });
+      ZPQ_TEAM_BARRIER();                                    // [A] the rows' and the tail's predictions are in X
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+        if constexpr (c.type == C_MIX) {
+          const int pin = (int)L32(mixx[c.slot]);             // (an earlier MIX of this wavefront wrote its output just above: LDS operations of a wavefront are in order)
+          mixp[c.slot] = pin;
+          const int x = (int)((unsigned)__mul24(mixw[c.slot] >> 8, pin) & mixin[c.slot]);
+          const int rp = sp_clamp2k(dual_half_sum<(int)c.a3>(x, upper) >> 8);
+          rsq[c.slot] = sp_squash(T, rp);
+          if (ci == 0) L32((unsigned)kTeamX + 4u * (unsigned)i) = (unsigned)rp;     // the MIX's prediction: for a later MIX of this wavefront and for the tail
+        }
+      });
+      ZPQ_TEAM_BARRIER();                                    // [A2] the tail takes over
+      ZPQ_TEAM_BARRIER();                                    // [B] the bit is known
+      const int y = (int)L32((unsigned)kTeamY);
+      const int yq = y * 32767;
+      static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr CompK c = Chain::comp[i];
+        if constexpr (c.type == C_MIX) {
+          const int err = ((yq - rsq[c.slot]) * (int)c.a4) >> 4;
+          const int w = sp_clamp512k(mixw[c.slot] + (sp_mad24(err, mixp[c.slot], 1 << 12) >> 13));
+          const unsigned wo = mixst[c.slot] + ((4u * mixrow[c.slot]) & mixin[c.slot]);
+          *(g_i32*)(arena + wo) = w;
+        }
+      });
+      ylast = y;
+      c8 += c8 + y;
+      if constexpr (B == 7) {
+        ZPQ_TEAM_BARRIER();                                  // [C] HCOMP has run
+        any = any_running();
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          constexpr CompK c = Chain::comp[i];
+          if constexpr (c.type == C_MIX) hmix[c.slot] = vm_H[(unsigned)i & Chain::HMASK];
+        });
+        c8 = 1;
+      }
+    });
+  }
+}
+
+// ---- TAIL wavefront: lane = (block, role), 8 lanes per block ------------------------------------------------------------
+template <class Chain, class TT>
+__device__ __forceinline__ void team_tail(const TT& T, lds_u8* const lds0, const BlockJob* jobs, BlockResult* res, unsigned nblocks, int lane) {
+  constexpr int N = Chain::N;
+  constexpr auto TM = team_tail_map<Chain>();
+  constexpr int NSSE = Chain::NSSE > 0 ? Chain::NSSE : 1;
+  constexpr int NMIX2 = team_mix2_slot<Chain>(N) > 0 ? team_mix2_slot<Chain>(N) : 1;
+  constexpr int kRegion = team_block_lds_bytes();
+  const int r = lane & 7;                                     // role
+  const unsigned bw = (unsigned)lane >> 3;                    // block of this lane inside the workgroup
+  const unsigned wg0 = blockIdx.x * (unsigned)kTeamBlocks;
+  const unsigned b = wg0 + bw;
+  const bool live = b < nblocks;
+  const BlockJob job0 = jobs[wg0];
+  const BlockJob job = jobs[live ? b : wg0];
+  g_u8* const arena = (g_u8*)sp_uni64((unsigned long long)job0.arena);
+  const unsigned long long delta64 = (unsigned long long)job.arena - (unsigned long long)job0.arena;
+  const unsigned hoff = live ? (unsigned)delta64 : 0u;
+  const g_u8* const in_ptr = (const g_u8*)job.in;
+  g_u8* const out_ptr = (g_u8*)job.out;
+  const unsigned in_len = job.in_len, out_cap = job.out_cap, rslot = job.res_slot;
+  lds_u8* const wl = lds0 + bw * (unsigned)kRegion;
+  const unsigned dummy = (unsigned)Chain::OFF_RUN;
+  const unsigned dummy_lds = (unsigned)(kRegion - 512) + (unsigned)r * 8u;
+
+  // this lane's own component: the r-th CM / MATCH of the chain
+  unsigned limit = 0, mask0 = 0, mask1 = 63, off0 = dummy, off1 = dummy, ctype = 0;
+  int cidx = 0;
+  static_for<0, 8>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int rr = decltype(rc)::value;
+    if constexpr (TM.role_comp[rr] >= 0) {
+      if (r == rr && live) {
+        constexpr CompK c = Chain::comp[TM.role_comp[rr]];
+        ctype = c.type; limit = c.limit; mask0 = c.mask0;
+        off0 = (unsigned)c.t0 + hoff;
+        if (c.type == C_MATCH) { off1 = (unsigned)c.t1 + hoff; mask1 = c.mask1; }
+        cidx = TM.role_comp[rr];
+      }
+    }
+  });
+  auto G32 = [&](unsigned off) __attribute__((always_inline)) -> g_u32& { return *(g_u32*)(arena + off); };
+  auto G8 = [&](unsigned off) __attribute__((always_inline)) -> g_u8& { return *(g_u8*)(arena + off); };
+  auto G128 = [&](unsigned off) __attribute__((always_inline)) -> g_u128& { return *(g_u128*)(arena + off); };
+  auto L32 = [&](unsigned off) __attribute__((always_inline)) -> lds_u32& { return *(lds_u32*)(wl + off); };
+
+  // HCOMP machine of this block (every lane of the block runs it: identical values, identical stores)
+  unsigned vm_b = 0, vm_c = 0, vm_d = 0, vm_f = 0;
+  g_u8* const vm_M = arena + (unsigned)Chain::OFF_M + hoff;
+  g_u32* const vm_R = (g_u32*)(arena + (unsigned)Chain::OFF_R + hoff);
+  lds_u32* const vm_H = (lds_u32*)(wl + Chain::H_LDS);
+
+  const bool is_cm = ctype == C_CM, is_match = ctype == C_MATCH;
+  const bool is_ctx = is_cm || is_match;
+  const bool pf_lane = is_cm && mask0 >= 511u;
+  const unsigned goff = is_cm ? off0 : dummy;
+  const unsigned gmask = is_cm ? mask0 : 0u;
+  auto lane_mask = [&](bool x) __attribute__((always_inline)) -> unsigned {
+    unsigned m = x ? 0xFFFFFFFFu : 0u;
+    ZPQ_OPAQUE(m);
+    return m;
+  };
+  const unsigned m_match = lane_mask(is_match), m_pf = lane_mask(pf_lane);
+  const unsigned m_lane0 = lane_mask(r == 0 && live);
+  const unsigned xoff = is_ctx ? (unsigned)kTeamX + 4u * (unsigned)cidx : dummy_lds;      // where this lane publishes its prediction
+
+  unsigned gidx = 0, h = 0, v0 = 0, dtv = 0;
+  unsigned ra = 0, rb = 0, rc = 0, rlimit = 0, mpred = 0, mdd = 0;
+  unsigned mcmv = 0, mcont = 0, mcand_at = 0;
+  unsigned long long mcand = 0, mhist = 0;
+  unsigned gwc0 = 0, gwc1 = 0;
+  uint4 ssev[NSSE], ssec0[NSSE], ssec1[NSSE];
+  unsigned ssecx[NSSE], ssetr[NSSE], ssedt[NSSE], ssebase[NSSE], ssest[NSSE], hsse[NSSE];
+  int m2w[NMIX2], m2c0[NMIX2], m2c1[NMIX2], m2d[NMIX2];
+  unsigned m2idx[NMIX2], m2base[NMIX2], m2st[NMIX2], hm2[NMIX2];
+#pragma unroll
+  for (int k = 0; k < NSSE; ++k) {
+    ssev[k] = make_uint4(0, 0, 0, 0); ssec0[k] = ssev[k]; ssec1[k] = ssev[k];
+    ssecx[k] = 0; ssetr[k] = 0; ssedt[k] = 0; ssebase[k] = dummy; ssest[k] = dummy; hsse[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < NMIX2; ++k) { m2w[k] = 0; m2c0[k] = 0; m2c1[k] = 0; m2d[k] = 0; m2idx[k] = 0; m2base[k] = dummy; m2st[k] = dummy; hm2[k] = 0; }
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr CompK c = Chain::comp[i];
+    if constexpr (c.type == C_SSE) {
+      ssebase[c.slot] = (unsigned)c.t0 + hoff + 16u * (unsigned)r;       // this lane's 4 of the row's 32 entries (a lane without a block reads the first block's table, never writes)
+      ZPQ_OPAQUE(ssebase[c.slot]);
+      ssest[c.slot] = (r == 0 && live) ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(ssest[c.slot]);
+    } else if constexpr (c.type == C_MIX2) {
+      constexpr int k2 = team_mix2_slot<Chain>(i);
+      m2base[k2] = live ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(m2base[k2]);
+      m2st[k2] = (r == 0 && live) ? (unsigned)c.t0 + hoff : dummy;
+      ZPQ_OPAQUE(m2st[k2]);
+      if constexpr (c.mask0 == 0u) m2w[k2] = (int)G32(m2base[k2]);       // a table of one weight never leaves its register
+    }
+  });
+  // rows of an SSE table are 128 bytes: with ssebase a lane's 16, candidate rows are whole-line fetches of the 8 lanes
+  auto sse_row = [&](int k, unsigned cx) __attribute__((always_inline)) -> uint4 { return G128(ssebase[k] + 4u * cx); };
+  int rep[N], rsq[N];                                         // dependent components: prediction and its squash, in every lane
+#pragma unroll
+  for (int k = 0; k < N; ++k) { rep[k] = 0; rsq[k] = 0; }
+  static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (Chain::comp[i].type == C_CONS) {
+      rep[i] = ((int)Chain::comp[i].a1 - 128) * 4;
+      if (r == 0) L32((unsigned)kTeamX + 4u * (unsigned)i) = (unsigned)rep[i];       // a constant: published once
+    }
+  });
+  int ylast = 0;
+  int c8 = 1, hmap4 = 1;
+  unsigned low = 1, high = 0xFFFFFFFFu;
+  unsigned steps = 0;
+  int status = 0;
+  int p = 0;
+
+  // ---- before [A]: this bit's table words (fetched a bit ago as candidates), the next bit's candidates, CM / MATCH predict
+  auto pre = [&](auto bitc) __attribute__((always_inline)) {
+    constexpr int B = decltype(bitc)::value;
+    constexpr bool pf_now = B > 0;
+    constexpr bool last_of_nibble = B == 3;
+    const int c8a = c8 * 2, c8b = c8 * 2 + 1;
+    const int hm4a = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1) : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2) & 0xf));
+    const int hm4b = last_of_nibble ? ((hmap4 & 0xf) << 5 | 1 << 4 | 1)
+                                    : ((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + 1) & 0xf));
+    unsigned gw;
+    gidx = (h ^ (unsigned)hmap4) & gmask;
+    if constexpr (pf_now) {
+      gw = ylast ? gwc1 : gwc0;
+      if constexpr (Chain::ANY_NONPF_GL) {
+        if (is_cm && !pf_lane) gw = G32(goff + 4u * gidx);
+      }
+    } else {
+      gw = G32(goff + 4u * gidx);
+    }
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_SSE) {
+        const unsigned hi = hsse[c.slot];
+        ssecx[c.slot] = ((hi + (unsigned)c8) * 32u) & c.mask0;
+        if constexpr (sse_pf(c)) {
+          if constexpr (pf_now) {
+            ssev[c.slot].x = ylast ? ssec1[c.slot].x : ssec0[c.slot].x; ssev[c.slot].y = ylast ? ssec1[c.slot].y : ssec0[c.slot].y;
+            ssev[c.slot].z = ylast ? ssec1[c.slot].z : ssec0[c.slot].z; ssev[c.slot].w = ylast ? ssec1[c.slot].w : ssec0[c.slot].w;
+          } else ssev[c.slot] = sse_row(c.slot, ssecx[c.slot]);
+          ssec0[c.slot] = sse_row(c.slot, ((hi + (unsigned)c8a) * 32u) & c.mask0);
+          ssec1[c.slot] = sse_row(c.slot, ((hi + (unsigned)c8b) * 32u) & c.mask0);
+        } else {
+          ssev[c.slot] = sse_row(c.slot, ssecx[c.slot]);
+        }
+      } else if constexpr (c.type == C_MIX2 && c.mask0 != 0u) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const unsigned hi = hm2[k2];
+        m2idx[k2] = (hi + (unsigned)(c8 & (int)c.a5)) & c.mask0;
+        if constexpr (mix2_pf(c)) {
+          if constexpr (pf_now) m2w[k2] = ylast ? m2c1[k2] : m2c0[k2];
+          else m2w[k2] = (int)G32(m2base[k2] + 4u * m2idx[k2]);
+          m2c0[k2] = (int)G32(m2base[k2] + 4u * ((hi + (unsigned)(c8a & 255)) & c.mask0));
+          m2c1[k2] = (int)G32(m2base[k2] + 4u * ((hi + (unsigned)(c8b & 255)) & c.mask0));
+        } else {
+          m2w[k2] = (int)G32(m2base[k2] + 4u * m2idx[k2]);
+        }
+      }
+    });
+    {
+      const unsigned ia = ((h ^ (unsigned)hm4a) & gmask) & m_pf, ib = ((h ^ (unsigned)hm4b) & gmask) & m_pf;
+      gwc0 = G32(goff + 4u * ia);
+      gwc1 = G32(goff + 4u * ib);
+    }
+    // MATCH
+    if constexpr (B == 0) {
+      mcmv = G32(is_match ? off0 + 4u * (h & mask0) : dummy);
+      mcont = G8(is_match ? off1 + ((rlimit + 1u - rb) & mask1) : dummy);
+    } else if constexpr (B == 4) {
+      const unsigned cpos = (mcmv - 8u) & mask1;
+      const bool wraps = cpos + 8u > mask1 + 1u || mask1 < 15u;
+      mcand = *(g_u64u*)(arena + (is_match && !wraps ? off1 + cpos : dummy));
+      mcand_at = G8(is_match ? off1 + (mcmv & mask1) : dummy);
+    }
+    const bool m_on = is_match && ra != 0;
+    rc = m_on ? ((mpred >> (7 - B)) & 1u) : rc;
+    const unsigned msx = m_on ? ((rc ? 0u - mdd : mdd) & 32767u) : 16384u;
+    v0 = gw;
+    const unsigned sx = sp_blend(m_match, msx, v0 >> 17);
+    p = sp_stretch(T, sx & 32767u);
+    dtv = (unsigned)T.dt[v0 & 0x3ffu];
+    L32(xoff) = (unsigned)p;                                  // CM / MATCH lanes: their prediction for the mix wavefronts (the others: a dummy word)
+  };
+
+  // prediction of component j, in every lane: a dependent component's is there already, everything else is in X
+  auto pred_of = [&](auto jc) __attribute__((always_inline)) -> int {
+    constexpr int j = decltype(jc)::value;
+    constexpr unsigned t = Chain::comp[j].type;
+    if constexpr (t == C_AVG || t == C_MIX2 || t == C_SSE || t == C_CONS) return rep[j];
+    else return (int)L32((unsigned)kTeamX + 4u * (unsigned)j);
+  };
+
+  // ---- after [A2]: the dependent components behind the MIX dot products, the final probability
+  auto chain = [&]() __attribute__((always_inline)) -> unsigned {
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_AVG) {
+        const int pj = pred_of(IC<(int)c.a1>{}), pk = pred_of(IC<(int)c.a2>{});
+        rep[i] = (pj * (int)c.a3 + pk * (256 - (int)c.a3)) >> 8;
+      } else if constexpr (c.type == C_MIX2) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const int pj = pred_of(IC<(int)c.a2>{}), pk = pred_of(IC<(int)c.a3>{});
+        m2d[k2] = pj - pk;
+        const int w = m2w[k2];
+        rep[i] = sp_mad24(w, pj, __mul24(65536 - w, pk)) >> 16;              // 17-bit x 12-bit products
+        rsq[i] = sp_squash(T, sp_clamp2k(rep[i]));
+      } else if constexpr (c.type == C_SSE) {
+        int pq = pred_of(IC<(int)c.a2>{}) + 992;
+        pq = min(max(pq, 0), 1983);
+        const int wt = pq & 63;
+        pq >>= 6;
+        // entries pq and pq + 1 of the row: 4 per lane, lane (pq >> 2) of this block holds entry pq as component pq & 3
+        const int q0 = pq & 3, q1 = (pq + 1) & 3;
+        const unsigned s0 = q0 == 0 ? ssev[c.slot].x : (q0 == 1 ? ssev[c.slot].y : (q0 == 2 ? ssev[c.slot].z : ssev[c.slot].w));
+        const unsigned s1 = q1 == 0 ? ssev[c.slot].x : (q1 == 1 ? ssev[c.slot].y : (q1 == 2 ? ssev[c.slot].z : ssev[c.slot].w));
+        const int base = (int)(bw * 8u);
+        const unsigned e0 = __shfl(s0, base + (pq >> 2)), e1 = __shfl(s1, base + ((pq + 1) >> 2));
+        rep[i] = sp_stretch(T, ((e0 >> 10) * (unsigned)(64 - wt) + (e1 >> 10) * (unsigned)wt) >> 13);
+        ssecx[c.slot] += (unsigned)(pq + (wt >> 5));
+        ssetr[c.slot] = (wt >> 5) ? e1 : e0;
+        ssedt[c.slot] = (unsigned)T.dt[ssetr[c.slot] & 0x3ffu];
+      }
+    });
+    constexpr unsigned tlast = Chain::comp[N - 1].type;
+    if constexpr (tlast == C_MIX2) return (unsigned)rsq[N - 1];
+    else return (unsigned)sp_squash(T, sp_clamp2k(pred_of(IC<N - 1>{})));
+  };
+
+  // ---- after [B]: update of the tail's components (Predictor::update0 cases CM, MATCH, MIX2, SSE)
+  auto update = [&](auto bitc, int y) __attribute__((always_inline)) {
+    constexpr int B = decltype(bitc)::value;
+    constexpr bool byte_done = B == 7;
+    const unsigned count = v0 & 0x3ffu;
+    const int yq = y * 32767;
+    const int errcm = yq - (int)(v0 >> 17);
+    const unsigned cm_new = v0 + ((unsigned)__mul24(errcm, (int)dtv) & 0xFFFFFC00u) + (count < limit ? 1u : 0u);
+    G32(goff + 4u * gidx) = cm_new;                           // (lanes that are no CM: their dummy)
+    ra = (is_match && (int)rc != y) ? 0u : ra;
+    if (byte_done && is_match) {
+      // Predictor::update0 case MATCH at the end of a byte (libzpaq.cpp:1992-2006), from registers
+      const unsigned mask = mask1;
+      const unsigned byte = (unsigned)(c8 * 2 + y) & 255u;
+      const unsigned wpos = rlimit & mask;                     // where this byte goes
+      G8(off1 + wpos) = (unsigned char)byte;
+      mhist = mhist << 8 | byte;
+      rlimit = (rlimit + 1) & mask;
+      const unsigned eo = off0 + 4u * (h & mask0);
+      bool fresh = false;
+      if (ra == 0) {
+        rb = rlimit - mcmv;
+        if (rb & mask) {
+          const unsigned cpos = (mcmv - 8u) & mask;
+          const bool wraps = cpos + 8u > mask + 1u || mask < 15u;
+          const bool overlap = ((mcmv - 1u - wpos) & mask) < 8u;
+          unsigned m = 0;
+          if (!wraps && !overlap) {
+            const unsigned long long diff = __builtin_bswap64(mcand) ^ mhist;
+            m = diff ? (unsigned)(__builtin_ctzll(diff) >> 3) : 8u;
+          }
+          ra = m;
+          if (wraps || overlap || m == 8u)
+            while (ra < 255 && G8(off1 + ((rlimit - ra - 1) & mask)) == G8(off1 + ((rlimit - ra - rb - 1) & mask))) ++ra;
+        }
+        fresh = true;
+      } else ra += ra < 255;
+      G32(eo) = rlimit;
+      if (ra != 0) {
+        const unsigned ppos = (rlimit - rb) & mask;
+        const unsigned early = fresh ? mcand_at : mcont;
+        mpred = ppos == wpos ? byte : early;
+        mdd = T.dt2k[ra];
+      }
+    }
+    static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr CompK c = Chain::comp[i];
+      if constexpr (c.type == C_MIX2) {
+        constexpr int k2 = team_mix2_slot<Chain>(i);
+        const int err2 = __mul24(yq - rsq[i], (int)c.a4) >> 5;
+        const int w2 = min(max(m2w[k2] + (sp_mad24(err2, m2d[k2], 1 << 12) >> 13), 0), 65535);   // 19-bit x 13-bit
+        if constexpr (c.mask0 == 0u) m2w[k2] = w2;
+        else *(g_i32*)(arena + m2st[k2] + ((4u * m2idx[k2]) & m_lane0)) = w2;
+      } else if constexpr (c.type == C_SSE) {
+        const unsigned e = ssecx[c.slot];
+        const unsigned v = ssetr[c.slot];
+        const unsigned cnt = v & 0x3ffu;
+        const int err = yq - (int)(v >> 17);
+        const unsigned prod = (unsigned)__mul24(err, (int)ssedt[c.slot]);
+        const unsigned nv = v + (prod & 0xFFFFFC00u) + (cnt < c.limit ? 1u : 0u);
+        *(g_u32*)(arena + ssest[c.slot] + ((4u * (e & c.mask0)) & m_lane0)) = nv;
+      }
+    });
+    ylast = y;
+  };
+
+  // ---- the coder of this block (Decoder::decode, libzpaq.cpp:2159-2181): every lane of the block alike
+  unsigned rp = 0, nout = 0, curr = 0;
+  bool run = live;
+  bool eos = false;
+  if (live && (delta64 >> 32) != 0) { status = 8; run = false; }   // arenas of the workgroup not inside a 4 GiB window
+  const unsigned in_lim = (in_len + 63u) & ~63u;
+  unsigned long long iwin = 0, if0 = 0, if1 = 0;
+  unsigned iavail = 0, ifpos = 0;
+  auto in_fetch = [&]() __attribute__((always_inline)) {
+    ifpos = in_lim >= 16u ? min(rp, in_lim - 16u) : 0u;
+    if0 = *(g_u64u*)(in_ptr + ifpos);
+    if1 = *(g_u64u*)(in_ptr + ifpos + 8u);
+  };
+  auto in_window = [&]() __attribute__((always_inline)) {
+    const unsigned o = rp - ifpos;
+    const unsigned long long b0 = __builtin_bswap64(if0), b1 = __builtin_bswap64(if1);
+    const unsigned sh = (o & 7u) * 8u;
+    const unsigned long long lo = sh ? (b0 << sh) | (b1 >> (64u - sh)) : b0;
+    const unsigned long long hi = b1 << sh;
+    iwin = o < 8u ? lo : hi;
+    iavail = in_lim < 16u ? 0u : (o < 8u ? 8u : (o < 16u ? 16u - o : 0u));
+  };
+  auto in_byte = [&]() __attribute__((always_inline)) -> unsigned {
+    unsigned v;
+    if (iavail) {
+      v = (unsigned)(iwin >> 56);
+      iwin <<= 8;
+      --iavail;
+    } else {
+      v = in_ptr[rp];
+      ZPQ_OPAQUE(v);
+    }
+    ++rp;
+    return v;
+  };
+  unsigned dmid = 0;
+  auto decode_bit = [&](unsigned pr) __attribute__((always_inline)) -> int {
+    const bool bad = run && (curr < low || curr > high);
+    status = bad ? 2 : status;
+    run = run && !bad;
+    dmid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
+    return (run && curr <= dmid) ? 1 : 0;
+  };
+  auto decode_shift = [&](int y) __attribute__((always_inline)) {
+    if (!run) return;
+    if (y) high = dmid; else low = dmid + 1;
+    while ((high ^ low) < 0x1000000u) {
+      high = high << 8 | 255u;
+      low = low << 8;
+      low += (low == 0);
+      if (rp >= in_len) { status = 6; run = false; break; }
+      curr = curr << 8 | in_byte();
+    }
+  };
+  auto decode = [&](unsigned pr) __attribute__((always_inline)) -> int {
+    const int y = decode_bit(pr);
+    decode_shift(y);
+    return y;
+  };
+  auto run_hcomp = [&](unsigned input) __attribute__((always_inline)) -> int {
+#ifndef ZPQ_EMU
+    int e = 0;
+    if (run) e = Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    return e;
+#else
+    int e = 0;
+    if (run && r == 0) e = Chain::hcomp(input, vm_b, vm_c, vm_d, vm_f, vm_M, vm_H, vm_R);
+    return __shfl(e, (int)(bw * 8u));
+#endif
+  };
+  auto any_running = [&]() __attribute__((always_inline)) -> bool {
+    unsigned rr = 0;
+    for (int i = 0; i < kTeamBlocks; ++i) rr |= *(lds_u32*)(lds0 + (unsigned)(i * kRegion + kTeamRun));
+    return rr != 0;
+  };
+
+  if (run && in_len) { in_fetch(); in_window(); }
+  for (int i = 0; i < 4; ++i) {
+    if (!run) break;
+    if (rp >= in_len) { status = 6; run = false; break; }
+    curr = curr << 8 | in_byte();
+  }
+  if (run && nout >= out_cap) run = false;
+  if (r == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
+  ZPQ_TEAM_BARRIER();                                        // [S]
+  bool any = any_running();
+  if (run) in_fetch();
+  while (any) {
+    int ch = 1;
+    if (run) { in_window(); in_fetch(); }
+    const int flag = decode(0);                               // end-of-stream flag, coded with p = 0
+    if (run && flag) { eos = true; if (curr != 0) status = 2; run = false; }
+    static_for<0, 8>([&](auto bitc) __attribute__((always_inline)) {
+      constexpr int B = decltype(bitc)::value;
+      pre(bitc);
+      ZPQ_TEAM_BARRIER();                                    // [A] CM / MATCH and the row components are in X: the mix wavefronts work
+      ZPQ_TEAM_BARRIER();                                    // [A2] the MIX outputs are in X
+      const unsigned pr = chain() * 2u + 1u;
+      const int y = decode_bit(pr);
+      if (r == 0) L32((unsigned)kTeamY) = (unsigned)y;
+      ZPQ_TEAM_BARRIER();                                    // [B]
+      decode_shift(y);
+      ch += ch + y;
+      if constexpr (B != 7) {
+        update(bitc, y);
+        c8 += c8 + y;
+        if (run) ++steps;
+        if constexpr (B == 3) hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
+        else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + y) & 0xf);
+      } else {
+        // HCOMP needs the byte, not the trained components: it runs first, and the last bit's update behind [C], while the
+        // row wavefronts are out for the next byte's rows
+        const int e = run_hcomp((unsigned)(c8 + c8 + y - 256));
+        if (run && e) { status = e; run = false; }
+        if (run) {
+          if (r == 0) out_ptr[nout] = (unsigned char)(ch - 256);
+          ++nout;
+          ++steps;
+          if (nout >= out_cap) run = false;
+        }
+        if (r == 0) L32((unsigned)kTeamRun) = run ? 1u : 0u;
+        ZPQ_TEAM_BARRIER();                                  // [C]
+        update(bitc, y);
+        any = any_running();
+        h = vm_H[(unsigned)cidx & Chain::HMASK];
+        static_for<0, N>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          constexpr CompK c = Chain::comp[i];
+          if constexpr (c.type == C_SSE) hsse[c.slot] = vm_H[(unsigned)i & Chain::HMASK];
+          if constexpr (c.type == C_MIX2 && c.mask0 != 0u) hm2[team_mix2_slot<Chain>(i)] = vm_H[(unsigned)i & Chain::HMASK];
+        });
+        hmap4 = 1;
+        c8 = 1;
+      }
+    });
+  }
+  if (r == 0 && live) {
+    res[rslot].out_len = nout;
+    res[rslot].consumed = eos ? rp : 0;
+    res[rslot].status = status;
+    res[rslot].steps = steps;
+  }
+}
+
+// =====================================================================================================================
 template <class Chain>
 __device__ __forceinline__ void spec_team_decode_body(const BlockJob* jobs, BlockResult* res, unsigned nblocks,
                                                       const DeviceTables* tb) {
@@ -1125,8 +1748,14 @@ __device__ __forceinline__ void spec_team_decode_body(const BlockJob* jobs, Bloc
     for (unsigned k = threadIdx.x; k < 128u; k += blockDim.x) ((lds_u32*)(wl + (kRegion - 512)))[k] = 0;
   }
   __syncthreads();
-  if (wave < NRW) team_rows<Chain>(T, lds0, jobs, nblocks, wave, lane);
-  else team_mixers<Chain>(T, lds0, jobs, res, nblocks, wave - NRW, lane);
+  if constexpr (team_tail_ok<Chain>()) {
+    if (wave < NRW) team_rows<Chain>(T, lds0, jobs, nblocks, wave, lane);
+    else if (wave < NRW + kTeamBlocks / 2) team_mix<Chain>(T, lds0, jobs, nblocks, wave - NRW, lane);
+    else team_tail<Chain>(T, lds0, jobs, res, nblocks, lane);
+  } else {
+    if (wave < NRW) team_rows<Chain>(T, lds0, jobs, nblocks, wave, lane);
+    else team_mixers<Chain>(T, lds0, jobs, res, nblocks, wave - NRW, lane);
+  }
 }
 
 }  // namespace zpq

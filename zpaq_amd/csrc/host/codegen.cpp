@@ -185,10 +185,31 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with
 
 }  // namespace
 
+// the lockstep decoder's TAIL wavefront (device/spec_team_kernel.h team_tail_map: the same rule): a chain with a MIX, at most 8
+// CM / MATCH components, and no MIX fed by an AVG / MIX2 / SSE; ZPAQ_AMD_TEAM_TAIL=0 builds the round-5 form (A/B)
+bool team_tail_wanted() {
+  static const bool off = [] { const char* v = getenv("ZPAQ_AMD_TEAM_TAIL"); return v && v[0] == '0'; }();
+  return !off;
+}
+static bool team_tail_ok(const zpq_plan& plan) {
+  if (!team_tail_wanted()) return false;
+  const CompDesc* comp = plan.comps();
+  int nmix = 0, nrole = 0;
+  for (uint32_t i = 0; i < plan.hdr().n; ++i) {
+    nmix += comp[i].type == C_MIX;
+    nrole += comp[i].type == C_CM || comp[i].type == C_MATCH;
+    if (comp[i].type == C_MIX)
+      for (uint32_t t = 0; t < comp[i].a3; ++t) {
+        const uint32_t ty = comp[comp[i].a2 + t].type;
+        if (ty == C_AVG || ty == C_MIX2 || ty == C_SSE) return false;
+      }
+  }
+  return nmix > 0 && nrole <= 8;
+}
 int team_threads(const zpq_plan& plan) {
   int rows = 0;
   for (uint32_t i = 0; i < plan.hdr().n; ++i) rows += plan.comps()[i].type == C_ICM || plan.comps()[i].type == C_ISSE;
-  return rows <= 16 ? 384 : 512;
+  return (rows <= 16 ? 384 : 512) + (team_tail_ok(plan) ? 64 : 0);
 }
 
 bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, std::string& why_not, int shape) {
@@ -224,6 +245,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
+    << (team && !team_tail_wanted() ? "#define ZPQ_TEAM_TAIL 0\n" : "")
     << "#include \"" << (team ? "spec_team_kernel.h" : (dual ? "spec_dual_kernel.h" : "spec_kernel.h")) << "\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
