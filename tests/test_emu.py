@@ -294,6 +294,17 @@ def test_pipe_encoder_table_fetches_that_alias(zlib_, oracle):
     _pipe_check(oracle, header, [b"\0" + d for d in fit] + [d[:1023] for d in fit], chunk=128, mode=0, persist=True)
 
 
+def test_coder_normalisation_in_closed_form(tmp_path):
+    """tests/cpp/coder_norm_check.c: the reference's shift-out loop against the closed form of the CODER unit, 2 x 10^7 states."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "coder_norm_check")
+    r = subprocess.run(["gcc", "-O2", os.path.join(root, "tests", "cpp", "coder_norm_check.c"), "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-500:]
+
+
 MATCH_RING_CFG = """
 comp 2 0 0 0 1
   0 match 10 9

@@ -1360,16 +1360,30 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
     if (n - nf >= 4u) flush4();
     for (; nf < n; ++nf) if (nf < L.out_cap) L.out[nf] = (unsigned char)(ob_lo >> (8u * (n - nf - 1u)));
   };
+  // Encoder::encode (libzpaq.cpp:2402-2416).  Its loop "while ((high ^ low) < 2^24) { out(high >> 24); high = high << 8 | 255;
+  // low <<= 8; low += (low == 0); }" in closed form: with 32 lanes in lockstep SOME lane shifts a byte out at nearly every bit
+  // of incompressible data, so the loop's branches were on every bit's path (profiles/unit_isa.py: the coder is the longest
+  // chain of a short model).  The loop runs k = (leading bytes high and low share) times, 0 .. 4: it emits the top k bytes of
+  // high, leaves high << 8k with ones shifted in, and low << 8k -- except that a turn which finds low << 8 == 0 makes it 1:
+  // that happens first at turn j = ceil((32 - ctz(low)) / 8) and never again (1 << 8 t != 0 for t < 4), so for j <= k the result
+  // is 1 << 8 (k - j).  Checked against the loop on 4 x 10^8 states (low >= 1 always: it starts at 1, mid + 1 <= high, and
+  // the rule above keeps it there; the OR below covers 0 as the loop would).
   auto encode = [&](int y, unsigned pr) __attribute__((always_inline)) {
     const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * pr) >> 16);
     if (y) high = mid; else low = mid + 1;
-    while ((high ^ low) < 0x1000000u) {
-      ob_hi = (ob_hi << 8) | (ob_lo >> 24);
-      ob_lo = (ob_lo << 8) | (high >> 24);
-      ++n;
-      high = high << 8 | 255u;
-      low = max(low << 8, 1u);                 // (low << 8, and 1 where that is 0)
-    }
+    const unsigned x = high ^ low;
+    const unsigned k = x ? (unsigned)__builtin_clz(x) >> 3 : 4u;
+    const unsigned sh = (8u * k) & 31u;
+    const unsigned emitted = (unsigned)(((unsigned long long)high << (8u * k)) >> 32);       // the top k bytes of high
+    const unsigned j = (39u - (unsigned)__builtin_ctz(low | 0x80000000u)) >> 3;
+    const unsigned nh = k == 4u ? 0xFFFFFFFFu : ((high << sh) | ((1u << sh) - 1u));
+    const unsigned nl = j <= k ? 1u << ((8u * (k - j)) & 31u) : low << sh;
+    high = nh;
+    low = nl;
+    const unsigned long long ob = ((((unsigned long long)ob_hi << 32) | ob_lo) << (8u * k)) | emitted;
+    ob_hi = (unsigned)(ob >> 32);
+    ob_lo = (unsigned)ob;
+    n += k;
     if (n - nf > 4u) flush4();                 // (an encode emits at most 4 bytes and finds at most 4 waiting: the buffer holds 8)
   };
   if (L.nb) {
@@ -2065,16 +2079,18 @@ template <class Chain, class = void> struct PipeMixLdsRows { static constexpr in
 template <class Chain> struct PipeMixLdsRows<Chain, decltype((void)Chain::MIX_LDS_ROWS)> { static constexpr int of(int r) { return Chain::MIX_LDS_ROWS[r]; } };
 
 // one chunk of MIX role r on packed rows.  q = the lane's weight quad, bl = the lane's block among the BPW of its wavefront;
-// lds = the unit's private region (LROWS > 0 only), stage = first chunk: copy rows [0, LROWS) from the arena
-template <class Chain, int r, int LROWS, int BPW, class SQ>
-__device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigned q, unsigned bl, unsigned* lds, bool stage, const SQ& squash) {
+// lds = the unit's private region (LROWS > 0 only), stage = first chunk: copy rows [0, LROWS) from the arena.  NH = 2: two lane
+// groups per block, `half` 0 codes bits 0 .. 3 and half 1 bits 4 .. 7 (pipe_mix_unit: both halves of a block in ONE wavefront).
+template <class Chain, int r, int LROWS, int BPW, int NH, class SQ>
+__device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigned q, unsigned half, unsigned bl, unsigned* lds, bool stage, const SQ& squash) {
   constexpr int I = Chain::MIX_COMP[r], QL = Chain::MIX_QL[r];
   constexpr CompK c = Chain::comp[I];
   constexpr int m = (int)c.a3, J = (int)c.a2, ci = Chain::P_CTX[I];
-  constexpr int NQ = (m + 3) / 4;
+  constexpr int NQ = (m + 3) / 4, NB = 8 / NH;
   constexpr unsigned PS = pipe_mix_pstride((unsigned)m);
   static_assert(NQ <= QL && c.a5 == 255u && c.mask0 >= 255u, "packed MIX rows: the 8 rows of a byte are distinct");
   static_assert(PS <= 4u * c.stride, "a packed row fits the padded row's place");
+  static_assert(NH == 1 || NH == 2, "lane groups per block");
   if (!L.nb) return;
   const bool act = q < (unsigned)NQ;                   // lanes that hold weights (the others: zero inputs, no stores)
   const unsigned qoff = 12u * (act ? q : 0u);
@@ -2086,18 +2102,28 @@ __device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigne
     have[x] = t < m;
     tin[x] = J + (have[x] ? t : 0);
   }
+  // bit b of this lane's part of the byte: its c8 and its value
+  auto c8_of = [&](unsigned bytev, int b) __attribute__((always_inline)) -> unsigned {
+    if constexpr (NH == 1) return pipe_c8(bytev, b);
+    else return ((half ? 16u : 1u) << b) | ((half ? bytev : bytev >> 4) >> (4 - b));
+  };
+  auto y_of = [&](unsigned bytev, int b) __attribute__((always_inline)) -> int {
+    if constexpr (NH == 1) return pipe_y(bytev, b);
+    else return (int)(((half ? bytev : bytev >> 4) >> (3 - b)) & 1u);
+  };
   // row index of bit b of a byte, and where its quad lives
-  auto row_of = [&](unsigned hh, unsigned bytev, int b) __attribute__((always_inline)) -> unsigned { return (hh + pipe_c8(bytev, b)) & c.mask0; };
+  auto row_of = [&](unsigned hh, unsigned bytev, int b) __attribute__((always_inline)) -> unsigned { return (hh + c8_of(bytev, b)) & c.mask0; };
   auto addr_of = [&](unsigned row) __attribute__((always_inline)) -> unsigned { return (unsigned)c.t0 + row * PS + qoff; };
   // LDS: [dword][row][quad][block]
-  auto lds_at = [&](unsigned row, unsigned w) __attribute__((always_inline)) -> unsigned {
-    return ((w * (unsigned)(LROWS > 0 ? LROWS : 1) + row) * (unsigned)NQ + (act ? q : 0u)) * (unsigned)BPW + bl;
-  };
+  constexpr unsigned LW = (unsigned)(LROWS > 0 ? LROWS : 1) * (unsigned)NQ * (unsigned)BPW;      // words from one dword plane to the next
+  const unsigned lbase = (act ? q : 0u) * (unsigned)BPW + bl;
+  auto lds_at = [&](unsigned row) __attribute__((always_inline)) -> unsigned { return row * (unsigned)(NQ * BPW) + lbase; };
   if constexpr (LROWS > 0) {
-    if (stage && act)
+    if (stage && act && (NH == 1 || half == 0u))
       for (unsigned row = 0; row < (unsigned)LROWS && row <= c.mask0; ++row) {
         const PipeW3 d = *(g_w3*)(L.arena + addr_of(row));
-        lds[lds_at(row, 0)] = d.x; lds[lds_at(row, 1)] = d.y; lds[lds_at(row, 2)] = d.z;
+        const unsigned a = lds_at(row);
+        lds[a] = d.x; lds[a + LW] = d.y; lds[a + 2u * LW] = d.z;
       }
   }
   unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
@@ -2106,7 +2132,8 @@ __device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigne
   auto inputs = [&](int x, unsigned kk) __attribute__((always_inline)) -> uint4 {
     const uint4 v = L.p(tin[x], kk);
     const unsigned mk = have[x] ? 0xFFFFFFFFu : 0u;
-    return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+    if constexpr (NH == 1) return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+    else return make_uint4((half ? v.z : v.x) & mk, (half ? v.w : v.y) & mk, 0u, 0u);
   };
   uint4 pv[4], pv1[4];
 #pragma unroll
@@ -2115,14 +2142,20 @@ __device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigne
   // this wavefront keeps in the L1: no branch around a request -- see pipe_match_in -- and no transaction at the L2)
   auto in_lds = [&](unsigned row) __attribute__((always_inline)) -> bool { return LROWS > 0 && row < (unsigned)LROWS; };
   auto fetch = [&](unsigned row) __attribute__((always_inline)) -> PipeW3 { return *(g_w3*)(L.arena + addr_of(in_lds(row) ? 0u : row)); };
-  PipeW3 w[8];
-  unsigned rowc[8];
+  auto from_lds = [&](PipeW3& d, unsigned row) __attribute__((always_inline)) {
+    const unsigned a = lds_at(in_lds(row) ? row : 0u);
+    const unsigned x = lds[a], y = lds[a + LW], z = lds[a + 2u * LW];
+    const bool li = in_lds(row);
+    d.x = li ? x : d.x; d.y = li ? y : d.y; d.z = li ? z : d.z;
+  };
+  PipeW3 w[NB];
+  unsigned rowc[NB];
 #pragma unroll
-  for (int B = 0; B < 8; ++B) { rowc[B] = row_of(h, byte, B); w[B] = fetch(rowc[B]); }
+  for (int B = 0; B < NB; ++B) { rowc[B] = row_of(h, byte, B); w[B] = fetch(rowc[B]); }
   if constexpr (LROWS > 0) {
+    if constexpr (NH == 2) (void)pipe_any(stage);      // (the other half staged the rows: a wavefront's LDS operations are in order; the emulator's lanes meet here)
 #pragma unroll
-    for (int B = 0; B < 8; ++B)
-      if (in_lds(rowc[B])) { w[B].x = lds[lds_at(rowc[B], 0)]; w[B].y = lds[lds_at(rowc[B], 1)]; w[B].z = lds[lds_at(rowc[B], 2)]; }
+    for (int B = 0; B < NB; ++B) from_lds(w[B], rowc[B]);
   }
   for (unsigned k = 0; k < L.nb; ++k) {
     const unsigned k2 = min(k + 2u, L.nb - 1u);
@@ -2130,53 +2163,58 @@ __device__ __forceinline__ void pipe_mix_packed_unit(PipeLane<Chain>& L, unsigne
     uint4 pv2[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) pv2[x] = inputs(x, k2);
-    unsigned rown[8];
+    unsigned rown[NB];
 #pragma unroll
-    for (int B = 0; B < 8; ++B) rown[B] = row_of(h1, byte1, B);
+    for (int B = 0; B < NB; ++B) rown[B] = row_of(h1, byte1, B);
     // next byte's rows: same context -> only equal bit positions select the same row (c8 ranges are disjoint), forwarded
     // below; contexts less than 256 apart -> any position may coincide: fetched after the stores
     const bool same = h1 == h;
     const bool late = !same && (((h1 - h) & c.mask0) < 256u || ((h - h1) & c.mask0) < 256u);
-    PipeW3 wn[8], nw[8];
+    PipeW3 wn[NB], nw[NB];
     if (!late) {
 #pragma unroll
-      for (int B = 0; B < 8; ++B) wn[B] = fetch(rown[B]);
+      for (int B = 0; B < NB; ++B) wn[B] = fetch(rown[B]);
     }
     PipeP8 out;
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
+    for (int B = 0; B < NB; ++B) {
       int w0, w1, w2, w3;
       pipe_unpack4(w[B], w0, w1, w2, w3);
       const int p0 = pipe_p_get(pv[0], B), p1 = pipe_p_get(pv[1], B), p2 = pipe_p_get(pv[2], B), p3 = pipe_p_get(pv[3], B);
       const int dot = __mul24(w0 >> 8, p0) + __mul24(w1 >> 8, p1) + __mul24(w2 >> 8, p2) + __mul24(w3 >> 8, p3);
       const int pr = sp_clamp2k(pipe_group_sum<QL>(dot) >> 8);
       out.set(B, pr);
-      const int err = __mul24(pipe_y(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
+      const int err = __mul24(y_of(byte, B) * 32767 - squash(pr), (int)c.a4) >> 4;
       nw[B] = pipe_pack4(sp_clamp512k(w0 + ((__mul24(err, p0) + (1 << 12)) >> 13)), sp_clamp512k(w1 + ((__mul24(err, p1) + (1 << 12)) >> 13)),
                          sp_clamp512k(w2 + ((__mul24(err, p2) + (1 << 12)) >> 13)), sp_clamp512k(w3 + ((__mul24(err, p3) + (1 << 12)) >> 13)));
       if (act) {
-        if (in_lds(rowc[B])) { lds[lds_at(rowc[B], 0)] = nw[B].x; lds[lds_at(rowc[B], 1)] = nw[B].y; lds[lds_at(rowc[B], 2)] = nw[B].z; }
+        if (in_lds(rowc[B])) { const unsigned a = lds_at(rowc[B]); lds[a] = nw[B].x; lds[a + LW] = nw[B].y; lds[a + 2u * LW] = nw[B].z; }
         else *(g_w3*)(L.arena + addr_of(rowc[B])) = nw[B];
       }
     }
-    if (q == 0) L.put_p(I, k, out.get());
+    if (q == 0) {
+      if constexpr (NH == 1) L.put_p(I, k, out.get());
+      else L.put_p64(I, k, half, make_uint2(out.w[0], out.w[1]));
+    }
+    if constexpr (NH == 2) {
+      if (pipe_any(late)) pipe_stores_done();       // (the other half's stores of this byte: ordered before the re-fetch)
+    }
     if (late) {
 #pragma unroll
-      for (int B = 0; B < 8; ++B) wn[B] = fetch(rown[B]);
+      for (int B = 0; B < NB; ++B) wn[B] = fetch(rown[B]);
     }
 #pragma unroll
-    for (int B = 0; B < 8; ++B) {
+    for (int B = 0; B < NB; ++B) {
       const bool fw = same && rown[B] == rowc[B];
       w[B].x = fw ? nw[B].x : wn[B].x; w[B].y = fw ? nw[B].y : wn[B].y; w[B].z = fw ? nw[B].z : wn[B].z;
     }
     if constexpr (LROWS > 0) {      // (behind this byte's LDS stores, in program order: no forwarding needed)
 #pragma unroll
-      for (int B = 0; B < 8; ++B)
-        if (in_lds(rown[B])) { w[B].x = lds[lds_at(rown[B], 0)]; w[B].y = lds[lds_at(rown[B], 1)]; w[B].z = lds[lds_at(rown[B], 2)]; }
+      for (int B = 0; B < NB; ++B) from_lds(w[B], rown[B]);
     }
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
 #pragma unroll
-    for (int B = 0; B < 8; ++B) rowc[B] = rown[B];
+    for (int B = 0; B < NB; ++B) rowc[B] = rown[B];
 #pragma unroll
     for (int x = 0; x < 4; ++x) { pv[x] = pv1[x]; pv1[x] = pv2[x]; }
   }
@@ -2237,7 +2275,7 @@ __device__ __forceinline__ void pipe_mix_body(const PipeArgs& a) {
     L.open(a, g * Chain::PIPE_G + sub * BPW + bl, Chain::P_LEVEL[I]);
     if (bl >= (unsigned)BPW) { L.live = false; L.nb = 0; }          // lanes beyond this wavefront's blocks
     if (L.chunk < 0 || !pipe_any(L.nb > 0)) return;
-    if constexpr (PipeMixPacked<Chain>::of(r)) pipe_mix_packed_unit<Chain, r, 0, 1>(L, q, 0u, nullptr, false, squash);
+    if constexpr (PipeMixPacked<Chain>::of(r)) pipe_mix_packed_unit<Chain, r, 0, 1, 1>(L, q, 0u, 0u, nullptr, false, squash);
     else pipe_mix_unit<Chain, r, 1>(L, q, 0u, squash);
   });
   }

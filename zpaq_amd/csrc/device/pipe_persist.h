@@ -229,9 +229,8 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       if (pipe_any(L.nb > 0)) {
         if constexpr (Chain::MIX_BITS != 0) pipe_mix_bits_unit<Chain, role>(L, q, B, ro.squash);
         else if constexpr (PipeMixPacked<Chain>::of(role)) {
-          constexpr int QL = Chain::MIX_QL[role], BPW = 64 / QL < (int)G ? 64 / QL : (int)G;
-          static_assert(Chain::PS_MIX_NH == 1, "packed MIX rows: one lane group per block");
-          pipe_mix_packed_unit<Chain, role, PipeMixLdsRows<Chain>::of(role), BPW>(L, q, mix_bl < (unsigned)BPW ? mix_bl : 0u, (unsigned*)priv, c == 0, ro.squash);
+          constexpr int QL = Chain::MIX_QL[role], NH = Chain::PS_MIX_NH, BPW = 64 / (QL * NH) < (int)G ? 64 / (QL * NH) : (int)G;
+          pipe_mix_packed_unit<Chain, role, PipeMixLdsRows<Chain>::of(role), BPW, NH>(L, q, B, mix_bl < (unsigned)BPW ? mix_bl : 0u, (unsigned*)priv, c == 0, ro.squash);
         }
         else pipe_mix_unit<Chain, role, Chain::PS_MIX_NH>(L, q, B, ro.squash);
       }

@@ -395,9 +395,9 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     // block of the wavefront: pipe_mix_packed_unit)
     int lds = 0;
     const CompDesc& c = comp[L.mix[r]];
-    if (!L.mix_bits && L.ps_mix_nh == 1 && L.mix_packed[r] && c.mask0 + 1u <= 256u && lds_rows_wish > 0) {
+    if (!L.mix_bits && L.mix_packed[r] && c.mask0 + 1u <= 256u && lds_rows_wish > 0) {
       const int rows = std::min<int>(lds_rows_wish, (int)(c.mask0 + 1u));
-      const int nq = ((int)c.a3 + 3) / 4, bpw = std::max(1, std::min(G, 64 / L.mix_ql[r]));
+      const int nq = ((int)c.a3 + 3) / 4, bpw = std::max(1, std::min(G, 64 / (L.mix_ql[r] * L.ps_mix_nh)));
       L.mix_lds_rows[r] = rows;
       lds = 3 * rows * nq * bpw * 4;
     }
