@@ -175,6 +175,25 @@ def cpu_decode_baseline(blocks, method, budget_s):
             "nproc": os.cpu_count(), "usable_cores": cores, "single_thread_MBps": bs / 1e6 / t1}
 
 
+def one_gpu_same_workload(kind, api=False):
+    """The committed one-GPU line of the same corpus (profiles/r06_bench_{default,mixed}.json, falling back to round 5's): the
+    device-resident value, or with api=True the host-buffer figure of its `api` leg."""
+    name = {"text": "default", "mixed": "mixed"}.get(kind)
+    if not name:
+        return None
+    for rnd in ("r06", "r05"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_{name}.json")
+        try:
+            one = json.load(open(path))
+            v = (one.get("api") or {}).get("value") if api else one["value"]
+            if v:
+                return {"value": v, "unit": "MB/s", "source": f"profiles/{rnd}_bench_{name}.json" + (" (api leg: host buffers)" if api else ""),
+                        "workload": one["config"]["workload"]}
+        except Exception:
+            continue
+    return None
+
+
 def in_library_bench(a, torch, z):
     """--in-library: N GPUs driven by ONE process through the library's own engines (zpq_init(-1): one engine and one
     host thread per device, the batch sharded contiguously by zpq_shard_range) -- the path a multi-threaded libzpaq
@@ -225,6 +244,19 @@ def in_library_bench(a, torch, z):
                          "frac": algo * a.steps / 1e9 / wall / (HBM_PEAK_GBS * ndev), "traffic": None,
                          "kernel": "whole zpq_compress_blocks call (wall clock, includes staging and PCIe)"},
             "cpu_baseline": None}
+    # like the rank path: what moved the blocks (nothing but the engines' own host-to-device copies, inside the timed call:
+    # the batch is cut by zpq_shard_range, no collective), and the one-GPU figure of the SAME workload through the same entry
+    # point (the `api` leg of the committed one-GPU line) for whoever computes an efficiency
+    ph = (C.c_double * 8)()
+    z.lib().zpq_last_api_timing(ph)
+    line["dist_ms"] = {"scatter": 0.0, "gather": 0.0, "scatter_bytes": 0, "gather_bytes": 0,
+                       "what": "no collective and no device-to-device traffic: host buffers sharded contiguously over the engines, each engine's "
+                               "H2D / D2H copies are part of the timed call",
+                       "last_call_ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3]}}
+    if ndev > 1:
+        one = one_gpu_same_workload(a.kind, api=True)
+        if one:
+            line["one_gpu_same_workload"] = one
     if a.cpu_seconds > 0:
         base, _ = cpu_baseline(host, a.method, a.cpu_seconds)
         line["cpu_baseline"] = base
@@ -728,13 +760,20 @@ def main():
                             "frac": (algo / 1e9 / code_s / HBM_PEAK_GBS) if code_s > 0 else 0.0, "traffic": None,
                             "kernel": kn, "kernel_kind": kk, "kernel_origin": org,
                             "algo_bytes_per_launch": algo, "kernel_s_per_launch": code_s,
-                            # FETCH_SIZE + WRITE_SIZE over the lockstep decoder's single dispatch (profiles/r05/call1_summary.txt):
-                            # 6 352 + 3 701 B per decoded byte of the -m5 text chain = 2.77 x its algorithmic 3 626; `traffic` is
-                            # filled for that corpus only (the records chain of the mixed corpus was not counted)
-                            "traffic_per_decoded_byte_text_chain": 10053.0},
+                            },
                "cpu_baseline": None}
-        if kind == "text" and "zpq_spec_decode3" in org and a.method == "5":
-            obj["roofline"]["traffic"] = 10053.0 * float(sum(lens_in))
+        # HBM traffic of the decoding launch from the committed counter passes (profiles/traffic.json "decode": FETCH_SIZE + WRITE_SIZE
+        # per decoded byte of each chain, counted over the lockstep decoder's single dispatch): filled when every chain of the
+        # batch was counted and the lockstep decoder is what ran
+        try:
+            dj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("decode", {})
+            per = {int(k.split("=")[1]): v for k, v in dj.items() if k.startswith("n=")}
+            if "zpq_spec_decode3" in org and a.method == "5" and all(p.ncomp in per for p in set(plans)):
+                obj["roofline"]["traffic"] = float(sum(per[p.ncomp]["traffic_per_decoded_byte"] * n for p, n in zip(plans, lens_in)))
+                obj["roofline"]["traffic_per_decoded_byte_by_chain"] = {f"n={k}": v["traffic_per_decoded_byte"] for k, v in per.items()}
+                obj["roofline"]["traffic_source"] = dj.get("source")
+        except Exception:
+            pass
         if a.cpu_seconds > 0:
             base = cpu_decode_baseline(dec_blocks, a.method, a.cpu_seconds)
             obj["cpu_baseline"] = base
@@ -941,12 +980,9 @@ def main():
         # The N = 1 line of a scaling series is configs[2] (text corpus), the N > 1 lines are configs[3]'s corpus (mixed: a second,
         # longer chain for a quarter of the blocks): efficiency against the N = 1 line mixes two workloads.  The one-GPU figure
         # of THIS workload, measured with `python bench.py --kind mixed`, is carried along for whoever computes the ratio.
-        try:
-            one = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_mixed.json")))
-            line["one_gpu_same_workload"] = {"value": one["value"], "unit": "MB/s", "source": "profiles/r05_bench_mixed.json",
-                                             "workload": one["config"]["workload"]}
-        except Exception:
-            pass
+        one = one_gpu_same_workload("mixed")
+        if one:
+            line["one_gpu_same_workload"] = one
     if rank == 0:
         # coded payloads of the timed run, for the identity check against the reference
         ncmp = min(nb, 512)

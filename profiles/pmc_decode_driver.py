@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 def gen(args):
     from zpaq_amd import corpus
-    return corpus.block("text", args[0], corpus.BASE_SEED + args[1])
+    return corpus.block(args[2] if len(args) > 2 else "text", args[0], corpus.BASE_SEED + args[1])
 
 
 def main():
@@ -30,12 +30,14 @@ def main():
     from zpaq_amd import corpus
     if sys.argv[1] == "make":
         nb, bs, prefix, path = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-        first = corpus.block("text", bs, corpus.BASE_SEED)
+        kind = sys.argv[6] if len(sys.argv) > 6 else "text"      # "records": the n = 29 chain of the mixed corpus (round 6)
+        first = corpus.block(kind, bs, corpus.BASE_SEED)
         hdr = z.method_to_header(z.expand_method("5", first))[0]
         with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:
-            blocks = pool.map(gen, [(prefix, b) for b in range(nb)], chunksize=8)
+            blocks = pool.map(gen, [(prefix, b, kind) for b in range(nb)], chunksize=8)
         z.init(0)
         plan = z.Plan(hdr)
+        print("chain: n =", plan.ncomp, "algorithmic bytes per byte", plan.algo_bytes_per_byte)
         coded = z.encode_batch([plan] * nb, [b"\0" + b.tobytes() for b in blocks])
         lens = np.array([len(c) for c in coded], np.int64)
         np.savez(path, header=np.frombuffer(bytes(hdr), np.uint8), lens=lens, coded=np.frombuffer(b"".join(coded), np.uint8),

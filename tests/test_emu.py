@@ -192,6 +192,23 @@ def test_lockstep_decoder_on_every_component_type_and_bad_streams(zlib_, oracle,
     assert emu.run(header, [good], decode=True, out_cap=701, team=True) == emu.run(header, [good], decode=True, waves=8, out_cap=701)
 
 
+def test_lockstep_decoder_with_the_tail_wavefront():
+    """ZPAQ_AMD_TEAM_TAIL=1 (spec_team_kernel.h, round 6: ONE tail wavefront for the scalar work of a workgroup's 8 blocks, the
+    mixer wavefronts keep the MIX dot products; measured slower on the MI355X and therefore off by default) must stay
+    bit-exact: the lockstep tests above again in a process that generates that form (448 threads per workgroup for -m5)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZPAQ_AMD_TEAM_TAIL="1")
+    chk = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests/emu'); import re, emu, zpaq_amd as z; from zpaq_amd import corpus; "
+           "h = z.method_to_header(z.expand_method('5', corpus.block('text', 1 << 20, corpus.BASE_SEED)))[0]; "
+           "assert re.findall(r'__launch_bounds__\\((\\d+)\\)', emu.team_source(h)) == ['448']" % (root, root))
+    r = subprocess.run([sys.executable, "-c", chk], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-800:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "test_lockstep_decoder and not tail_wavefront"],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=3000)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:]
+
+
 # ---------------------------------------------------------------------------------------------------------
 # The pipelined encoder (zpaq_amd/csrc/device/pipe_kernel.h): the same generated source the GPU runs, executed
 # step by step on the host with consumers launched BEFORE producers inside a step (tests/emu/pipe_emu_main.cpp).

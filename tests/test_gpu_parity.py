@@ -753,6 +753,36 @@ def test_foreign_kernel_on_the_device_makes_the_persistent_launch_step_aside(gpu
     assert gpu.compress_blocks(blocks, "5") == want and L.zpq_last_persistent() == 1
 
 
+def test_measured_and_shelved_forms_stay_bit_exact(gpu, tmp_path):
+    """Two forms of round 6 that were built, measured slower on the MI355X and left off by default: MIX
+    weight rows packed as 24-bit quads with the first rows of a small table in LDS (ZPAQ_AMD_MIX_PACKED=1), and the lockstep
+    decoder with a tail wavefront (ZPAQ_AMD_TEAM_TAIL=1).  The generator reads its knobs once per process: a child codes
+    blocks of the headline's chain with both on (code objects from the prebuilt cache, hipRTC otherwise) -- the coded streams
+    must be the default's byte for byte, and the tail form must decode them."""
+    import subprocess
+    blocks = [corpus.block("text", 1 << 20, 900 + i) for i in range(12)]
+    hdr = gpu.method_to_header(gpu.expand_method("5", blocks[0]))[0]
+    plan = gpu.Plan(hdr)
+    want = gpu.encode_batch([plan] * len(blocks), [b"\0" + b.tobytes() for b in blocks])
+    digest = hashlib.sha1(b"".join(want)).hexdigest()
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import zpaq_amd as z\nfrom zpaq_amd import corpus, prebuild\n"
+            "blocks = [corpus.block('text', 1 << 20, 900 + i) for i in range(12)]\n"
+            "hdr = z.method_to_header(z.expand_method('5', blocks[0]))[0]\n"
+            "assert 'MIX_PACKED[2] = {1,1}' in prebuild.pipe_source_and_key(hdr, 0)[0] and '__launch_bounds__(448)' in prebuild.team_source_and_key(hdr)[0]\n"
+            "z.init(0)\nplan = z.Plan(hdr)\n"
+            "coded = z.encode_batch([plan] * 12, [b'\\0' + b.tobytes() for b in blocks])\n"
+            "print('PERSIST', z.lib().zpq_last_persistent())\n"
+            "print('DIGEST', hashlib.sha1(b''.join(coded)).hexdigest())\n"
+            "z.set_kernel(6)\n"
+            "back = z.decode_batch([plan] * 12, [c + b'\\0\\0\\0\\0' for c in coded], [40001] * 12)\n"
+            "print('DECODED', all(d == (b'\\0' + blocks[i].tobytes())[:40001] for i, (d, _) in enumerate(back)))\n" % ROOT)
+    env = dict(os.environ, ZPAQ_AMD_MIX_PACKED="1", ZPAQ_AMD_TEAM_TAIL="1", ZPAQ_AMD_PIPE_MODE="throughput")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "PERSIST 1" in r.stdout and f"DIGEST {digest}" in r.stdout and "DECODED True" in r.stdout, r.stdout[-2000:]
+
+
 def test_input_tail_copied_behind_the_first_steps(gpu, monkeypatch):
     """A batch of 64 or more equally long blocks of 512 KiB or more from pinned staging has only the first 64 KiB of every block
     on the device when the step kernels start; the rest follows behind the first steps (engine.cpp LateInput: step s reads

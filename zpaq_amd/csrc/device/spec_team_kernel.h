@@ -1093,8 +1093,12 @@ __device__ __forceinline__ void team_mixers(const TT& T, lds_u8* const lds0, con
 //
 // One more barrier per bit, ~970 instead of ~1 840 wave-instructions per bit and compute unit.  The model arithmetic is the
 // mixers' above, statement for statement.
+// Measured (profiles/r06_results.md): SLOWER than the form above, 139.6 against 159.5 MB/s on the mixed corpus at the decoder's
+// operating point.  The bit is a chain of latencies -- rows -> [A] -> dot products -> MIX2 / SSE -> coder -> [B] -> updates -- and
+// the split puts a third barrier and an LDS hand-over into it; the issue slots it frees were not what the bit waited for.
+// Kept behind ZPAQ_AMD_TEAM_TAIL=1 (host/codegen.cpp writes the define), bit-exact in the emulator and on the GPU.
 #ifndef ZPQ_TEAM_TAIL
-#define ZPQ_TEAM_TAIL 1
+#define ZPQ_TEAM_TAIL 0
 #endif
 
 template <class Chain>

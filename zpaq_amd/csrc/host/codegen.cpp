@@ -186,10 +186,13 @@ bool translate_hcomp(const U8* prog, int len, std::ostringstream& out, bool with
 }  // namespace
 
 // the lockstep decoder's TAIL wavefront (device/spec_team_kernel.h team_tail_map: the same rule): a chain with a MIX, at most 8
-// CM / MATCH components, and no MIX fed by an AVG / MIX2 / SSE; ZPAQ_AMD_TEAM_TAIL=0 builds the round-5 form (A/B)
+// CM / MATCH components, and no MIX fed by an AVG / MIX2 / SSE.  OFF by default: measured on the MI355X (profiles/r06, call 2:
+// 2 048 x 1 MiB of the mixed corpus, every byte verified) the form with the tail wavefront decodes at 139.6 MB/s against 159.5
+// without it -- the bit is a latency chain (rows -> MIX -> MIX2 / SSE -> coder), not an issue-slot budget, and the tail adds a
+// barrier and an LDS hand-over to that chain.  ZPAQ_AMD_TEAM_TAIL=1 builds it (tests keep it bit-exact).
 bool team_tail_wanted() {
-  static const bool off = [] { const char* v = getenv("ZPAQ_AMD_TEAM_TAIL"); return v && v[0] == '0'; }();
-  return !off;
+  static const bool on = [] { const char* v = getenv("ZPAQ_AMD_TEAM_TAIL"); return v && v[0] == '1'; }();
+  return on;
 }
 static bool team_tail_ok(const zpq_plan& plan) {
   if (!team_tail_wanted()) return false;
@@ -245,7 +248,7 @@ bool generate_spec_source(const zpq_plan& plan, int waves, std::string& source, 
   if (h_bytes <= 4096) { h_lds = 0; lds_used = (h_bytes + 15) & ~15; }
   std::ostringstream o;
   o << "// generated by zpaq_amd codegen v" << kCodegenVersion << " -- do not edit\n"
-    << (team && !team_tail_wanted() ? "#define ZPQ_TEAM_TAIL 0\n" : "")
+    << (team && team_tail_wanted() ? "#define ZPQ_TEAM_TAIL 1\n" : "")
     << "#include \"" << (team ? "spec_team_kernel.h" : (dual ? "spec_dual_kernel.h" : "spec_kernel.h")) << "\"\n"
        "namespace zpq_gen {\n"
        "struct Chain {\n";
@@ -333,7 +336,7 @@ static uint32_t mix_pstride(uint32_t m) {              // = device pipe_mix_pstr
   return p;
 }
 // lds_rows_wish: rows of a SMALL packed MIX table (up to 256 rows: the mixer selected by the partial byte alone) kept in the LDS
-static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wish) {
+static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wish, bool halves) {
   const CompDesc* comp = plan.comps();
   const PlanHeader& ph = plan.hdr();
   const int n = L.n, G = L.G;
@@ -377,10 +380,10 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
   // throughput shape: a MIX whose 8 rows of a byte are distinct splits the byte over two lane groups (device: pipe_mix_unit NH = 2)
   L.ps_mix_nh = 1;
-  // (measured on the MI355X, profiles/r05/call12: no faster than one lane group per block -- at 1024 blocks the MIX units wait
-  //  for their rows, not for their own instructions -- and 8 more wavefronts per group; ZPAQ_AMD_MIX_HALVES=1 builds it)
-  static const bool halves_wanted = [] { const char* v = getenv("ZPAQ_AMD_MIX_HALVES"); return v && v[0] == '1'; }();
-  if (halves_wanted && !L.mix_bits && !L.mix.empty()) {
+  // (round 5, call 12: no faster than one lane group per block.  Round 6, after the other units had caught up: the two MIX units
+  //  were the longest streams of the launch -- 2.5-2.9 s busy of 3.0 -- and in halves the -m5 headline goes from 349.7 to 369.2 MB/s
+  //  (profiles/r06 call 3; 8 more wavefronts per group: 62 of the 64 slots of its 8 workgroups).  ZPAQ_AMD_MIX_HALVES=0: one group.)
+  if (halves && !L.mix_bits && !L.mix.empty()) {
     bool ok = true;
     for (size_t r = 0; r < L.mix.size(); ++r) {
       const CompDesc& c = comp[L.mix[r]];
@@ -612,7 +615,12 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
   // packed MIX rows (device/pipe_kernel.h): a mixer whose rows are distinct per bit, with 3 .. 64 inputs, whose packed row is
   // smaller than its padded one or whose table is small enough to be worth keeping in the LDS; not with a lane per bit position
   L.mix_packed.assign(L.mix.size(), 0);
-  static const bool packed_off = [] { const char* v = getenv("ZPAQ_AMD_MIX_PACKED"); return v && v[0] == '0'; }();
+  // OFF by default -- built, bit-exact, measured, slower (profiles/r06 calls 1 and 3, -m5 headline): 286 MB/s against 356 with one lane
+  // group per block, 317 against 369 in halves, and the same 317 whether 0, 64 or 128 rows of m8 live in the LDS.  The units' own
+  // instruction streams grew (619 -> 811 / 1209 instructions per byte) and became the longest of the launch, while the requests
+  // they saved were the cheap ones (profiles/r06/gups2.hip: a row touch that stays on the die costs about half of one that
+  // goes to HBM, and a launch at 0.8 of the machine's request rate is not paced by requests alone).  ZPAQ_AMD_MIX_PACKED=1 builds it.
+  static const bool packed_off = [] { const char* v = getenv("ZPAQ_AMD_MIX_PACKED"); return !(v && v[0] == '1'); }();
   for (size_t r = 0; r < L.mix.size(); ++r) {
     const CompDesc& c = comp[L.mix[r]];
     const uint32_t ps = mix_pstride(c.a3);
@@ -622,13 +630,22 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
   // the persistent launch: with as many of a small packed table's rows in the LDS as still pack into the same number of
   // workgroups per group as none would (a ninth workgroup per group would cost the headline its one-round residency)
   static const int rows_forced = [] { const char* v = getenv("ZPAQ_AMD_MIX_LDS_ROWS"); return v ? atoi(v) : -1; }();
-  plan_persistent(plan, L, 0);
+  // MIX units in halves (two lane groups per block: twice the wavefronts, half the stream each) when that costs no extra
+  // workgroup per group -- a ninth would cost a 1024-block batch its one-round residency
+  static const bool halves_wanted = [] { const char* v = getenv("ZPAQ_AMD_MIX_HALVES"); return !(v && v[0] == '0'); }();
+  plan_persistent(plan, L, 0, false);
+  bool halves = false;
+  if (L.persist_ok && halves_wanted) {
+    PipeLayout T = L;
+    plan_persistent(plan, T, 0, true);
+    if (T.persist_ok && T.ps_mix_nh == 2 && T.ps_wpg <= L.ps_wpg) { L = T; halves = true; }
+  }
   if (L.persist_ok) {
     const int wpg0 = L.ps_wpg;
     for (int wish : {128, 64, 32}) {
       if (rows_forced >= 0 && wish != rows_forced) continue;
       PipeLayout T = L;
-      plan_persistent(plan, T, wish);
+      plan_persistent(plan, T, wish, halves);
       bool any = false;
       for (int v : T.mix_lds_rows) any = any || v != 0;
       if (!any) break;

@@ -170,6 +170,42 @@ def compile_one(args):
     return key, "built"
 
 
+# Code-generation knobs that tests keep bit-exact although they are off by default (built, measured on the MI355X, slower:
+# DESIGN.md section 10): the generator reads them once per process, so each variant is generated and built by a child.
+KNOB_VARIANTS = [({"ZPAQ_AMD_MIX_PACKED": "1"}, "pipe"), ({"ZPAQ_AMD_TEAM_TAIL": "1"}, "team")]
+
+
+def build_variant(which):
+    """(child process, knobs in the environment) the -m5 text chain's pipelined encoder (throughput shape) or lockstep
+    decoder: prints 'KEY <cache key>' and builds the code object."""
+    import zpaq_amd as z
+    from zpaq_amd import corpus
+    L = z.lib()
+    L.zpq_spec_cache_dir.restype = C.c_char_p
+    L.zpq_spec_include_dir.restype = C.c_char_p
+    cache, inc = L.zpq_spec_cache_dir().decode(), L.zpq_spec_include_dir().decode()
+    os.makedirs(cache, exist_ok=True)
+    h = z.method_to_header(z.expand_method("5", corpus.block("text", 1 << 20, corpus.BASE_SEED)))[0]
+    src, key = pipe_source_and_key(h, 0) if which == "pipe" else team_source_and_key(h)
+    if src is None:
+        raise RuntimeError(key)
+    print("KEY", key, flush=True)
+    compile_one((src, key, cache, inc))
+
+
+def knob_variants():
+    """Builds KNOB_VARIANTS (children, side by side); returns their cache keys."""
+    procs = [subprocess.Popen([sys.executable, "-m", "zpaq_amd.prebuild", "--variant", which], cwd=ROOT, env=dict(os.environ, **env),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for env, which in KNOB_VARIANTS]
+    keys = []
+    for pr, (env, which) in zip(procs, KNOB_VARIANTS):
+        out = pr.communicate()[0]
+        if pr.returncode != 0:
+            raise RuntimeError(f"prebuild of variant {env} failed:\n{out[-3000:]}")
+        keys += [l.split()[1] for l in out.splitlines() if l.startswith("KEY ")]
+    return keys
+
+
 def main(verbose=True, clean=True):
     import zpaq_amd as z
     L = z.lib()
@@ -213,6 +249,7 @@ def main(verbose=True, clean=True):
         del os.environ["ZPAQ_AMD_SPEC_WAVES"]
     else:
         os.environ["ZPAQ_AMD_SPEC_WAVES"] = forced
+    seen.update(knob_variants())
     # drop stale code objects of older template versions
     for fn in os.listdir(cache):
         if clean and fn.endswith(".hsaco") and fn[:-6] not in seen:       # (--keep: experiments keep their variants)
@@ -226,4 +263,7 @@ def main(verbose=True, clean=True):
 
 
 if __name__ == "__main__":
-    main(clean="--keep" not in sys.argv)
+    if "--variant" in sys.argv:
+        build_variant(sys.argv[sys.argv.index("--variant") + 1])
+    else:
+        main(clean="--keep" not in sys.argv)
