@@ -354,15 +354,20 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   L.ps_nunit = nunit;
   std::vector<int> unit_waves(nunit, 0);
   std::vector<PipeLayout::Slot> slots;
-  auto add = [&](int kind, int role, int sub, int unit, int lds, float cost) {
-    PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost;
+  auto add = [&](int kind, int role, int sub, int unit, int lds, float cost, float lines = 0.f) {
+    PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost; s.lines = lines;
     slots.push_back(s); ++unit_waves[unit];
   };
+  // a table of up to 256 KiB per block stays on the die for a batch that fills the device (1024 x 256 KiB = the Infinity Cache):
+  // its lines cost about half of one that goes to HBM (profiles/r06/gups2.hip)
+  static const float ondie = [] { const char* v = getenv("ZPAQ_AMD_PACK_ONDIE_WEIGHT"); return v ? (float)atof(v) : 0.5f; }();      // (A/B)
+  auto line_weight = [](uint64_t table_bytes) { return table_bytes <= (256u << 10) ? ondie : 1.0f; };
   const int hl = std::min(L.hcomp_lanes, G);
   const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
   // relative time per chunk of a unit wavefront inside a full launch (-m5, 1024 blocks, profiles/r05/call5: ms per 2049 chunks / 1000)
   for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.94f);
-  for (size_t r = 0; r < L.rows.size(); ++r) add(1, (int)r, 0, row_unit[L.rows[r]], 0, 1.8f);
+  for (size_t r = 0; r < L.rows.size(); ++r)      // two finds per byte and block: two lines
+    add(1, (int)r, 0, row_unit[L.rows[r]], 0, 1.8f, 2.f * G * line_weight((uint64_t)comp[L.rows[r]].mask1 + 1u));
   for (size_t r = 0; r < L.light.size(); ++r) {
     const int k = L.light[r].first, i = L.light[r].second;
     static const float lc[12] = {0, 0, 0.1f, 2.5f, 3.1f, 0.3f, 1.5f, 2.5f, 1.43f, 0.45f, 0.45f, 0.78f};
@@ -372,7 +377,20 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     // a CM / MIX2 with a table of up to 512 words keeps it in the LDS (device/pipe_persist.h pipe_light_lds_words)
     int lds = 0;
     if ((k == K_CM || (k == K_MIX2 && comp[i].mask0 != 0u)) && comp[i].mask0 + 1u <= 512u && comp[i].mask0 >= 3u) lds = (int)(comp[i].mask0 + 1u) * G * 4;
-    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0]);
+    // lines per byte of the unit's wavefront: CM 2 per block (a nibble's four words share a line), MATCH ~2, MIX2 / SSE one per bit;
+    // with a lane per bit position a wavefront holds 8 blocks
+    float lines = 0.f;
+    if (!lds) {
+      const float wcm = line_weight(4ull * (comp[i].mask0 + 1ull));
+      if (k == K_CM) lines = 2.f * G * wcm;
+      else if (k == K_CM_BITS) lines = 2.f * 8 * wcm;
+      else if (k == K_MATCH) lines = 2.f * G;
+      else if (k == K_MIX2 && comp[i].mask0 != 0u) lines = 8.f * G * wcm;
+      else if (k == K_MIX2_BITS) lines = 8.f * 8 * wcm;
+      else if (k == K_SSE) lines = 8.f * G * wcm;
+      else if (k == K_SSE_BITS) lines = 8.f * 8 * wcm;
+    }
+    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0], lines);
   }
   for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f);
   for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 256 * G * 4 + 64 * G * 4, 1.5f);      // (packed pairs: pipe_isse_packed_unit)
@@ -404,8 +422,12 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
       L.mix_lds_rows[r] = rows;
       lds = 3 * rows * nq * bpw * 4;
     }
+    // a lane group touches one row per bit it codes: (lane groups per wavefront) x (bits per lane group) lines per byte
+    const float groups_per_wave = 64.f / (float)L.mix_ql[r];
+    float lines = groups_per_wave * (L.mix_bits ? 1.f : 8.f / (float)L.ps_mix_nh) * line_weight(4ull * c.stride * (c.mask0 + 1ull));
+    if (L.mix_lds_rows[r]) lines *= 1.f / 8.f;
     for (int sub = 0; sub < nw; ++sub)
-      add(5, (int)r, sub, p_unit[L.mix[r]], lds, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : (lds ? 1.6f : 2.6f)));
+      add(5, (int)r, sub, p_unit[L.mix[r]], lds, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : (lds ? 1.6f : 2.6f)), lines);
   }
   // who reads whose streams
   std::vector<std::vector<int>> producers(nunit);
@@ -452,6 +474,94 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     if (total >= 40 && wpg_min < 8) tries.push_back(8);
     for (int w = wpg_min; w <= total; ++w) tries.push_back(w);
   }
+  // Round 6: a workgroup is a compute unit, and what paces a compute unit's wavefronts is how many memory lines they have in
+  // flight together (per-unit profile, profiles/r06 call 2: the workgroup of a group with 288 lines per byte had every
+  // wavefront at 2.5-2.8 s, those with 160 at 1.6-1.9 s, whatever the units were).  So the packing balances LINES first --
+  // units that ask for lines go, heaviest first, to the workgroup with the fewest so far -- then the units with LDS tables
+  // (no lines: maps, HCOMP, the small light tables) fill the remaining wavefront slots by LDS fit, then the rest by cost.
+  // Tried for the workgroup count the table-first packing below needs; when it does not fit, that packing stands.
+  static const bool balance_lines = [] { const char* v = getenv("ZPAQ_AMD_PACK_LINES"); return !(v && v[0] == '0'); }();
+  auto finish = [&](int wpg, int W, const std::vector<std::vector<int>>& bin_items) {
+    L.ps_wpg = wpg; L.ps_waves = W;
+    int max_lds = 0;
+    L.ps_slots.assign((size_t)wpg * W, PipeLayout::Slot());
+    L.ps_deps.assign((size_t)wpg * W, {});
+    for (int b = 0; b < wpg; ++b) {
+      // wavefront w runs on SIMD w % 4: the four heaviest units first, then the next four against them
+      std::vector<int> v = bin_items[b];
+      std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return slots[x].cost > slots[y].cost; });
+      std::vector<int> at(W, -1);
+      if (W == 8) {
+        // two wavefronts per SIMD (w and w + 4): the units sorted by cost, the k-th heaviest shares its SIMD with the k-th lightest
+        // (an idle slot counts as the lightest)
+        std::vector<int> padded = v;
+        padded.resize(8, -1);
+        for (int k = 0; k < 4; ++k) { at[k] = padded[k]; at[4 + k] = padded[7 - k]; }
+      } else {
+        for (int k = 0; k < (int)v.size(); ++k) at[k] = v[k];
+      }
+      // (a wavefront without a unit exits at once: the unit that would have shared its SIMD has it to itself)
+      int off = (kPersistRoBytes + 255) & ~255;
+      for (int w = 0; w < W; ++w) {
+        if (at[w] < 0) continue;
+        PipeLayout::Slot s = slots[at[w]];
+        s.lds_off = off; off += s.lds;
+        L.ps_slots[(size_t)b * W + w] = s;
+        L.ps_deps[(size_t)b * W + w] = unit_deps[s.unit];
+      }
+      max_lds = std::max(max_lds, off);
+    }
+    L.ps_lds_bytes = max_lds;
+    L.persist_ok = true;
+  };
+  auto pack_by_lines = [&](int wpg, int W, std::vector<std::vector<int>>& out) -> bool {
+    struct Bin { std::vector<int> s; int lds = 0; float cost = 0, lines = 0; };
+    std::vector<Bin> bins(wpg);
+    std::vector<int> order;
+    for (int i = 0; i < total; ++i) if (slots[i].lines > 0.f) order.push_back(i);
+    const int nline = (int)order.size(), nrest = total - nline;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return slots[x].lines > slots[y].lines; });
+    // every workgroup keeps room for its share of the units without lines (they carry the LDS tables)
+    const int keep = std::min(W - 1, (nrest + wpg - 1) / wpg);
+    for (int idx : order) {
+      int best = -1;
+      for (int b = 0; b < wpg; ++b) {
+        if ((int)bins[b].s.size() >= W - keep || bins[b].lds + slots[idx].lds > cap) continue;
+        if (best < 0 || bins[b].lines < bins[best].lines || (bins[b].lines == bins[best].lines && bins[b].cost < bins[best].cost)) best = b;
+      }
+      if (best < 0) {       // no room under the reserve: any workgroup with a free wavefront
+        for (int b = 0; b < wpg; ++b)
+          if ((int)bins[b].s.size() < W && bins[b].lds + slots[idx].lds <= cap && (best < 0 || bins[b].lines < bins[best].lines)) best = b;
+      }
+      if (best < 0) return false;
+      bins[best].s.push_back(idx); bins[best].lds += slots[idx].lds; bins[best].cost += slots[idx].cost; bins[best].lines += slots[idx].lines;
+    }
+    std::vector<int> rest;
+    for (int i = 0; i < total; ++i) if (!(slots[i].lines > 0.f)) rest.push_back(i);
+    std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) {
+      if (slots[x].lds != slots[y].lds) return slots[x].lds > slots[y].lds;
+      return slots[x].cost > slots[y].cost;
+    });
+    for (int idx : rest) {
+      const auto& s = slots[idx];
+      int best = -1;
+      for (int b = 0; b < wpg; ++b) {
+        if ((int)bins[b].s.size() >= W || bins[b].lds + s.lds > cap) continue;
+        if (best < 0) { best = b; continue; }
+        if (s.lds) {
+          // a table: the workgroup with the most free wavefront slots, then the emptiest LDS (the tables have to spread: a workgroup
+          // with few free wavefronts cannot take many)
+          const int fb = W - (int)bins[b].s.size(), fbest = W - (int)bins[best].s.size();
+          if (fb > fbest || (fb == fbest && bins[b].lds < bins[best].lds)) best = b;
+        } else if (bins[b].cost < bins[best].cost) best = b;
+      }
+      if (best < 0) return false;
+      bins[best].s.push_back(idx); bins[best].lds += s.lds; bins[best].cost += s.cost;
+    }
+    out.clear();
+    for (auto& b : bins) out.push_back(b.s);
+    return true;
+  };
   for (size_t ti = 0; ti < tries.size() * 2; ++ti) {
     const int wpg = tries[ti / 2];
     const bool best_fit = (ti & 1) == 1;          // (spread the tables when that works: the units that own them are LDS-bound together)
@@ -483,37 +593,12 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
       bins[best].s.push_back(idx); bins[best].lds += s.lds; bins[best].cost += s.cost;
     }
     if (!fits) continue;
-    L.ps_wpg = wpg; L.ps_waves = W;
-    int max_lds = 0;
-    L.ps_slots.assign((size_t)wpg * W, PipeLayout::Slot());
-    L.ps_deps.assign((size_t)wpg * W, {});
-    for (int b = 0; b < wpg; ++b) {
-      // wavefront w runs on SIMD w % 4: the four heaviest units first, then the next four against them
-      std::vector<int> v = bins[b].s;
-      std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return slots[x].cost > slots[y].cost; });
-      std::vector<int> at(W, -1);
-      if (W == 8) {
-        // two wavefronts per SIMD (w and w + 4): the units sorted by cost, the k-th heaviest shares its SIMD with the k-th lightest
-        // (an idle slot counts as the lightest)
-        std::vector<int> padded = v;
-        padded.resize(8, -1);
-        for (int k = 0; k < 4; ++k) { at[k] = padded[k]; at[4 + k] = padded[7 - k]; }
-      } else {
-        for (int k = 0; k < (int)v.size(); ++k) at[k] = v[k];
-      }
-      // (a wavefront without a unit exits at once: the unit that would have shared its SIMD has it to itself)
-      int off = (kPersistRoBytes + 255) & ~255;
-      for (int w = 0; w < W; ++w) {
-        if (at[w] < 0) continue;
-        PipeLayout::Slot s = slots[at[w]];
-        s.lds_off = off; off += s.lds;
-        L.ps_slots[(size_t)b * W + w] = s;
-        L.ps_deps[(size_t)b * W + w] = unit_deps[s.unit];
-      }
-      max_lds = std::max(max_lds, off);
+    std::vector<std::vector<int>> items;
+    if (!(balance_lines && W == 8 && pack_by_lines(wpg, W, items))) {
+      items.clear();
+      for (auto& b : bins) items.push_back(b.s);
     }
-    L.ps_lds_bytes = max_lds;
-    L.persist_ok = true;
+    finish(wpg, W, items);
     return;
   }
   L.persist_why = "the units of a group cannot be packed into workgroups";

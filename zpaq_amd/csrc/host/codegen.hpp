@@ -81,6 +81,7 @@ struct PipeLayout {
     int lds = 0;               // bytes of private LDS (HCOMP: H, ICM / ISSE: the side tables of the group)
     int lds_off = 0;           // where in the workgroup's LDS
     float cost = 0;            // relative time per chunk (packing heuristic only)
+    float lines = 0;           // distinct memory lines of model state the wavefront asks for per input byte, lines that stay on the die at half weight (packing: what a compute unit can have in flight is what paces its wavefronts)
   };
   struct Dep { int unit, lag, mult; };   // wait for progress[unit] >= mult * (chunk + 1 - lag)
   bool persist_ok = false;
