@@ -1064,10 +1064,19 @@ def main():
                                   "library_total_first_call": first_ms}}
         want_c1 = a.configs1 if a.configs1 is not None else int(world == 1 and a.mode == "encode" and a.method == "5" and a.kind == "text"
                                                                 and nb == 1024 and bs == (1 << 20))
-        if want_c1 and world == 1:
-            line["configs1"] = configs1_leg(min(a.cpu_seconds, 6.0))
         want_legacy = a.legacy if a.legacy is not None else int(world == 1 and a.mode == "encode" and a.method == "5" and a.kind == "text"
                                                                  and nb == 1024 and bs == (1 << 20))
+        if (want_c1 or want_legacy) and world == 1:
+            # the side legs run in child processes with engines of their own: this process is done with the device (max.cfg's
+            # 1024 blocks need 235 GiB of model state -- with the headline's 100 GiB still held here the child's budget refuses)
+            try:
+                del d_in, d_res
+            except Exception:
+                pass
+            torch.cuda.empty_cache()
+            z.shutdown()
+        if want_c1 and world == 1:
+            line["configs1"] = configs1_leg(min(a.cpu_seconds, 6.0))
         if want_legacy and world == 1:
             line["legacy2"] = legacy_leg(2, min(a.cpu_seconds, 4.0))
             line["legacy3"] = legacy_leg(3, min(a.cpu_seconds, 6.0))

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <sstream>
 #include <algorithm>
@@ -354,20 +355,26 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   L.ps_nunit = nunit;
   std::vector<int> unit_waves(nunit, 0);
   std::vector<PipeLayout::Slot> slots;
-  auto add = [&](int kind, int role, int sub, int unit, int lds, float cost, float lines = 0.f) {
-    PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost; s.lines = lines;
+  // `lines` of a unit wavefront: the distinct 128-byte memory lines it asks for per input byte -- rows of the model's tables AND the
+  // elements of the streams it reads and writes (a ctx element is 4 bytes per block, bh 8, p 16: G blocks side by side).  Two
+  // weights exist for A/Bs -- lines of a table small enough to stay on the die (up to 256 KiB per block: 1024 blocks = the
+  // Infinity Cache), stream lines -- and both are 1: measured (profiles/r06 calls 5-7, six packings) counting every line alike
+  // packs as well as any weighting tried (0.7 / 0.25: the same; 0.5 / 0: -5 %; 0.3 / 0.25: -10 %).
+  static const float ondie_w = [] { const char* v = getenv("ZPAQ_AMD_PACK_ONDIE_WEIGHT"); return v ? (float)atof(v) : 1.0f; }();
+  static const float stream_w = [] { const char* v = getenv("ZPAQ_AMD_PACK_STREAM_WEIGHT"); return v ? (float)atof(v) : 1.0f; }();
+  const float ctx_l = G * 4 / 128.f, bh_l = G * 8 / 128.f, p_l = G * 16 / 128.f;
+  auto add = [&](int kind, int role, int sub, int unit, int lds, float cost, float lines = 0.f, float stream_lines = 0.f) {
+    PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost;
+    s.lines = lines + stream_w * stream_lines;
     slots.push_back(s); ++unit_waves[unit];
   };
-  // a table of up to 256 KiB per block stays on the die for a batch that fills the device (1024 x 256 KiB = the Infinity Cache):
-  // its lines cost about half of one that goes to HBM (profiles/r06/gups2.hip)
-  static const float ondie = [] { const char* v = getenv("ZPAQ_AMD_PACK_ONDIE_WEIGHT"); return v ? (float)atof(v) : 0.5f; }();      // (A/B)
-  auto line_weight = [](uint64_t table_bytes) { return table_bytes <= (256u << 10) ? ondie : 1.0f; };
+  auto line_weight = [](uint64_t table_bytes) { return table_bytes <= (256u << 10) ? ondie_w : 1.0f; };
   const int hl = std::min(L.hcomp_lanes, G);
   const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
   // relative time per chunk of a unit wavefront inside a full launch (-m5, 1024 blocks, profiles/r05/call5: ms per 2049 chunks / 1000)
-  for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.94f);
+  for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.94f, 0.f, (float)L.nctx * ctx_l * hl / G);
   for (size_t r = 0; r < L.rows.size(); ++r)      // two finds per byte and block: two lines
-    add(1, (int)r, 0, row_unit[L.rows[r]], 0, 1.8f, 2.f * G * line_weight((uint64_t)comp[L.rows[r]].mask1 + 1u));
+    add(1, (int)r, 0, row_unit[L.rows[r]], 0, 1.8f, 2.f * G * line_weight((uint64_t)comp[L.rows[r]].mask1 + 1u), ctx_l + bh_l);
   for (size_t r = 0; r < L.light.size(); ++r) {
     const int k = L.light[r].first, i = L.light[r].second;
     static const float lc[12] = {0, 0, 0.1f, 2.5f, 3.1f, 0.3f, 1.5f, 2.5f, 1.43f, 0.45f, 0.45f, 0.78f};
@@ -390,10 +397,13 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
       else if (k == K_SSE) lines = 8.f * G * wcm;
       else if (k == K_SSE_BITS) lines = 8.f * 8 * wcm;
     }
-    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0], lines);
+    const bool bits = k >= K_CM_BITS;                                   // a quarter of the group's blocks per wavefront
+    float sl = (k == K_CODER ? p_l : p_l + ctx_l) + (k == K_MIX2 || k == K_MIX2_BITS || k == K_AVG ? 2.f * p_l : (k == K_SSE || k == K_SSE_BITS ? p_l : 0.f));
+    if (bits) sl *= 8.f * 8.f / (float)(G * 8);
+    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0], lines, sl);
   }
-  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f);
-  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 256 * G * 4 + 64 * G * 4, 1.5f);      // (packed pairs: pipe_isse_packed_unit)
+  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f, 0.f, bh_l + p_l);
+  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 256 * G * 4 + 64 * G * 4, 1.5f, 0.f, bh_l + 2.f * p_l);      // (packed pairs: pipe_isse_packed_unit)
   // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
   //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
   // throughput shape: a MIX whose 8 rows of a byte are distinct splits the byte over two lane groups (device: pipe_mix_unit NH = 2)
@@ -427,7 +437,8 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     float lines = groups_per_wave * (L.mix_bits ? 1.f : 8.f / (float)L.ps_mix_nh) * line_weight(4ull * c.stride * (c.mask0 + 1ull));
     if (L.mix_lds_rows[r]) lines *= 1.f / 8.f;
     for (int sub = 0; sub < nw; ++sub)
-      add(5, (int)r, sub, p_unit[L.mix[r]], lds, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : (lds ? 1.6f : 2.6f)), lines);
+      // (every input stream: one line per wavefront and byte, whatever part of it the wavefront's blocks are)
+      add(5, (int)r, sub, p_unit[L.mix[r]], lds, L.mix_bits ? 0.55f : (L.ps_mix_nh == 2 ? 1.7f : (lds ? 1.6f : 2.6f)), lines, (float)c.a3 + ctx_l);
   }
   // who reads whose streams
   std::vector<std::vector<int>> producers(nunit);
@@ -475,11 +486,16 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     for (int w = wpg_min; w <= total; ++w) tries.push_back(w);
   }
   // Round 6: a workgroup is a compute unit, and what paces a compute unit's wavefronts is how many memory lines they have in
-  // flight together (per-unit profile, profiles/r06 call 2: the workgroup of a group with 288 lines per byte had every
-  // wavefront at 2.5-2.8 s, those with 160 at 1.6-1.9 s, whatever the units were).  So the packing balances LINES first --
-  // units that ask for lines go, heaviest first, to the workgroup with the fewest so far -- then the units with LDS tables
-  // (no lines: maps, HCOMP, the small light tables) fill the remaining wavefront slots by LDS fit, then the rest by cost.
-  // Tried for the workgroup count the table-first packing below needs; when it does not fit, that packing stands.
+  // flight together (per-unit profile, profiles/r06 call 2: the workgroup of a group with 288 table lines per byte had every
+  // wavefront at 2.5-2.8 s, those with 160 at 1.6-1.9 s, whatever the units were; the decoder's compute units and the encoder's
+  // both run at ~90 lines per microsecond, which x 256 is the machine's random-access rate of profiles/r03/gups.hip).  So the
+  // packing balances LINES: every unit, heaviest first, goes to the workgroup with the fewest lines so far that still has a
+  // wavefront slot and the LDS for its tables (units without any line -- none once stream lines count -- would follow by LDS fit
+  // and cost).  -m5 headline: 355-367 -> 401-412 MB/s on one box
+  // (calls 6, 8).  A least-squares fit of per-unit loads from nine profiled launches with a randomised min-max search
+  // (profiles/r06/fit_packing.py; call 8) balanced its own model to 2 % and ran 5 % slower than this: what it cannot see is
+  // who shares a SIMD with whom.  Tried for the workgroup count the table-first packing below needs; when it does not fit,
+  // that packing stands.
   static const bool balance_lines = [] { const char* v = getenv("ZPAQ_AMD_PACK_LINES"); return !(v && v[0] == '0'); }();
   auto finish = [&](int wpg, int W, const std::vector<std::vector<int>>& bin_items) {
     L.ps_wpg = wpg; L.ps_waves = W;
@@ -604,7 +620,32 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   L.persist_why = "the units of a group cannot be packed into workgroups";
 }
 
+static bool pipe_layout_compute(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, std::string& why_not);
+
+// The layout of a (header, options) pair is asked for many times per batch (mode choice, buffer sizes, launch geometry):
+// computed once per process and remembered.
 bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, std::string& why_not) {
+  struct Memo { bool ok; PipeLayout L; std::string why; };
+  static std::mutex mu;
+  static std::map<std::string, Memo> memo;
+  std::string key((const char*)plan.header.data(), plan.header.size());
+  key += '|'; key += std::to_string(opt.mode); key += ','; key += std::to_string(opt.chunk); key += ','; key += std::to_string(opt.group);
+  key += ','; key += opt.persist ? '1' : '0';
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) { L = it->second.L; why_not = it->second.why; return it->second.ok; }
+  }
+  Memo m;
+  m.ok = pipe_layout_compute(plan, opt, m.L, m.why);
+  L = m.L; why_not = m.why;
+  std::lock_guard<std::mutex> g(mu);
+  if (memo.size() > 4096) memo.clear();
+  memo[key] = m;
+  return m.ok;
+}
+
+static bool pipe_layout_compute(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, std::string& why_not) {
   const PlanHeader& ph = plan.hdr();
   const int n = (int)ph.n;
   if (n < 1 || n > 64) { why_not = "more than 64 components"; return false; }
