@@ -1056,7 +1056,9 @@ def main():
                 golden["api_archives_compared"] = na
                 golden["api_archives_identical"] = not badw
                 golden["identical"] = golden["identical"] and not badw
+            L.zpq_last_persist_abort_ms.restype = C.c_double
             line["api"] = {"value": napi * bs / 1e6 / (ph[0] / 1e3) if ph[0] else None, "unit": "MB/s", "blocks": napi,
+                           "persistent_launch": bool(L.zpq_last_persistent()), "persistent_launch_given_up_after_ms": float(L.zpq_last_persist_abort_ms()),
                            "what": "zpq_compress_blocks on host buffers: SHA-1 + method expansion + header assembly, "
                                    "staging + H2D, Predictor init + coding kernels, D2H, archive framing",
                            "ms": {"library_total": ph[0], "host_front": ph[1], "device_call": ph[2], "stitch": ph[3],

@@ -119,7 +119,7 @@ def test_legacy_min_mid_max_models(gpu, golden, kernel, idx):
         gpu.set_kernel(0)
 
 
-@pytest.mark.parametrize("level,kind,nblocks,bs", [(2, "lcg", 64, 1 << 18), (3, "text", 16, 1 << 20)])
+@pytest.mark.parametrize("level,kind,nblocks,bs", [(2, "lcg", 64, 1 << 18), (3, "text", 8, 1 << 20)])
 def test_legacy_models_at_baseline_block_sizes(gpu, level, kind, nblocks, bs):
     """mid.cfg on configs[1]'s 256 KiB LCG blocks, max.cfg on configs[2]'s 1 MiB text blocks
     (Compressor::startBlock(2 | 3), libzpaq.cpp:2793-2839) -- coded through the PERSISTENT launch of the pipelined encoder,
@@ -751,6 +751,23 @@ def test_foreign_kernel_on_the_device_makes_the_persistent_launch_step_aside(gpu
         p.kill()
         p.wait()
     assert gpu.compress_blocks(blocks, "5") == want and L.zpq_last_persistent() == 1
+
+
+def test_the_librarys_own_hashing_kernel_does_not_make_the_persistent_launch_step_aside(gpu):
+    """zpq_compress_blocks hashes the blocks on the device beside the coder (sha1_blocks_kernel: a lane per block, 46 ms for
+    1 MiB blocks).  A batch that needs EVERY compute unit for its persistent launch must not find a few of them held by that
+    kernel for longer than the arrival handshake waits (round 6, call 9: the API leg of the bench fell to the step kernels,
+    267 instead of 357 MB/s): the engine waits for the hashing before the grid arrives."""
+    import ctypes as C
+    base = np.random.default_rng(5000).integers(0, 256, 1 << 20, dtype=np.uint8)
+    blocks = [np.roll(base, 977 * i) ^ np.uint8(i & 255) for i in range(1024)]         # (1024 different incompressible blocks, cheaply)
+    L = gpu.lib()
+    L.zpq_last_persist_abort_ms.restype = C.c_double
+    arch = gpu.compress_blocks(blocks, "5")
+    assert L.zpq_last_persistent() == 1 and L.zpq_last_persist_abort_ms() == 0.0, L.zpq_last_persist_abort_ms()
+    for i in (0, 511, 1023):
+        assert gpu.decompress(arch[i]) == blocks[i].tobytes()
+        assert hashlib.sha1(blocks[i].tobytes()).digest() in arch[i]          # the segment's SHA-1 trailer
 
 
 def test_measured_and_shelved_forms_stay_bit_exact(gpu, tmp_path):

@@ -873,7 +873,8 @@ static void launch_pipe(Engine& e, std::vector<PipeRun>& runs, hipStream_t st, L
 // so that each group is one launch (or one launch sequence).
 static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResult* d_res,
                        const std::vector<LaunchGroup>& groups, uint32_t nb, uint64_t max_arena, hipStream_t st,
-                       bool timed, LateInput* late = nullptr, const BlockJob* h_jobs = nullptr) {
+                       bool timed, LateInput* late = nullptr, const BlockJob* h_jobs = nullptr,
+                       const std::function<void()>* before_persist = nullptr) {
   Event ev0(true), ev1(true), ev2(true), ev3(true);
   // enough 256-thread groups per block to stream the arena at HBM rate
   uint64_t per = max_arena / (256 * 16 * 8) + 1;
@@ -975,6 +976,10 @@ static void launch_all(Engine& e, bool decode, const BlockJob* d_jobs, BlockResu
     }
     if (fits) {
       if (late && late->from_byte) HIP_CHECK(hipStreamWaitEvent(st, late->arrive(), 0));
+      // nothing of this call may hold compute units when the grid arrives (the hashing kernel beside the coder, 46 ms for 1024
+      // blocks, kept a few workgroups out for longer than the arrival handshake waits: the launch stepped aside for the
+      // library's own kernel -- round 6, call 9)
+      if (before_persist) (*before_persist)();
       bool aborted = false, untouched = false;
       std::string what;
       const auto t_launch = std::chrono::steady_clock::now();
@@ -1497,8 +1502,11 @@ void engine_code_host_on(int dev, bool decode, const std::vector<HostBlock>& blo
     Timing before = e.last;
     const auto wave_t0 = std::chrono::steady_clock::now();
     e.last_kind = groups.empty() ? 0 : groups[0].pick.kind;
+    const std::function<void()> hashing_done = [&]() {
+      if (!shj.empty()) HIP_CHECK(hipStreamWaitEvent(e.stream, sha_done, 0));        // (enqueued above, or by late.arrive() just now)
+    };
     launch_all(e, decode, (const BlockJob*)e.jobs.p, (BlockResult*)e.results.p, groups, (uint32_t)cnt, max_arena,
-               e.stream, true, split ? &late : nullptr, jobs.data());
+               e.stream, true, split ? &late : nullptr, jobs.data(), &hashing_done);
     if (split && !tail_sent) HIP_CHECK(hipStreamWaitEvent(e.stream, late.arrive(), 0));   // (no pipelined group after all)
     e.last.init_ms += before.init_ms;
     e.last.code_ms += before.code_ms;
