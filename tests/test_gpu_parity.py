@@ -369,6 +369,45 @@ def test_torch_corpus_matches_numpy(gpu):
     assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
 
 
+def test_device_resident_entry_point_timed_and_in_flight(gpu):
+    """zpq_code_device_multi on buffers already in HBM (what bench.py times), in both forms: timed = 1 waits for the results and
+    takes the persistent launch; timed = 0 returns with the work in flight on the caller's stream and runs the step kernels --
+    in the shape chosen FOR the step kernels (engine.cpp pipe_mode_for: blocks of 128 KiB and more in a small batch take the
+    2048-byte steps).  Same coded bytes either way, and the same as zpq_encode_batch's.  Own process: torch (device buffers)
+    has to initialise HIP before the library is loaded."""
+    import subprocess
+    code = (
+        "import torch, sys, ctypes as C; sys.path.insert(0, %r)\n"
+        "import numpy as np, zpaq_amd as z\nfrom zpaq_amd import corpus\n"
+        "dev = torch.device('cuda', 0)\nz.init(0)\nL = z.lib()\n"
+        "blocks = [corpus.block(['text', 'records'][i %% 2], 160000 + 37 * i, 800 + i) for i in range(48)]\n"
+        "hdrs = [z.method_to_header(z.expand_method('5', b))[0] for b in blocks]\n"
+        "plans = {}\n"
+        "for h in hdrs: plans.setdefault(h, z.Plan(h))\n"
+        "pl = [plans[h] for h in hdrs]\n"
+        "ins = [b'\\0' + b.tobytes() for b in blocks]\n"
+        "want = z.encode_batch(pl, ins)\n"
+        "n, si, so = len(ins), 163840, 208896\n"
+        "host = np.zeros((n, si), np.uint8)\n"
+        "for i, x in enumerate(ins): host[i, :len(x)] = np.frombuffer(x, np.uint8)\n"
+        "d_in = torch.from_numpy(host).to(dev)\n"
+        "L.zpq_code_device_multi.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_int]\n"
+        "PA = (C.c_void_p * n)(*[p._h for p in pl]); IO = (C.c_uint64 * n)(*[i * si for i in range(n)]); IL = (C.c_uint32 * n)(*[len(x) for x in ins])\n"
+        "OO = (C.c_uint64 * n)(*[i * so for i in range(n)]); OC = (C.c_uint32 * n)(*[so] * n)\n"
+        "for timed in (1, 0):\n"
+        "    d_out = torch.zeros((n, so), dtype=torch.uint8, device=dev); d_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)\n"
+        "    rc = L.zpq_code_device_multi(0, PA, C.c_void_p(d_in.data_ptr()), IO, IL, n, C.c_void_p(d_out.data_ptr()), OO, OC, C.c_void_p(d_res.data_ptr()), None, timed)\n"
+        "    assert rc == 0, L.zpq_last_error()\n"
+        "    torch.cuda.synchronize()\n"
+        "    res = d_res.cpu().numpy(); out = d_out.cpu().numpy()\n"
+        "    assert (res[:, 2] == 0).all()\n"
+        "    assert all(out[i, :res[i, 0]].tobytes() == want[i] for i in range(n)), timed\n"
+        "    print('FORM', timed, 'persistent', L.zpq_last_persistent() if timed else '-')\n"
+        "print('same')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "same" in r.stdout and "FORM 1 persistent 1" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_large_batch_picks_its_own_kernels(gpu, oracle):
     """More than 4 x CUs blocks in ONE call, nothing forced: compression runs on the pipelined encoder (35 groups, the
     last one ragged), decompression picks the 8-blocks-per-workgroup shape of the wavefront kernel by itself

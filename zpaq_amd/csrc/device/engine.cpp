@@ -386,21 +386,25 @@ static uint32_t persist_xcd_share(uint64_t groups, uint64_t wpg) {
   if (groups >= 8) return (uint32_t)((groups / 8) * wpg + ((groups % 8) * wpg + 7) / 8);
   return (uint32_t)((groups * wpg + 7) / 8);
 }
-static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte, const zpq_plan* plan = nullptr) {
+// persist_expected: the call will take the persistent launch if the chain can (it waits for its results: zpq_*_device with timed = 0
+// returns with the work in flight and runs the step kernels) -- the shape is chosen for the launch form that will really run
+static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32_t stream_bytes_per_byte, const zpq_plan* plan = nullptr,
+                         bool persist_expected = true) {
   bool latency = blocks_of_plan <= kLatencyModeBlocks;
+  const char* pp_env = getenv("ZPAQ_AMD_PIPE_PERSIST");
+  bool persist_off = (pp_env && !strcmp(pp_env, "0")) || !persist_expected;
   // With the persistent launch the shapes differ in how many workgroups a group of blocks needs (-m5: 14 against 8): the
   // latency shape is the faster one exactly while ALL its workgroups are resident together (measured, profiles/r05
   // call13: 512 blocks 268 MB/s against 187; beyond that -- 640 blocks: 280 workgroups -- it would need a second round,
   // which costs a whole block's serial time, and the throughput shape in one round wins: 768 blocks 264 MB/s, 1024: 350)
   {
-    const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
-    if (plan && !(pp && !strcmp(pp, "0"))) {
+    if (plan && !persist_off) {
       PipeLayout L1;
       std::string why;
       if (pipe_layout(*plan, pipe_options(1), L1, why) && L1.persist_ok) {
         const uint64_t groups = (blocks_of_plan + (uint32_t)L1.G - 1) / (uint32_t)L1.G;
         latency = groups * (uint64_t)L1.ps_wpg <= (uint64_t)g_cus_hint.load();
-      }
+      } else persist_off = true;       // (a chain that cannot be packed: the step kernels, by round 4's rule)
     }
   }
   if (const char* m = getenv("ZPAQ_AMD_PIPE_MODE")) {
@@ -409,8 +413,7 @@ static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32
   }
   if (!latency) return 0;
   // (long steps exist to spread the per-step launch cost; the persistent launch has none and takes the 512-byte shape)
-  const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
-  const bool long_steps = pp && !strcmp(pp, "0") && longest_block >= kLongStepBytes && stream_bytes_per_byte &&
+  const bool long_steps = persist_off && longest_block >= kLongStepBytes && stream_bytes_per_byte &&
                           (uint64_t)blocks_of_plan * 2048u * stream_bytes_per_byte <= kLongStepStreamBytes;
   return long_steps ? 2 : 1;
 }
@@ -1055,16 +1058,16 @@ static int kind_of_sorted(const std::vector<LaunchGroup>& groups, size_t k) {
 // kernel_kind() then finds them there.
 // blocks of the batch per plan (and the longest of them) -> the variant of its pipelined encoder
 template <class PlanOf, class LenOf>
-static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of) {
+static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of, bool persist_expected = true) {
   std::map<const zpq_plan*, std::pair<uint32_t, uint32_t>> cnt;
   for (uint32_t b : order) { auto& c = cnt[plan_of(b)]; ++c.first; c.second = std::max(c.second, (uint32_t)len_of(b)); }
   std::map<const zpq_plan*, int> mode;
-  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second, pipe_stream_bytes_per_byte(kv.first), kv.first);
+  for (auto& kv : cnt) mode[kv.first] = pipe_mode_for(kv.second.first, kv.second.second, pipe_stream_bytes_per_byte(kv.first), kv.first, persist_expected);
   // several chains in one batch share the device's workgroup slots: the persistent launches run side by side only when they
   // are resident TOGETHER, so chains go from the latency shape to the throughput shape (fewer workgroups per group), the one
   // that frees the most first, until the batch fits
   const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
-  if (cnt.size() > 1 && !(pp && !strcmp(pp, "0")) && !getenv("ZPAQ_AMD_PIPE_MODE")) {
+  if (cnt.size() > 1 && !(pp && !strcmp(pp, "0")) && persist_expected && !getenv("ZPAQ_AMD_PIPE_MODE")) {
     struct Need { const zpq_plan* p; uint64_t lat, thr; };      // what an XCD has to hold of the chain in either shape
     std::vector<Need> need;
     bool all = true;
@@ -1121,10 +1124,10 @@ static void precompile_unseen(Engine& e, bool decode, bool dense, const std::vec
 
 template <class PlanOf, class LenOf>
 static std::vector<LaunchGroup> make_groups(Engine& e, bool decode, std::vector<uint32_t>& order, PlanOf plan_of, LenOf len_of,
-                                            const std::set<const zpq_plan*>* multi_segment = nullptr) {
+                                            const std::set<const zpq_plan*>* multi_segment = nullptr, bool persist_expected = true) {
   const size_t cnt = order.size();
   const bool dense = cnt > (size_t)4 * e.cus;
-  const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of, len_of);
+  const std::map<const zpq_plan*, int> mode_of = pipe_modes(order, plan_of, len_of, persist_expected);
   precompile_unseen(e, decode, dense, order, plan_of, mode_of);
   std::vector<KernelPick> pick(cnt);
   for (size_t k = 0; k < cnt; ++k) {
@@ -1606,7 +1609,7 @@ void engine_code_device(bool decode, const zpq_plan* const* plans, bool one_plan
   // group blocks by (kernel, plan); results keep the caller's block order through res_slot
   std::vector<uint32_t> order(nblocks);
   for (uint32_t b = 0; b < nblocks; ++b) order[b] = b;
-  std::vector<LaunchGroup> groups = make_groups(e, decode, order, plan_of, [&](uint32_t b) { return in_len[b]; });
+  std::vector<LaunchGroup> groups = make_groups(e, decode, order, plan_of, [&](uint32_t b) { return in_len[b]; }, nullptr, timed);
   uint64_t pipe_need = 0;
   for (const LaunchGroup& gr : groups)
     if (gr.pick.kind == 4) pipe_need += pipe_bytes(gr.plan, gr.count, gr.pick.mode);
