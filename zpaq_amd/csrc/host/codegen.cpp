@@ -362,6 +362,9 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   // packs as well as any weighting tried (0.7 / 0.25: the same; 0.5 / 0: -5 %; 0.3 / 0.25: -10 %).
   static const float ondie_w = [] { const char* v = getenv("ZPAQ_AMD_PACK_ONDIE_WEIGHT"); return v ? (float)atof(v) : 1.0f; }();
   static const float stream_w = [] { const char* v = getenv("ZPAQ_AMD_PACK_STREAM_WEIGHT"); return v ? (float)atof(v) : 1.0f; }();
+  // MATCH: the index entry, the history behind the candidate, the byte a match predicts -- three lines per block and byte
+  // (measured against 2 and 4, profiles/r06 call 12: text 389.7 -> 395.4 MB/s, 4 MiB blocks of zeros -- MATCH's worst case -- 399 -> 431)
+  static const float match_lines = [] { const char* v = getenv("ZPAQ_AMD_PACK_MATCH_LINES"); return v ? (float)atof(v) : 3.0f; }();
   const float ctx_l = G * 4 / 128.f, bh_l = G * 8 / 128.f, p_l = G * 16 / 128.f;
   auto add = [&](int kind, int role, int sub, int unit, int lds, float cost, float lines = 0.f, float stream_lines = 0.f) {
     PipeLayout::Slot s; s.kind = kind; s.role = role; s.sub = sub; s.unit = unit; s.lds = (lds + 255) & ~255; s.cost = cost;
@@ -391,7 +394,7 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
       const float wcm = line_weight(4ull * (comp[i].mask0 + 1ull));
       if (k == K_CM) lines = 2.f * G * wcm;
       else if (k == K_CM_BITS) lines = 2.f * 8 * wcm;
-      else if (k == K_MATCH) lines = 2.f * G;
+      else if (k == K_MATCH) lines = match_lines * G;
       else if (k == K_MIX2 && comp[i].mask0 != 0u) lines = 8.f * G * wcm;
       else if (k == K_MIX2_BITS) lines = 8.f * 8 * wcm;
       else if (k == K_SSE) lines = 8.f * G * wcm;
