@@ -180,7 +180,11 @@ int zpq_decode_batch(const zpq_plan* const* plans, const uint8_t* const* in,
  * reads d_in + in_off[b] and writes d_out + out_off[b] (in_off/in_len/out_off/
  * out_cap are HOST arrays).  Per-block results land in the DEVICE array d_res.
  * `stream` is a hipStream_t (NULL = the engine's own stream).  One plan for the
- * whole batch, which must fit the state budget.  The call enqueues
+ * whole batch, which must fit the state budget.  Of block b's output region
+ * [out_off[b], out_off[b] + out_cap[b]) the first out_len bytes are the result;
+ * what the rest holds afterwards is undefined (the coder of small batches stores
+ * four bytes per coded bit and lets the next store overwrite what was not yet
+ * final), nothing outside the region is written.  The call enqueues
  * init_arena + the coding kernel on `stream`; with timed!=0 it also brackets
  * them with hipEvents on that stream, waits, and makes the durations available
  * through zpq_last_timing(). */

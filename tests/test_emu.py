@@ -391,6 +391,49 @@ def test_persistent_launch_of_the_pipelined_encoder(zlib_, oracle, golden):
     assert len(seen) >= 3
 
 
+SMALL_CHAIN_CFGS = [
+    # (config, blocks).  One ICM; ICM + ISSE on tables of 4 KiB (the ROW units stay lane-per-block: the nibbles of a byte can share
+    # a line) and of 64 KiB (a lane per nibble); two ISSEs in a row behind a CM and a MATCH.
+    "comp 1 0 0 0 1\n  0 icm 12\nhcomp\n  *d=a halt\nend\n",
+    "comp 2 0 0 0 2\n  0 icm 4\n  1 isse 4 0\nhcomp\n  b=a a=*d a<<= 4 a+=b *d=a d++ a<<= 3 a+=b *d=a halt\nend\n",
+    "comp 2 0 0 0 2\n  0 icm 10\n  1 isse 10 0\nhcomp\n  b=a a=*d a<<= 8 a+=b *d=a d++ a<<= 5 a+=b *d=a halt\nend\n",
+    "comp 2 0 0 0 4\n  0 cm 9 255\n  1 icm 9\n  2 isse 10 1\n  3 isse 11 2\nhcomp\n  b=a *d=a d++ a=*d a<<= 8 a+=b *d=a d++ a<<= 2 a+=b *d=a d++ hash *d=a halt\nend\n",
+]
+
+
+def test_small_chains_in_the_latency_shape(zlib_, oracle):
+    """Round 6: the latency shape of a chain of at most 16 unit wavefronts (configs[1]'s n = 2 is six) -- a wavefront per SIMD
+    (workgroups of 4), ISSE pairs as two words, whole squash / stretch tables in LDS, ROW units with a lane per nibble on tables of
+    8 KiB and more -- and the coder every latency-shape launch now has (pipe_coder_fast: one 4-byte store per bit, a byte coded
+    again with the reference's loop when its test fails or when less than 40 bytes of room are left).  Ragged and empty blocks,
+    zeros (every next row clashes with the row being stored), incompressible bytes (the coder emits at nearly every bit), blocks
+    against their output capacity (status 3 exactly when the reference's length does not fit, never a byte past it)."""
+    blk = corpus.block("lcg", 1 << 18, corpus.BASE_SEED)
+    h3, _, _ = zlib_.method_to_header(zlib_.expand_method("3", blk))
+    src = emu.pipe_source(h3, 64, mode=1)
+    assert "PS_CODER_FAST = true, PS_SMALL = true" in src and "PS_WAVES = 4" in src
+    assert "PS_SMALL = false" in emu.pipe_source(h3, 64, mode=0) and "PS_CODER_FAST = false" in emu.pipe_source(h3, 64, mode=0)
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65, 2000, 777])]
+    _pipe_check(oracle, h3, ragged + [b""], chunk=64, mode=1, persist=True)
+    _pipe_check(oracle, h3, [b"\0" + corpus.block(kinds[i % 5], 100 + 13 * i, i).tobytes() for i in range(70)], chunk=128, mode=1, persist=True)     # three groups
+    for cfg in SMALL_CHAIN_CFGS:
+        header, _ = zlib_.assemble(cfg)
+        assert "PS_SMALL = true" in emu.pipe_source(header, 64, mode=1)
+        _pipe_check(oracle, header, ragged, chunk=64, mode=1, persist=True)
+    # long incompressible blocks: ~2 x 10^6 coded bits, a few dozen of which fail the fast form's test
+    long_ones = [corpus.block("lcg", 8192, 100 + i).tobytes() for i in range(32)]
+    _pipe_check(oracle, h3, long_ones, chunk=512, mode=1, persist=True)
+    # output capacities around the coded length: the careful path near the end, status 3 when it does not fit
+    data = [b"\0" + corpus.block("lcg", 400, 7).tobytes(), b"\0" + corpus.block("text", 400, 8).tobytes(), b"\0" + bytes(300)]
+    want = [oracle.encode(h3, d) for d in data]
+    for cap in (8, 40, 41, len(want[1]), len(want[0]) - 1, len(want[0]), len(want[0]) + 3, len(want[0]) + 39, len(want[0]) + 41):
+        res = emu.pipe_run(h3, data, chunk=64, mode=1, persist=True, out_cap=cap)
+        for w, (coded, status, consumed) in zip(want, res):
+            assert status == (0 if len(w) <= cap else 3), (cap, len(w), status)
+            assert coded == w[:cap]
+
+
 def test_pipe_units_do_not_depend_on_lane_order(zlib_, oracle, monkeypatch):
     """Between two cross-lane operations the emulator may run the lanes of a wavefront in any order; the hardware runs them
     together.  The bit-lane units' lanes meet in memory (the positions of one block share its tables), so they must give

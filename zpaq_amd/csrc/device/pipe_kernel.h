@@ -240,6 +240,9 @@ struct PipeLane {
   __device__ __forceinline__ void put_bh(int ri, unsigned k, const uint2& v) const {
     if constexpr (WT) pipe_wt_store8(gb, off_bh(ri, k), v); else bh(ri, k) = v;
   }
+  __device__ __forceinline__ void put_bh_half(int ri, unsigned k, unsigned half, unsigned v) const {      // one nibble's four bit histories
+    if constexpr (WT) pipe_wt_store4(gb, off_bh(ri, k) + 4u * half, v); else *(g_u32*)(gb + off_bh(ri, k) + 4u * half) = v;
+  }
   __device__ __forceinline__ void put_p(int i, unsigned k, const uint4& v) const {
     if constexpr (WT) pipe_wt_store16(gb, off_p(i, k), v); else p(i, k) = v;
   }
@@ -309,6 +312,18 @@ struct PipeSquash {
     const int v = mid[min(max(i, 0), 1343)];
     return i < 0 ? 0 : (i > 1343 ? 32767 : v);
   }
+};
+
+// stretch through the whole table (64 KiB: a unit of a small chain, LDS to spare -- the compact form costs ~20 instructions a lookup)
+struct PipeStretchFull {
+  const short* t;
+  __device__ __forceinline__ int operator()(unsigned x) const { return t[x]; }   // x in 0..32767
+};
+
+// squash through the whole table (a unit with LDS to spare: no range tests around the lookup)
+struct PipeSquashFull {
+  const unsigned short* t;
+  __device__ __forceinline__ int operator()(int p) const { return t[p + 2048]; }   // p in -2048..2047
 };
 
 // Predictor::train (libzpaq.h:1151-1157)
@@ -397,15 +412,21 @@ struct PipeRow { unsigned off, w0, w1, w2, w3; };
 __device__ __forceinline__ PipeRow pipe_find(const uint4& r0, const uint4& r1, const uint4& r2, unsigned chk, unsigned h0) {
   const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
   const unsigned p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
-  const int victim = (p0 <= p1 && p0 <= p2) ? 0 : (p1 < p2 ? 1 : 2);
   const bool hit = m0 || m1 || m2;
-  const int pick = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : victim));
+  // the row taken: the first that matches, else the victim (lowest priority, the earlier of equals).  As two flags, not as an
+  // index: the compiler turned "pick == 0 ? .. : pick == 1 ? .." into a switch and the switch into ladders of exec-mask
+  // branches -- ~100 scalar and branch instructions per find, two finds per byte in every ROW unit (round 6, profiles/unit_isa.py)
+  const bool v0 = p0 <= p1 && p0 <= p2, v1 = !v0 && p1 < p2;
+  const bool t0 = m0 || (!hit && v0);
+  const bool t1 = !m0 && (m1 || (!hit && v1));
   PipeRow r;
-  r.off = h0 ^ (unsigned)(pick << 4);
-  r.w0 = hit ? (pick == 0 ? r0.x : (pick == 1 ? r1.x : r2.x)) : chk;
-  r.w1 = hit ? (pick == 0 ? r0.y : (pick == 1 ? r1.y : r2.y)) : 0u;
-  r.w2 = hit ? (pick == 0 ? r0.z : (pick == 1 ? r1.z : r2.z)) : 0u;
-  r.w3 = hit ? (pick == 0 ? r0.w : (pick == 1 ? r1.w : r2.w)) : 0u;
+  r.off = h0 ^ (t0 ? 0u : (t1 ? 16u : 32u));
+  const unsigned x = t0 ? r0.x : (t1 ? r1.x : r2.x), y = t0 ? r0.y : (t1 ? r1.y : r2.y);
+  const unsigned z = t0 ? r0.z : (t1 ? r1.z : r2.z), w = t0 ? r0.w : (t1 ? r1.w : r2.w);
+  r.w0 = hit ? x : chk;
+  r.w1 = hit ? y : 0u;
+  r.w2 = hit ? z : 0u;
+  r.w3 = hit ? w : 0u;
   return r;
 }
 
@@ -495,6 +516,55 @@ __device__ __forceinline__ void pipe_row(PipeLane<Chain>& L, const NS& ns) {
     }
     a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
     ha = han; hb = hbn;
+    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
+  }
+}
+
+// The same unit with a lane per NIBBLE (round 6; small chains in the latency shape, whose wavefronts are half empty: lane b codes
+// the first nibble of block b's bytes, lane 32 + b the second).  The encoder knows both contexts of a byte before its first bit,
+// and the two finds of a byte touch different 64-byte lines whenever the table has 8 KiB or more (their addresses differ by
+// 3 840 .. 7 680 bytes; the caller checks), so within a byte the halves do not meet; the next byte's candidates are fetched before
+// this byte's row is stored unless their line is the one either half is about to store (then behind the stores, as above).
+// Half the instruction stream per byte.
+template <class Chain, int I, class NS>
+__device__ __forceinline__ void pipe_row_halves(PipeLane<Chain>& L, const NS& ns, unsigned half) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
+  constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I];
+  static_assert(rmask + 1u >= 8192u, "the two nibbles of a byte must not share a line");
+  if (!L.nb) return;
+  auto lines = [&](unsigned hh, unsigned bytev, unsigned& mine, unsigned& other) __attribute__((always_inline)) {
+    const unsigned ha = ((hh + 16u) * 16u) & (rmask - 15u);
+    const unsigned hb = ((hh + 16u * (16u + (bytev >> 4))) * 16u) & (rmask - 15u);
+    mine = half ? hb : ha;
+    other = half ? ha : hb;
+  };
+  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
+  unsigned k1 = L.next(0);
+  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
+  unsigned hm, ho;
+  lines(h, byte, hm, ho);
+  uint4 a0 = L.A128(ht + hm), a1 = L.A128(ht + (hm ^ 16u)), a2 = L.A128(ht + (hm ^ 32u));
+  for (unsigned k = 0; k < L.nb; ++k) {
+    const unsigned k2 = min(k + 2u, L.nb - 1u);
+    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
+    unsigned hmn, hon;
+    lines(h1, byte1, hmn, hon);
+    const unsigned lmn = hmn & ~63u;
+    const bool clash = lmn == (hm & ~63u) || lmn == (ho & ~63u);
+    uint4 n0 = a0, n1 = a1, n2 = a2;
+    if (!clash) { n0 = L.A128(ht + hmn); n1 = L.A128(ht + (hmn ^ 16u)); n2 = L.A128(ht + (hmn ^ 32u)); }
+    const unsigned cx = half ? h + 16u * (16u + (byte >> 4)) : h + 16u;
+    PipeRow r = pipe_find(a0, a1, a2, (cx >> sizebits) & 255u, hm);
+    const unsigned o = pipe_row_bits(r, half ? byte & 15u : byte >> 4, ns);
+    L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
+    L.put_bh_half(ri, k, half, o);
+    if (pipe_any(clash)) {
+      pipe_stores_done();                // (the other half's store as well: another lane's)
+      if (clash) { n0 = L.A128(ht + hmn); n1 = L.A128(ht + (hmn ^ 16u)); n2 = L.A128(ht + (hmn ^ 32u)); }
+    }
+    a0 = n0; a1 = n1; a2 = n2;
+    hm = hmn; ho = hon;
     h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
 }
@@ -1433,6 +1503,126 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
   }
 }
 
+// CODER of the latency shape's persistent launch (round 6).  A chain of a few components on a batch that leaves the machine
+// empty goes at the pace of its longest per-bit instruction stream, and that was this unit's: ~50 executed instructions per bit
+// (profiles/r06_results.md section 5: a 64-bit multiply, the closed form's case analysis, the 64-bit output window, a flush test).
+// Here a bit is ~25:
+//   * p comes from a private LDS table of 4096 words that already hold (squash(p) * 2 + 1) << 16, so that
+//     (high - low) * p >> 16 is ONE v_mul_hi_u32;
+//   * y selects by mask (no compare, no VCC);
+//   * the shift-out is done for the case that covers all but ~2^-16 of the bits -- high and low differ somewhere and the
+//     low 16 bits of low are not all zero: then k = clz(high ^ low) / 8 <= 3 turns of the reference's loop leave
+//     high << 8k | ones and max(low << 8k, 1) (only the LAST of three turns can find low << 8 == 0 when bits 0 .. 15 are not
+//     all zero) -- and every bit keeps min(high ^ low, low & 0xFFFF) in an accumulator: if it is 0 after a byte's 9 codes,
+//     the lane takes the byte again from the saved state with the reference's loop (tests/cpp/coder_norm_check.c checks the
+//     fast form against the loop on every state that passes the test);
+//   * output: the 4 top bytes of high go out with ONE unaligned 4-byte store per bit at out + n, n += k.  The k bytes the
+//     loop would have emitted are the first k of them; the rest is overwritten by the next stores (a lane's stores to one
+//     address arrive in program order).  No window, no flush test.  It needs 4 bytes of room behind every byte written: a
+//     lane within 40 bytes of its capacity takes the byte the careful way (byte stores, each tested).  What lies between
+//     out_len and out_cap afterwards is undefined, as the C ABI says.
+// More stores (9 per input byte and block instead of one per 4 coded bytes, all into one or two lines that stay in the L2), which is
+// why the throughput shape -- a machine paced by its memory lines -- keeps pipe_coder.
+// pt: 4096 words of LDS owned by this wavefront; load_tab: fill it (first chunk).
+template <class Chain>
+__device__ __forceinline__ void pipe_coder_fast(PipeLane<Chain>& L, const PipeArgs& a, unsigned* pt, int lane, bool load_tab) {
+  constexpr int sw = Chain::CODER_STATE;
+  if (load_tab) {
+    for (int i = lane; i < 4096; i += 64) pt[i] = (((unsigned)a.tb->squash[i] * 2u) + 1u) << 16;
+    (void)pipe_any(true);          // (every lane reads what every lane wrote: the lanes meet here -- the emulator runs them one by one)
+  }
+  const unsigned nchunks = max((L.len + (unsigned)Chain::PIPE_C - 1u) / (unsigned)Chain::PIPE_C, 1u);
+  const bool active = L.live && L.chunk >= 0 && (unsigned)L.chunk < nchunks;
+  if (!active) return;
+  unsigned low = 1, high = 0xFFFFFFFFu, n = 0;
+  unsigned seg = 0, seg_end = 0xFFFFFFFFu;
+  const bool multi = L.nseg > 1;
+  if (L.chunk > 0) { low = L.state(sw + 0); high = L.state(sw + 1); n = L.state(sw + 2); seg = L.state(sw + 3); }
+  typedef __attribute__((address_space(1))) SegRange g_seg;
+  g_seg* const segs = (g_seg*)L.segs;
+  if (multi) seg_end = segs[seg].in_end;
+  typedef unsigned __attribute__((aligned(1))) u32u;
+  typedef __attribute__((address_space(1))) u32u g_u32u;
+  // Encoder::encode (libzpaq.cpp:2402-2416) as the reference writes it; p16 = the 16-bit probability
+  auto encode_loop = [&](int y, unsigned p16) __attribute__((always_inline)) {
+    const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * p16) >> 16);
+    if (y) high = mid; else low = mid + 1u;
+    while (((high ^ low) & 0xFF000000u) == 0u) {
+      if (n < L.out_cap) L.out[n] = (unsigned char)(high >> 24);
+      ++n;
+      high = high << 8 | 255u;
+      low <<= 8;
+      low += (low == 0u);
+    }
+  };
+  unsigned acc = 0xFFFFFFFFu;
+  // the common case of the same (see above); P = p16 << 16, ym = 0 - y
+  auto shift_out = [&](unsigned high1, unsigned low1) __attribute__((always_inline)) {
+    const unsigned x = high1 ^ low1;
+    acc = min(acc, min(x, low1 & 0xFFFFu));
+    const unsigned sh = (unsigned)__builtin_clz(x | 1u) & 24u;
+    *(g_u32u*)(L.out + n) = __builtin_bswap32(high1);
+    n += sh >> 3;
+    high = (high1 << sh) | ((1u << sh) - 1u);
+    low = max(low1 << sh, 1u);
+  };
+  auto encode_fast = [&](unsigned ym, unsigned P) __attribute__((always_inline)) {
+    const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * P) >> 32);
+    shift_out((mid & ym) | (high & ~ym), (low & ym) | ((mid + 1u) & ~ym));
+  };
+  if (L.nb) {
+    unsigned byte = L.byte_at(0);
+    uint4 v = L.p(Chain::N - 1, 0);
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint4 vn = L.p(Chain::N - 1, kn);
+      if (multi) {
+        while (seg + 1 < L.nseg && L.k0 + k == seg_end) {      // (empty segments: several boundaries at one byte)
+          encode_loop(1, 0);
+          segs[seg].out_end = n;
+          ++seg;
+          seg_end = segs[seg].in_end;
+        }
+      }
+      unsigned P[8];
+#pragma unroll
+      for (int B = 0; B < 8; ++B) P[B] = pt[(unsigned)(sp_clamp2k(pipe_p_get(v, B)) + 2048)];
+      const unsigned low0 = low, high0 = high, n0 = n;
+      bool again = n + 40u > L.out_cap;
+      if (!again) {
+        acc = 0xFFFFFFFFu;
+        shift_out(high, low + 1u);                               // encode(0, 0): mid = low
+#pragma unroll
+        for (int B = 0; B < 8; ++B) encode_fast(0u - (unsigned)pipe_y(byte, B), P[B]);
+        again = acc == 0u;
+      }
+      if (pipe_any(again)) {
+        if (again) {
+          low = low0; high = high0; n = n0;
+          encode_loop(0, 0);
+          for (int B = 0; B < 8; ++B) encode_loop(pipe_y(byte, B), P[B] >> 16);
+        }
+      }
+      byte = byten; v = vn;
+    }
+  }
+  if ((unsigned)L.chunk == nchunks - 1u) {
+    int status = (int)(unsigned)L.state(Chain::HCOMP_STATE + 4);
+    if (multi && !status) {
+      while (seg + 1 < L.nseg) { encode_loop(1, 0); segs[seg].out_end = n; ++seg; }     // trailing empty segments
+    }
+    if (!status) encode_loop(1, 0);
+    if (multi) segs[seg].out_end = n;
+    if (!status && n > L.out_cap) status = 3;
+    BlockResult r;
+    r.out_len = n; r.consumed = L.len; r.status = status; r.steps = 8u * L.len;
+    a.res[L.rslot] = r;
+  } else {
+    L.state(sw + 0) = low; L.state(sw + 1) = high; L.state(sw + 2) = n; L.state(sw + 3) = seg;
+  }
+}
+
 // =====================================================================================================
 // Rows kernel: the ROW unit of every ICM / ISSE (1 KB of LDS: the state table).  One wavefront per (unit, group).
 template <class Chain>
@@ -1542,8 +1732,8 @@ __device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return 
 // LDS round trip is off the lane's serial chain.
 // one chunk of the ICM map of component I; tab = [256][G] words of LDS; load_tab / store_tab: the side table is staged from /
 // written back to the arena around this chunk (the persistent launch keeps it in LDS from chunk to chunk)
-template <class Chain, int I>
-__device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab, const PipeStretch& stretch, int lane, bool load_tab, bool store_tab) {
+template <class Chain, int I, class ST>
+__device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab, const ST& stretch, int lane, bool load_tab, bool store_tab) {
   constexpr unsigned G = Chain::PIPE_G;
   constexpr CompK c = Chain::comp[I];
   constexpr int ri = Chain::P_ROW[I];

@@ -85,6 +85,18 @@ __device__ __forceinline__ constexpr unsigned pipe_light_lds_words(int lk, int I
   return 0u;
 }
 
+// what host/codegen.cpp plan_persistent decided for the chain (absent in older generated sources: off)
+template <class Chain, class = void> struct PipeCoderFast { static constexpr bool value = false; };
+template <class Chain> struct PipeCoderFast<Chain, decltype((void)Chain::PS_CODER_FAST)> { static constexpr bool value = Chain::PS_CODER_FAST; };
+template <class Chain, class = void> struct PipeSmallChain { static constexpr bool value = false; };
+template <class Chain> struct PipeSmallChain<Chain, decltype((void)Chain::PS_SMALL)> { static constexpr bool value = Chain::PS_SMALL; };
+
+// ROW unit `role` with a lane per nibble (pipe_row_halves): small chains, groups of 32 blocks, tables of 8 KiB or more
+template <class Chain>
+__device__ __forceinline__ constexpr bool pipe_row_in_halves(int role) {
+  return PipeSmallChain<Chain>::value && Chain::PIPE_G == 32u && Chain::comp[Chain::ROW_COMP[role]].mask1 + 1u >= 8192u;
+}
+
 // a pointer every lane holds the same value of, as a value the compiler knows to be wave-uniform (function arguments and
 // what is loaded through them arrive in vector registers; a buffer descriptor built from one would be waterfalled)
 template <class T>
@@ -202,6 +214,8 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     B = (unsigned)lane & 7u;
     const unsigned gl = (unsigned)sub * 8u + ((unsigned)lane >> 3);
     L.bind(a, g, gl < G ? gl : 0u, gl < G);
+  } else if constexpr (kind == 1 && pipe_row_in_halves<Chain>(role < 0 ? 0 : role)) {
+    L.bind(a, g, (unsigned)lane & 31u, true);                       // lanes b and 32 + b: the two nibbles of block b's bytes
   } else {
     const bool okl = (unsigned)lane < G;
     L.bind(a, g, okl ? (unsigned)lane : 0u, okl);
@@ -220,11 +234,31 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     if constexpr (kind == 0) {
       pipe_hcomp_unit<Chain>(L, (unsigned*)priv, lane, c == 0, false);
     } else if constexpr (kind == 1) {
-      if (pipe_any(L.nb > 0)) pipe_row<Chain, Chain::ROW_COMP[role]>(L, ro.ns);
+      if constexpr (pipe_row_in_halves<Chain>(role)) { if (pipe_any(L.nb > 0)) pipe_row_halves<Chain, Chain::ROW_COMP[role]>(L, ro.ns, (unsigned)lane >> 5); }
+      else if (pipe_any(L.nb > 0)) pipe_row<Chain, Chain::ROW_COMP[role]>(L, ro.ns);
     } else if constexpr (kind == 3) {
-      if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
+      if constexpr (PipeSmallChain<Chain>::value) {
+        short* const st = (short*)(priv + 256u * G * 4u);          // the whole stretch table behind the side table
+        if (c == 0) {
+          for (int i = lane; i < 16384; i += 64) ((unsigned*)st)[i] = ((const unsigned*)a.tb->stretch)[i];
+          (void)pipe_any(true);    // (a table every lane reads: the lanes meet here)
+        }
+        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, PipeStretchFull{st}, lane, c == 0, false);
+      } else {
+        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
+      }
     } else if constexpr (kind == 4) {
-      if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0);
+      if constexpr (PipeSmallChain<Chain>::value) {
+        // a chain of a few units (PS_SMALL): LDS to spare, so the weight pairs stay as two words and squash is the whole table
+        unsigned short* const sq = (unsigned short*)(priv + 512u * G * 4u);
+        if (c == 0) {
+          for (int i = lane; i < 4096; i += 64) sq[i] = a.tb->squash[i];
+          (void)pipe_any(true);    // (a table every lane reads: the lanes meet here)
+        }
+        if (pipe_any(L.nb > 0)) pipe_isse_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, PipeSquashFull{sq}, lane, c == 0, false);
+      } else {
+        if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0);
+      }
     } else if constexpr (kind == 5) {
       if (pipe_any(L.nb > 0)) {
         if constexpr (Chain::MIX_BITS != 0) pipe_mix_bits_unit<Chain, role>(L, q, B, ro.squash);
@@ -237,7 +271,8 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     } else {
       constexpr int lk = Chain::LIGHT_KIND[role], I = Chain::LIGHT_COMP[role];
       if constexpr (lk == PK_CODER) {
-        pipe_coder<Chain>(L, a, ro.squash);
+        if constexpr (PipeCoderFast<Chain>::value) pipe_coder_fast<Chain>(L, a, (unsigned*)priv, lane, c == 0);
+        else pipe_coder<Chain>(L, a, ro.squash);
       } else if (pipe_any(L.nb > 0)) {
         if constexpr (lk == PK_CONS) pipe_cons<Chain, I>(L);
         else if constexpr (lk == PK_CM) {

@@ -372,6 +372,20 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     slots.push_back(s); ++unit_waves[unit];
   };
   auto line_weight = [](uint64_t table_bytes) { return table_bytes <= (256u << 10) ? ondie_w : 1.0f; };
+  // Latency shape (round 6, profiles/r06_results.md section 5): a launch that leaves the machine empty goes at the pace of its
+  // longest per-bit instruction stream.  Its coder stores once per bit instead of keeping a window (pipe_coder_fast), and a
+  // chain of a few units (configs[1]'s n = 2: six wavefronts per group) gets a SIMD per wavefront -- two workgroups of 4 instead
+  // of one of 6, where the ROW units shared their SIMDs with the ICM map and HCOMP -- and, with LDS to spare, unpacked ISSE
+  // pairs and whole squash tables.
+  static const bool fast_off = [] { const char* v = getenv("ZPAQ_AMD_CODER_FAST"); return v && v[0] == '0'; }();
+  static const bool small_off = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN"); return v && v[0] == '0'; }();
+  L.ps_coder_fast = L.mode == 1 && !fast_off;
+  {
+    int waves = std::max(1, G / std::min(L.hcomp_lanes, G)) + (int)L.rows.size() + (int)L.light.size() + (int)L.icm.size() + (int)L.isse.size();
+    for (size_t r = 0; r < L.mix.size(); ++r) waves += L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
+    L.ps_small = L.mode == 1 && !small_off && waves <= 16;
+  }
+  const bool small = L.ps_small;
   const int hl = std::min(L.hcomp_lanes, G);
   const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
   // relative time per chunk of a unit wavefront inside a full launch (-m5, 1024 blocks, profiles/r05/call5: ms per 2049 chunks / 1000)
@@ -403,10 +417,13 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     const bool bits = k >= K_CM_BITS;                                   // a quarter of the group's blocks per wavefront
     float sl = (k == K_CODER ? p_l : p_l + ctx_l) + (k == K_MIX2 || k == K_MIX2_BITS || k == K_AVG ? 2.f * p_l : (k == K_SSE || k == K_SSE_BITS ? p_l : 0.f));
     if (bits) sl *= 8.f * 8.f / (float)(G * 8);
-    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds ? 0.9f : lc[k < 12 ? k : 0], lines, sl);
+    if (k == K_CODER && L.ps_coder_fast) lds = 4096 * 4;                 // (its table of probabilities: pipe_coder_fast)
+    add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds && k != K_CODER ? 0.9f : lc[k < 12 ? k : 0], lines, sl);
   }
-  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4, 1.1f, 0.f, bh_l + p_l);
-  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], 256 * G * 4 + 64 * G * 4, 1.5f, 0.f, bh_l + 2.f * p_l);      // (packed pairs: pipe_isse_packed_unit)
+  // (a small chain: the whole stretch table behind the ICM's side table, device PipeStretchFull)
+  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4 + (small ? 65536 : 0), 1.1f, 0.f, bh_l + p_l);
+  // (packed pairs: pipe_isse_packed_unit; a small chain: two words per pair and the whole squash table, pipe_isse_unit)
+  for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], small ? 512 * G * 4 + 8192 : 256 * G * 4 + 64 * G * 4, 1.5f, 0.f, bh_l + 2.f * p_l);
   // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
   //  64 / QL blocks per wavefront, not the G / QL of the step kernels' G-thread workgroups)
   // throughput shape: a MIX whose 8 rows of a byte are distinct splits the byte over two lane groups (device: pipe_mix_unit NH = 2)
@@ -481,7 +498,8 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   // 7 x 32 = 224 workgroups); otherwise the fewest that hold the units.  The tables go first (largest first, each into the
   // bin it fits best -- tried emptiest-first as well), then the units without tables to the bin with the least work.
   static const int wpg_floor = [] { const char* v = getenv("ZPAQ_AMD_PERSIST_WPG_MIN"); return v ? atoi(v) : -1; }();      // (experiments)
-  const int wpg_min = (total + 7) / 8;
+  const int Wmax = small ? 4 : 8;
+  const int wpg_min = (total + Wmax - 1) / Wmax;
   std::vector<int> tries;
   if (wpg_floor >= 0) { for (int w = std::max(wpg_min, std::min(wpg_floor, total)); w <= total; ++w) tries.push_back(w); }
   else {
@@ -585,7 +603,7 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   for (size_t ti = 0; ti < tries.size() * 2; ++ti) {
     const int wpg = tries[ti / 2];
     const bool best_fit = (ti & 1) == 1;          // (spread the tables when that works: the units that own them are LDS-bound together)
-    const int W = std::min(8, total);
+    const int W = std::min(Wmax, total);
     struct Bin { std::vector<int> s; int lds = 0; float cost = 0; };
     std::vector<Bin> bins(wpg);
     std::vector<int> order(total);
@@ -866,6 +884,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     o << "struct ChainP : Chain {\n"
          "  static constexpr bool PIPE_PERSIST = true;\n"
          "  static constexpr int PS_MIX_NH = " << L.ps_mix_nh << ";\n"
+         "  static constexpr bool PS_CODER_FAST = " << (L.ps_coder_fast ? "true" : "false") << ", PS_SMALL = " << (L.ps_small ? "true" : "false") << ";\n"
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
       << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";
     arr("PS_KIND", kind.data(), (int)kind.size());
