@@ -367,18 +367,24 @@ __device__ __forceinline__ void pipe_hcomp_unit(PipeLane<Chain>& L, unsigned* Hs
   unsigned ch = L.nb ? L.byte_at(0) : 0u;
   for (unsigned k = 0; k < L.nb; ++k) {
     const unsigned chn = L.byte_at(L.next(k));
-    // contexts of byte k = H as left by the bytes before it (Predictor::update0, libzpaq.cpp:2049-2054)
+    // contexts of byte k = H as left by the bytes before it (Predictor::update0, libzpaq.cpp:2049-2054): read before the
+    // program runs, stored BEHIND it -- the stream stores are written through and vmcnt counts in order, so a load of the
+    // program (its M array lives in the arena) issued behind them would wait for their acknowledgements (round 6, profiles/r06
+    // call 16: mid.cfg's HCOMP unit set the pace of its launch at 2.1 us per byte)
+    unsigned hv[Chain::PIPE_NCTX];
     static_for<0, Chain::N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       if constexpr (Chain::P_CTX[i] >= 0) {
-        unsigned hv;
-        if constexpr (HLDS) hv = Hl[(unsigned)i & Chain::HMASK]; else hv = Hg[(unsigned)i & Chain::HMASK];
-        L.put_ctx(Chain::P_CTX[i], k, hv);
+        if constexpr (HLDS) hv[Chain::P_CTX[i]] = Hl[(unsigned)i & Chain::HMASK]; else hv[Chain::P_CTX[i]] = Hg[(unsigned)i & Chain::HMASK];
       }
     });
     int e;
     if constexpr (HLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hl, vm_R);
     else e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hg, vm_R);
+    static_for<0, Chain::N>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (Chain::P_CTX[i] >= 0) L.put_ctx(Chain::P_CTX[i], k, hv[Chain::P_CTX[i]]);
+    });
     if (e) { st = (unsigned)e; break; }
     ch = chn;
   }
@@ -533,39 +539,65 @@ __device__ __forceinline__ void pipe_row_halves(PipeLane<Chain>& L, const NS& ns
   constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I];
   static_assert(rmask + 1u >= 8192u, "the two nibbles of a byte must not share a line");
   if (!L.nb) return;
+  // the lines of a byte's two finds: this lane's and the other half's
   auto lines = [&](unsigned hh, unsigned bytev, unsigned& mine, unsigned& other) __attribute__((always_inline)) {
     const unsigned ha = ((hh + 16u) * 16u) & (rmask - 15u);
     const unsigned hb = ((hh + 16u * (16u + (bytev >> 4))) * 16u) & (rmask - 15u);
     mine = half ? hb : ha;
     other = half ? ha : hb;
   };
-  unsigned h = L.ctx(ci, 0), byte = L.byte_at(0);
-  unsigned k1 = L.next(0);
-  unsigned h1 = L.ctx(ci, k1), byte1 = L.byte_at(k1);
-  unsigned hm, ho;
-  lines(h, byte, hm, ho);
-  uint4 a0 = L.A128(ht + hm), a1 = L.A128(ht + (hm ^ 16u)), a2 = L.A128(ht + (hm ^ 32u));
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned k2 = min(k + 2u, L.nb - 1u);
-    const unsigned h2 = L.ctx(ci, k2), byte2 = L.byte_at(k2);
-    unsigned hmn, hon;
-    lines(h1, byte1, hmn, hon);
-    const unsigned lmn = hmn & ~63u;
-    const bool clash = lmn == (hm & ~63u) || lmn == (ho & ~63u);
-    uint4 n0 = a0, n1 = a1, n2 = a2;
-    if (!clash) { n0 = L.A128(ht + hmn); n1 = L.A128(ht + (hmn ^ 16u)); n2 = L.A128(ht + (hmn ^ 32u)); }
-    const unsigned cx = half ? h + 16u * (16u + (byte >> 4)) : h + 16u;
-    PipeRow r = pipe_find(a0, a1, a2, (cx >> sizebits) & 255u, hm);
-    const unsigned o = pipe_row_bits(r, half ? byte & 15u : byte >> 4, ns);
-    L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
-    L.put_bh_half(ri, k, half, o);
-    if (pipe_any(clash)) {
-      pipe_stores_done();                // (the other half's store as well: another lane's)
-      if (clash) { n0 = L.A128(ht + hmn); n1 = L.A128(ht + (hmn ^ 16u)); n2 = L.A128(ht + (hmn ^ 32u)); }
+  auto same_line = [](unsigned x, unsigned y) __attribute__((always_inline)) { return ((x ^ y) & ~63u) == 0u; };
+  // The table runs TWO bytes ahead, the streams four: a lone wavefront on an empty machine waits for every row it asks for, and
+  // one byte of lead left a byte's work to cover a trip to HBM.  Everything a byte needs lives in one of four SLOTS (byte k in
+  // slot k mod 4), the loop is unrolled four times and every slot is a fixed set of registers: a value handed from register to
+  // register would have to be waited for on the spot, which is the lead gone.  The rows of byte k + 2 are asked for when byte k
+  // is done; if their line is one that byte k or k + 1 stores into (either half's), they are asked for AGAIN behind byte k + 1's
+  // store.  No lane leaves the loop early (the compiler's vmcnt bookkeeping gives up at a divergent branch): a lane whose block
+  // ends inside the chunk goes on over its last byte's elements -- its tables and stream positions are dead by then, and a
+  // chunk's length is a multiple of 4, so a block that goes on never overruns.
+  static_assert(Chain::PIPE_C % 4 == 0, "ring of four slots");
+  const unsigned last = L.nb - 1u;
+  unsigned hq[4], byq[4], hmq[4], hoq[4];
+  uint4 r0[4], r1[4], r2[4];
+  bool late[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const unsigned kd = min((unsigned)sl, last);
+    hq[sl] = L.ctx(ci, kd); byq[sl] = L.byte_at(kd);
+    late[sl] = false;
+  }
+  lines(hq[0], byq[0], hmq[0], hoq[0]);
+  lines(hq[1], byq[1], hmq[1], hoq[1]);
+  hmq[2] = hmq[3] = hmq[1]; hoq[2] = hoq[3] = hoq[1];
+  r0[0] = L.A128(ht + hmq[0]); r1[0] = L.A128(ht + (hmq[0] ^ 16u)); r2[0] = L.A128(ht + (hmq[0] ^ 32u));
+  late[1] = same_line(hmq[1], hmq[0]) || same_line(hmq[1], hoq[0]);         // byte 1's rows: again behind byte 0's store?
+  r0[1] = L.A128(ht + hmq[1]); r1[1] = L.A128(ht + (hmq[1] ^ 16u)); r2[1] = L.A128(ht + (hmq[1] ^ 32u));
+  r0[2] = r0[3] = r0[0]; r1[2] = r1[3] = r1[0]; r2[2] = r2[3] = r2[0];
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += 4u) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int s1 = (sl + 1) % 4, s2 = (sl + 2) % 4;
+      const unsigned k = kb + (unsigned)sl;
+      // byte k: find, the nibble's four bits, the row back, the bit histories out
+      const unsigned h = hq[sl], byte = byq[sl], hm = hmq[sl];
+      const unsigned cx = half ? h + 16u * (16u + (byte >> 4)) : h + 16u;
+      PipeRow r = pipe_find(r0[sl], r1[sl], r2[sl], (cx >> sizebits) & 255u, hm);
+      const unsigned o = pipe_row_bits(r, half ? byte & 15u : byte >> 4, ns);
+      L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
+      L.put_bh_half(ri, k, half, o);
+      // byte k + 1's rows again, if their line was one this byte or the one before stored into (the other half's store as well)
+      if (pipe_any(late[s1])) {
+        pipe_stores_done();
+        if (late[s1]) { r0[s1] = L.A128(ht + hmq[s1]); r1[s1] = L.A128(ht + (hmq[s1] ^ 16u)); r2[s1] = L.A128(ht + (hmq[s1] ^ 32u)); }
+      }
+      // byte k + 2: its lines from the stream elements asked for two bytes ago, its rows now
+      lines(hq[s2], byq[s2], hmq[s2], hoq[s2]);
+      late[s2] = same_line(hmq[s2], hm) || same_line(hmq[s2], hoq[sl]) || same_line(hmq[s2], hmq[s1]) || same_line(hmq[s2], hoq[s1]);
+      r0[s2] = L.A128(ht + hmq[s2]); r1[s2] = L.A128(ht + (hmq[s2] ^ 16u)); r2[s2] = L.A128(ht + (hmq[s2] ^ 32u));
+      // byte k + 4's stream elements into the slot byte k leaves
+      const unsigned k4 = min(k + 4u, last);
+      hq[sl] = L.ctx(ci, k4); byq[sl] = L.byte_at(k4);
     }
-    a0 = n0; a1 = n1; a2 = n2;
-    hm = hmn; ho = hon;
-    h = h1; byte = byte1; h1 = h2; byte1 = byte2;
   }
 }
 
@@ -1506,25 +1538,25 @@ __device__ __forceinline__ void pipe_coder(PipeLane<Chain>& L, const PipeArgs& a
 // CODER of the latency shape's persistent launch (round 6).  A chain of a few components on a batch that leaves the machine
 // empty goes at the pace of its longest per-bit instruction stream, and that was this unit's: ~50 executed instructions per bit
 // (profiles/r06_results.md section 5: a 64-bit multiply, the closed form's case analysis, the 64-bit output window, a flush test).
-// Here a bit is ~25:
+// Here a bit is ~27:
 //   * p comes from a private LDS table of 4096 words that already hold (squash(p) * 2 + 1) << 16, so that
 //     (high - low) * p >> 16 is ONE v_mul_hi_u32;
-//   * y selects by mask (no compare, no VCC);
 //   * the shift-out is done for the case that covers all but ~2^-16 of the bits -- high and low differ somewhere and the
 //     low 16 bits of low are not all zero: then k = clz(high ^ low) / 8 <= 3 turns of the reference's loop leave
 //     high << 8k | ones and max(low << 8k, 1) (only the LAST of three turns can find low << 8 == 0 when bits 0 .. 15 are not
 //     all zero) -- and every bit keeps min(high ^ low, low & 0xFFFF) in an accumulator: if it is 0 after a byte's 9 codes,
 //     the lane takes the byte again from the saved state with the reference's loop (tests/cpp/coder_norm_check.c checks the
 //     fast form against the loop on every state that passes the test);
-//   * output: the 4 top bytes of high go out with ONE unaligned 4-byte store per bit at out + n, n += k.  The k bytes the
-//     loop would have emitted are the first k of them; the rest is overwritten by the next stores (a lane's stores to one
-//     address arrive in program order).  No window, no flush test.  It needs 4 bytes of room behind every byte written: a
-//     lane within 40 bytes of its capacity takes the byte the careful way (byte stores, each tested).  What lies between
-//     out_len and out_cap afterwards is undefined, as the C ABI says.
-// More stores (9 per input byte and block instead of one per 4 coded bytes, all into one or two lines that stay in the L2), which is
-// why the throughput shape -- a machine paced by its memory lines -- keeps pipe_coder.
-// pt: 4096 words of LDS owned by this wavefront; load_tab: fill it (first chunk).
-template <class Chain>
+//   * output: the coded bytes of ONE input byte collect in a 32-bit window (window << 8k | top k bytes of high: no test) and
+//     leave with ONE unaligned 4-byte store per input byte; the bytes of the store that are not yet final are overwritten by
+//     the next (a lane's stores to one address arrive in program order).  A byte that codes into more than 4 bytes (a model
+//     badly wrong nine times in a row) takes the careful way as well, and so does a lane within 40 bytes of its capacity
+//     (byte stores, each tested).  What lies between out_len and out_cap afterwards is undefined, as the C ABI says.
+//     (The first version stored the 4 top bytes of high once per BIT: the fastest coder alone, 386 -> 271 ms on configs[1], but
+//     9 partial stores per input byte and block into one line slowed every other unit of the launch -- mid.cfg 110 -> 92 MB/s,
+//     -m5 on 256 blocks 142 -> 106; profiles/r06 calls 15, 16.)
+// pt: 4096 words of LDS owned by this wavefront; load_tab: fill it (first chunk).  PD: how many bytes ahead the stream is read.
+template <class Chain, int PD>
 __device__ __forceinline__ void pipe_coder_fast(PipeLane<Chain>& L, const PipeArgs& a, unsigned* pt, int lane, bool load_tab) {
   constexpr int sw = Chain::CODER_STATE;
   if (load_tab) {
@@ -1555,56 +1587,78 @@ __device__ __forceinline__ void pipe_coder_fast(PipeLane<Chain>& L, const PipeAr
       low += (low == 0u);
     }
   };
-  unsigned acc = 0xFFFFFFFFu;
-  // the common case of the same (see above); P = p16 << 16, ym = 0 - y
+  unsigned acc = 0xFFFFFFFFu, ob = 0u;
+  // the common case of the same (see above)
   auto shift_out = [&](unsigned high1, unsigned low1) __attribute__((always_inline)) {
     const unsigned x = high1 ^ low1;
     acc = min(acc, min(x, low1 & 0xFFFFu));
     const unsigned sh = (unsigned)__builtin_clz(x | 1u) & 24u;
-    *(g_u32u*)(L.out + n) = __builtin_bswap32(high1);
+#ifdef ZPQ_EMU
+    const unsigned top = sh ? high1 >> (32u - sh) : 0u;
+#else
+    const unsigned top = __builtin_amdgcn_ubfe(high1, 0u - sh, sh);      // (offset 32 - sh mod 32, width sh: 0 when sh = 0)
+#endif
+    ob = (ob << sh) | top;
     n += sh >> 3;
     high = (high1 << sh) | ((1u << sh) - 1u);
     low = max(low1 << sh, 1u);
   };
-  auto encode_fast = [&](unsigned ym, unsigned P) __attribute__((always_inline)) {
+  auto encode_fast = [&](bool y, unsigned P) __attribute__((always_inline)) {            // P = p16 << 16
     const unsigned mid = low + (unsigned)(((unsigned long long)(high - low) * P) >> 32);
-    shift_out((mid & ym) | (high & ~ym), (low & ym) | ((mid + 1u) & ~ym));
+    shift_out(y ? mid : high, y ? low : mid + 1u);
   };
   if (L.nb) {
-    unsigned byte = L.byte_at(0);
-    uint4 v = L.p(Chain::N - 1, 0);
-    for (unsigned k = 0; k < L.nb; ++k) {
-      const unsigned kn = L.next(k);
-      const unsigned byten = L.byte_at(kn);
-      const uint4 vn = L.p(Chain::N - 1, kn);
-      if (multi) {
-        while (seg + 1 < L.nseg && L.k0 + k == seg_end) {      // (empty segments: several boundaries at one byte)
-          encode_loop(1, 0);
-          segs[seg].out_end = n;
-          ++seg;
-          seg_end = segs[seg].in_end;
+    const unsigned last = L.nb - 1u;
+    constexpr int U = PD + 1;            // (ring of U slots, byte k in slot k mod U, unrolled U times: see pipe_icm_unit)
+    static_assert(Chain::PIPE_C % U == 0, "ring of U slots");
+    unsigned bq[U];
+    uint4 vq[U];
+#pragma unroll
+    for (int sl = 0; sl < U; ++sl) { const unsigned kd = min((unsigned)sl, last); bq[sl] = L.byte_at(kd); vq[sl] = L.p(Chain::N - 1, kd); }
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)U) {
+#pragma unroll
+      for (int sl = 0; sl < U; ++sl) {
+        const unsigned k = kb + (unsigned)sl;
+        {
+          // (no lane leaves the loop early: see pipe_icm_unit.  A lane past its last byte codes nothing: it takes neither way)
+          const bool on = k < L.nb;
+          const unsigned byte = bq[sl];
+          const uint4 v = vq[sl];
+          if (multi && on) {
+            while (seg + 1 < L.nseg && L.k0 + k == seg_end) {      // (empty segments: several boundaries at one byte)
+              encode_loop(1, 0);
+              segs[seg].out_end = n;
+              ++seg;
+              seg_end = segs[seg].in_end;
+            }
+          }
+          unsigned P[8];
+#pragma unroll
+          for (int B = 0; B < 8; ++B) P[B] = pt[(unsigned)(sp_clamp2k(pipe_p_get(v, B)) + 2048)];
+          bool yb[8];                        // (the byte's bits as lane masks, all eight before the first is used)
+#pragma unroll
+          for (int B = 0; B < 8; ++B) yb[B] = pipe_y(byte, B) != 0;
+          const unsigned low0 = low, high0 = high, n0 = n;
+          const bool room = n + 40u <= L.out_cap;
+          acc = 0xFFFFFFFFu;
+          ob = 0u;
+          shift_out(high, low + 1u);                               // encode(0, 0): mid = low
+#pragma unroll
+          for (int B = 0; B < 8; ++B) encode_fast(yb[B], P[B]);
+          const unsigned cnt = n - n0;                             // coded bytes of this input byte: the low cnt bytes of ob, the oldest on top
+          const bool fine = room && acc != 0u && cnt <= 4u;
+          if (fine && on) *(g_u32u*)(L.out + n0) = __builtin_bswap32(ob << ((32u - 8u * cnt) & 31u));     // (cnt = 0: four bytes the next store overwrites)
+          if (!(fine && on)) { low = low0; high = high0; n = n0; }
+          if (pipe_any(on && !fine)) {
+            if (on && !fine) {
+              encode_loop(0, 0);
+              for (int B = 0; B < 8; ++B) encode_loop(pipe_y(byte, B), P[B] >> 16);
+            }
+          }
+          const unsigned kf = min(k + (unsigned)U, last);
+          bq[sl] = L.byte_at(kf); vq[sl] = L.p(Chain::N - 1, kf);
         }
       }
-      unsigned P[8];
-#pragma unroll
-      for (int B = 0; B < 8; ++B) P[B] = pt[(unsigned)(sp_clamp2k(pipe_p_get(v, B)) + 2048)];
-      const unsigned low0 = low, high0 = high, n0 = n;
-      bool again = n + 40u > L.out_cap;
-      if (!again) {
-        acc = 0xFFFFFFFFu;
-        shift_out(high, low + 1u);                               // encode(0, 0): mid = low
-#pragma unroll
-        for (int B = 0; B < 8; ++B) encode_fast(0u - (unsigned)pipe_y(byte, B), P[B]);
-        again = acc == 0u;
-      }
-      if (pipe_any(again)) {
-        if (again) {
-          low = low0; high = high0; n = n0;
-          encode_loop(0, 0);
-          for (int B = 0; B < 8; ++B) encode_loop(pipe_y(byte, B), P[B] >> 16);
-        }
-      }
-      byte = byten; v = vn;
     }
   }
   if ((unsigned)L.chunk == nchunks - 1u) {
@@ -1732,7 +1786,11 @@ __device__ __forceinline__ unsigned pipe_bh_get(const uint2& w, int B) { return 
 // LDS round trip is off the lane's serial chain.
 // one chunk of the ICM map of component I; tab = [256][G] words of LDS; load_tab / store_tab: the side table is staged from /
 // written back to the arena around this chunk (the persistent launch keeps it in LDS from chunk to chunk)
-template <class Chain, int I, class ST>
+// PD: the streams are read PD + 1 bytes ahead (0: as the step kernels do.  A lone wavefront of the persistent launch stores its
+// output stream write-through and vmcnt counts in order, so a load issued right behind a byte's store -- the next byte's
+// element, one byte ahead -- cannot be waited for without waiting for that store's acknowledgement; two more bytes of lead and
+// the wait only covers stores that are two bytes old)
+template <class Chain, int I, class ST, int PD = 0>
 __device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab, const ST& stretch, int lane, bool load_tab, bool store_tab) {
   constexpr unsigned G = Chain::PIPE_G;
   constexpr CompK c = Chain::comp[I];
@@ -1743,14 +1801,10 @@ __device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab,
       const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
       tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
     }
-  unsigned byte = L.byte_at(0);
-  uint2 w = L.bh(ri, 0);
-  unsigned s = pipe_bh_get(w, 0);
-  unsigned v = tab[s * G + lane];
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned byten = L.byte_at(kn);
-    const uint2 wn = L.bh(ri, kn);
+  const unsigned last = L.nb - 1u;
+  unsigned s, v;
+  // the 8 bits of one byte: its bit histories w, the next byte's wn (bit 7 reads ahead), the p element out
+  auto do_byte = [&](unsigned k, unsigned byte, const uint2& w, const uint2& wn) __attribute__((always_inline)) {
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
@@ -1763,7 +1817,42 @@ __device__ __forceinline__ void pipe_icm_unit(PipeLane<Chain>& L, unsigned* tab,
       s = sn;
     }
     L.put_p(I, k, out.get());
-    byte = byten; w = wn;
+  };
+  if constexpr (PD > 0) {
+    // ring of U slots, byte k in slot k mod U, the loop unrolled U times: every slot a fixed set of registers (a value handed
+    // from register to register would be waited for on the spot)
+    constexpr int U = PD + 1;
+    unsigned bq[U];
+    uint2 wq[U];
+#pragma unroll
+    for (int sl = 0; sl < U; ++sl) { const unsigned kd = min((unsigned)sl, last); bq[sl] = L.byte_at(kd); wq[sl] = L.bh(ri, kd); }
+    s = pipe_bh_get(wq[0], 0);
+    v = tab[s * G + lane];
+    // (no lane leaves the loop early -- the compiler's vmcnt bookkeeping gives up at a divergent branch --: a lane whose block
+    //  ends inside the chunk goes on over its last byte's elements, its table column and stream positions are dead by then;
+    //  a chunk's length is a multiple of U, so a block that goes on never overruns)
+    static_assert(Chain::PIPE_C % U == 0, "ring of U slots");
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)U) {
+#pragma unroll
+      for (int sl = 0; sl < U; ++sl) {
+        const unsigned k = kb + (unsigned)sl;
+        do_byte(k, bq[sl], wq[sl], wq[(sl + 1) % U]);
+        const unsigned kf = min(k + (unsigned)U, last);
+        bq[sl] = L.byte_at(kf); wq[sl] = L.bh(ri, kf);
+      }
+    }
+  } else {
+    unsigned byte = L.byte_at(0);
+    uint2 w = L.bh(ri, 0);
+    s = pipe_bh_get(w, 0);
+    v = tab[s * G + lane];
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint2 wn = L.bh(ri, kn);
+      do_byte(k, byte, w, wn);
+      byte = byten; w = wn;
+    }
   }
   if (store_tab)
     for (int e = 0; e < 256; e += 4)
@@ -1848,7 +1937,7 @@ __device__ __forceinline__ void pipe_isse_packed_unit(PipeLane<Chain>& L, unsign
 }
 
 // ISSE map (libzpaq.cpp:1923-1931, 2031-2039): weight pairs of 64 blocks in LDS as [2 entry + w][lane].
-template <class Chain, int I, class SQ>
+template <class Chain, int I, class SQ, int PD = 0>
 __device__ __forceinline__ void pipe_isse_unit(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab, bool store_tab) {
   constexpr unsigned G = Chain::PIPE_G;
   constexpr CompK c = Chain::comp[I];
@@ -1859,16 +1948,10 @@ __device__ __forceinline__ void pipe_isse_unit(PipeLane<Chain>& L, unsigned* tab
       const uint4 q = L.A128((unsigned)c.t0 + 4u * e);
       tab[e * G + lane] = q.x; tab[(e + 1) * G + lane] = q.y; tab[(e + 2) * G + lane] = q.z; tab[(e + 3) * G + lane] = q.w;
     }
-  unsigned byte = L.byte_at(0);
-  uint2 w = L.bh(ri, 0);
-  uint4 vj = L.p(J, 0);
-  unsigned s = pipe_bh_get(w, 0);
-  int w0 = (int)tab[(2u * s) * G + lane], w1 = (int)tab[(2u * s + 1u) * G + lane];
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned byten = L.byte_at(kn);
-    const uint2 wn = L.bh(ri, kn);
-    const uint4 vjn = L.p(J, kn);
+  const unsigned last = L.nb - 1u;
+  unsigned s;
+  int w0, w1;
+  auto do_byte = [&](unsigned k, unsigned byte, const uint2& w, const uint2& wn, const uint4& vj) __attribute__((always_inline)) {
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
@@ -1887,7 +1970,40 @@ __device__ __forceinline__ void pipe_isse_unit(PipeLane<Chain>& L, unsigned* tab
       s = sn;
     }
     L.put_p(I, k, out.get());
-    byte = byten; w = wn; vj = vjn;
+  };
+  if constexpr (PD > 0) {
+    constexpr int U = PD + 1;            // (ring of U slots, unrolled U times: see pipe_icm_unit)
+    unsigned bq[U];
+    uint2 wq[U];
+    uint4 vq[U];
+#pragma unroll
+    for (int sl = 0; sl < U; ++sl) { const unsigned kd = min((unsigned)sl, last); bq[sl] = L.byte_at(kd); wq[sl] = L.bh(ri, kd); vq[sl] = L.p(J, kd); }
+    s = pipe_bh_get(wq[0], 0);
+    w0 = (int)tab[(2u * s) * G + lane]; w1 = (int)tab[(2u * s + 1u) * G + lane];
+    static_assert(Chain::PIPE_C % U == 0, "ring of U slots");          // (no lane leaves the loop early: see pipe_icm_unit)
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)U) {
+#pragma unroll
+      for (int sl = 0; sl < U; ++sl) {
+        const unsigned k = kb + (unsigned)sl;
+        do_byte(k, bq[sl], wq[sl], wq[(sl + 1) % U], vq[sl]);
+        const unsigned kf = min(k + (unsigned)U, last);
+        bq[sl] = L.byte_at(kf); wq[sl] = L.bh(ri, kf); vq[sl] = L.p(J, kf);
+      }
+    }
+  } else {
+    unsigned byte = L.byte_at(0);
+    uint2 w = L.bh(ri, 0);
+    uint4 vj = L.p(J, 0);
+    s = pipe_bh_get(w, 0);
+    w0 = (int)tab[(2u * s) * G + lane]; w1 = (int)tab[(2u * s + 1u) * G + lane];
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint2 wn = L.bh(ri, kn);
+      const uint4 vjn = L.p(J, kn);
+      do_byte(k, byte, w, wn, vj);
+      byte = byten; w = wn; vj = vjn;
+    }
   }
   if (store_tab)
     for (int e = 0; e < 512; e += 4)

@@ -88,6 +88,8 @@ __device__ __forceinline__ constexpr unsigned pipe_light_lds_words(int lk, int I
 // what host/codegen.cpp plan_persistent decided for the chain (absent in older generated sources: off)
 template <class Chain, class = void> struct PipeCoderFast { static constexpr bool value = false; };
 template <class Chain> struct PipeCoderFast<Chain, decltype((void)Chain::PS_CODER_FAST)> { static constexpr bool value = Chain::PS_CODER_FAST; };
+template <class Chain, class = void> struct PipeAhead { static constexpr int value = 0; };          // stream elements read value + 1 bytes ahead
+template <class Chain> struct PipeAhead<Chain, decltype((void)Chain::PS_AHEAD)> { static constexpr int value = Chain::PS_AHEAD; };
 template <class Chain, class = void> struct PipeSmallChain { static constexpr bool value = false; };
 template <class Chain> struct PipeSmallChain<Chain, decltype((void)Chain::PS_SMALL)> { static constexpr bool value = Chain::PS_SMALL; };
 
@@ -243,7 +245,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
           for (int i = lane; i < 16384; i += 64) ((unsigned*)st)[i] = ((const unsigned*)a.tb->stretch)[i];
           (void)pipe_any(true);    // (a table every lane reads: the lanes meet here)
         }
-        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, PipeStretchFull{st}, lane, c == 0, false);
+        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role], PipeStretchFull, PipeAhead<Chain>::value>(L, (unsigned*)priv, PipeStretchFull{st}, lane, c == 0, false);
       } else {
         if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
       }
@@ -255,7 +257,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
           for (int i = lane; i < 4096; i += 64) sq[i] = a.tb->squash[i];
           (void)pipe_any(true);    // (a table every lane reads: the lanes meet here)
         }
-        if (pipe_any(L.nb > 0)) pipe_isse_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, PipeSquashFull{sq}, lane, c == 0, false);
+        if (pipe_any(L.nb > 0)) pipe_isse_unit<Chain, Chain::ISSE_COMP[role], PipeSquashFull, PipeAhead<Chain>::value>(L, (unsigned*)priv, PipeSquashFull{sq}, lane, c == 0, false);
       } else {
         if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0);
       }
@@ -271,7 +273,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
     } else {
       constexpr int lk = Chain::LIGHT_KIND[role], I = Chain::LIGHT_COMP[role];
       if constexpr (lk == PK_CODER) {
-        if constexpr (PipeCoderFast<Chain>::value) pipe_coder_fast<Chain>(L, a, (unsigned*)priv, lane, c == 0);
+        if constexpr (PipeCoderFast<Chain>::value) pipe_coder_fast<Chain, (PipeAhead<Chain>::value > 0 ? PipeAhead<Chain>::value : 1)>(L, a, (unsigned*)priv, lane, c == 0);
         else pipe_coder<Chain>(L, a, ro.squash);
       } else if (pipe_any(L.nb > 0)) {
         if constexpr (lk == PK_CONS) pipe_cons<Chain, I>(L);

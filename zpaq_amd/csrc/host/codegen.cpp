@@ -385,6 +385,9 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     for (size_t r = 0; r < L.mix.size(); ++r) waves += L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
     L.ps_small = L.mode == 1 && !small_off && waves <= 16;
   }
+  // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
+  static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
+  L.ps_ahead = L.ps_small ? ahead : 0;
   const bool small = L.ps_small;
   const int hl = std::min(L.hcomp_lanes, G);
   const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
@@ -884,6 +887,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     o << "struct ChainP : Chain {\n"
          "  static constexpr bool PIPE_PERSIST = true;\n"
          "  static constexpr int PS_MIX_NH = " << L.ps_mix_nh << ";\n"
+         "  static constexpr int PS_AHEAD = " << L.ps_ahead << ";\n"
          "  static constexpr bool PS_CODER_FAST = " << (L.ps_coder_fast ? "true" : "false") << ", PS_SMALL = " << (L.ps_small ? "true" : "false") << ";\n"
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
       << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";

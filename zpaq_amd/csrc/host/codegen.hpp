@@ -91,6 +91,7 @@ struct PipeLayout {
   int ps_nunit = 0;
   int ps_lds_bytes = 0;        // per workgroup: shared tables + the largest flavour's private tables
   bool ps_coder_fast = false;  // latency shape: the coder with one store per bit (device pipe_coder_fast; 16 KiB of LDS)
+  int ps_ahead = 0;            // a small chain's units read their streams ps_ahead + 1 bytes ahead
   bool ps_small = false;       // a chain of at most 16 unit wavefronts in the latency shape: one wavefront per SIMD, ISSE pairs unpacked
   int ps_mix_nh = 1;           // lane groups a MIX unit gives a block: 2 = bits 0 .. 3 and bits 4 .. 7 apart (half the chain per byte)
   std::vector<Slot> ps_slots;  // ps_wpg * ps_waves, flavour-major
