@@ -342,6 +342,21 @@ struct PipeHLds {
   __device__ __forceinline__ unsigned& operator[](unsigned i) const { return base[i * Chain::HCOMP_LANES + lane]; }
 };
 
+// M in LDS as [index][lane] bytes (the persistent launch, M of up to 256 bytes: Chain::HCOMP_M_LDS)
+template <class Chain>
+struct PipeMLds {
+  unsigned char* base;
+  int lane;
+  struct Ref {
+    unsigned char* p;
+    __device__ __forceinline__ operator unsigned char() const { return *p; }
+    __device__ __forceinline__ Ref& operator=(unsigned char v) { *p = v; return *this; }
+  };
+  __device__ __forceinline__ Ref operator[](unsigned i) const { return Ref{base + i * Chain::HCOMP_LANES + lane}; }
+};
+template <class Chain, class = void> struct PipeHcompMLds { static constexpr bool value = false; };
+template <class Chain> struct PipeHcompMLds<Chain, decltype((void)Chain::HCOMP_M_LDS)> { static constexpr bool value = Chain::HCOMP_M_LDS; };
+
 // One chunk of the HCOMP unit for the lanes of `L` (lane < HCOMP_LANES; the others are idle).  load_h / store_h: H is
 // staged from / written back to the arena around this chunk (the persistent launch keeps it in LDS from chunk to chunk).
 template <class Chain>
@@ -364,9 +379,21 @@ __device__ __forceinline__ void pipe_hcomp_unit(PipeLane<Chain>& L, unsigned* Hs
   if constexpr (HLDS) {
     if (L.nb && load_h) for (unsigned i = 0; i < HW; ++i) Hl[i] = Hg[i];
   }
-  unsigned ch = L.nb ? L.byte_at(0) : 0u;
+  constexpr bool MLDS = PipeHcompMLds<Chain>::value;
+  PipeMLds<Chain> Ml{(unsigned char*)Hs + (HLDS ? HW * (unsigned)Chain::HCOMP_LANES * 4u : 16u), lane};
+  if constexpr (MLDS) {
+    if (L.nb && load_h) for (unsigned i = 0; i <= Chain::MMASK; ++i) Ml[i] = (unsigned char)vm_M[i];
+  }
+  // the input four bytes at a time, a word ahead (a byte asked for one byte ahead is waited for behind the stream stores of the
+  // byte before: they are written through, and vmcnt counts in order); a block's input may be read up to the next multiple of 64
+  typedef unsigned __attribute__((aligned(1))) u32u;
+  typedef const __attribute__((address_space(1))) u32u g_cu32u;
+  const unsigned lastw = L.nb ? (L.nb - 1u) & ~3u : 0u;
+  unsigned cur = L.nb ? *(g_cu32u*)(L.in + L.k0) : 0u;
+  unsigned nxt = L.nb ? *(g_cu32u*)(L.in + L.k0 + min(4u, lastw)) : 0u;
   for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned chn = L.byte_at(L.next(k));
+    if ((k & 3u) == 0u && k) { cur = nxt; nxt = *(g_cu32u*)(L.in + L.k0 + min(k + 4u, lastw)); }
+    const unsigned ch = (cur >> (8u * (k & 3u))) & 255u;
     // contexts of byte k = H as left by the bytes before it (Predictor::update0, libzpaq.cpp:2049-2054): read before the
     // program runs, stored BEHIND it -- the stream stores are written through and vmcnt counts in order, so a load of the
     // program (its M array lives in the arena) issued behind them would wait for their acknowledgements (round 6, profiles/r06
@@ -379,14 +406,15 @@ __device__ __forceinline__ void pipe_hcomp_unit(PipeLane<Chain>& L, unsigned* Hs
       }
     });
     int e;
-    if constexpr (HLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hl, vm_R);
+    if constexpr (HLDS && MLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, Ml, Hl, vm_R);
+    else if constexpr (HLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hl, vm_R);
+    else if constexpr (MLDS) e = Chain::hcomp(ch, vb, vc, vd, vf, Ml, Hg, vm_R);
     else e = Chain::hcomp(ch, vb, vc, vd, vf, vm_M, Hg, vm_R);
     static_for<0, Chain::N>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       if constexpr (Chain::P_CTX[i] >= 0) L.put_ctx(Chain::P_CTX[i], k, hv[Chain::P_CTX[i]]);
     });
     if (e) { st = (unsigned)e; break; }
-    ch = chn;
   }
   if (L.nb) {
     if constexpr (HLDS) { if (store_h) for (unsigned i = 0; i < HW; ++i) Hg[i] = Hl[i]; }
@@ -594,6 +622,82 @@ __device__ __forceinline__ void pipe_row_halves(PipeLane<Chain>& L, const NS& ns
       lines(hq[s2], byq[s2], hmq[s2], hoq[s2]);
       late[s2] = same_line(hmq[s2], hm) || same_line(hmq[s2], hoq[sl]) || same_line(hmq[s2], hmq[s1]) || same_line(hmq[s2], hoq[s1]);
       r0[s2] = L.A128(ht + hmq[s2]); r1[s2] = L.A128(ht + (hmq[s2] ^ 16u)); r2[s2] = L.A128(ht + (hmq[s2] ^ 32u));
+      // byte k + 4's stream elements into the slot byte k leaves
+      const unsigned k4 = min(k + 4u, last);
+      hq[sl] = L.ctx(ci, k4); byq[sl] = L.byte_at(k4);
+    }
+  }
+}
+
+// The lane-per-block unit with the table TWO bytes ahead and the context stream four (round 6; pipe_row_halves says why and how:
+// byte k in slot k mod 4, the loop unrolled four times, every slot a fixed set of registers, no lane leaving the loop early).
+// The six candidate rows of byte k + 2 are asked for when byte k is done; if one of their lines is a line byte k or k + 1 stores
+// into, they are asked for again behind byte k + 1's stores.
+template <class Chain, int I, class NS>
+__device__ __forceinline__ void pipe_row_ring(PipeLane<Chain>& L, const NS& ns) {
+  constexpr CompK c = Chain::comp[I];
+  constexpr unsigned sizebits = c.a1 + 2, rmask = c.mask1, ht = (unsigned)c.t1;
+  constexpr int ci = Chain::P_CTX[I], ri = Chain::P_ROW[I];
+  static_assert(Chain::PIPE_C % 4 == 0, "ring of four slots");
+  if (!L.nb) return;
+  auto lines = [&](unsigned hh, unsigned bytev, unsigned& ha, unsigned& hb) __attribute__((always_inline)) {
+    ha = ((hh + 16u) * 16u) & (rmask - 15u);
+    hb = ((hh + 16u * (16u + (bytev >> 4))) * 16u) & (rmask - 15u);
+  };
+  auto same_line = [](unsigned x, unsigned y) __attribute__((always_inline)) { return ((x ^ y) & ~63u) == 0u; };
+  const unsigned last = L.nb - 1u;
+  unsigned hq[4], byq[4], haq[4], hbq[4];
+  uint4 a0[4], a1[4], a2[4], b0[4], b1[4], b2[4];
+  bool late[4];
+  auto fetch = [&](int sl) __attribute__((always_inline)) {
+    a0[sl] = L.A128(ht + haq[sl]); a1[sl] = L.A128(ht + (haq[sl] ^ 16u)); a2[sl] = L.A128(ht + (haq[sl] ^ 32u));
+    b0[sl] = L.A128(ht + hbq[sl]); b1[sl] = L.A128(ht + (hbq[sl] ^ 16u)); b2[sl] = L.A128(ht + (hbq[sl] ^ 32u));
+  };
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const unsigned kd = min((unsigned)sl, last);
+    hq[sl] = L.ctx(ci, kd); byq[sl] = L.byte_at(kd);
+    late[sl] = false;
+  }
+  lines(hq[0], byq[0], haq[0], hbq[0]);
+  lines(hq[1], byq[1], haq[1], hbq[1]);
+  haq[2] = haq[3] = haq[1]; hbq[2] = hbq[3] = hbq[1];
+  fetch(0);
+  late[1] = same_line(haq[1], haq[0]) || same_line(haq[1], hbq[0]) || same_line(hbq[1], haq[0]) || same_line(hbq[1], hbq[0]);
+  fetch(1);
+  a0[2] = a0[3] = a0[0]; a1[2] = a1[3] = a1[0]; a2[2] = a2[3] = a2[0];
+  b0[2] = b0[3] = b0[0]; b1[2] = b1[3] = b1[0]; b2[2] = b2[3] = b2[0];
+  for (unsigned kb = 0; pipe_any(kb < L.nb); kb += 4u) {
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int s1 = (sl + 1) % 4, s2 = (sl + 2) % 4;
+      const unsigned k = kb + (unsigned)sl;
+      const unsigned h = hq[sl], byte = byq[sl], ha = haq[sl], hb = hbq[sl];
+      const unsigned cxa = h + 16u, cxb = h + 16u * (16u + (byte >> 4));
+      PipeRow ra = pipe_find(a0[sl], a1[sl], a2[sl], (cxa >> sizebits) & 255u, ha);
+      uint2 o;
+      o.x = pipe_row_bits(ra, byte >> 4, ns);
+      const uint4 na = make_uint4(ra.w0, ra.w1, ra.w2, ra.w3);
+      L.A128(ht + ra.off) = na;
+      // the second nibble's candidates were fetched before that store: forward the row it rewrote
+      uint4 c0 = b0[sl], c1 = b1[sl], c2 = b2[sl];
+      if (ra.off == hb) c0 = na;
+      if (ra.off == (hb ^ 16u)) c1 = na;
+      if (ra.off == (hb ^ 32u)) c2 = na;
+      PipeRow rb = pipe_find(c0, c1, c2, (cxb >> sizebits) & 255u, hb);
+      o.y = pipe_row_bits(rb, byte & 15u, ns);
+      L.A128(ht + rb.off) = make_uint4(rb.w0, rb.w1, rb.w2, rb.w3);
+      L.put_bh(ri, k, o);
+      // byte k + 1's rows again, if one of their lines was a line this byte or the one before stored into
+      if (pipe_any(late[s1])) {
+        pipe_stores_done();
+        if (late[s1]) fetch(s1);
+      }
+      // byte k + 2: its lines from the stream elements asked for two bytes ago, its rows now
+      lines(hq[s2], byq[s2], haq[s2], hbq[s2]);
+      late[s2] = same_line(haq[s2], ha) || same_line(haq[s2], hb) || same_line(haq[s2], haq[s1]) || same_line(haq[s2], hbq[s1]) ||
+                 same_line(hbq[s2], ha) || same_line(hbq[s2], hb) || same_line(hbq[s2], haq[s1]) || same_line(hbq[s2], hbq[s1]);
+      fetch(s2);
       // byte k + 4's stream elements into the slot byte k leaves
       const unsigned k4 = min(k + 4u, last);
       hq[sl] = L.ctx(ci, k4); byq[sl] = L.byte_at(k4);
@@ -1884,7 +1988,7 @@ __device__ __forceinline__ void pipe_icm_body(const PipeArgs& a) {
 // ISSE map inside the persistent launch: the weight pairs PACKED -- both weights are clamped to +-2^19 (libzpaq.cpp:2031-2039),
 // 40 bits per pair: a word [entry][lane] with w0 and the low 12 bits of w1, and w1's high 8 bits in a byte of the word
 // [entry / 4][lane] -- 40 KiB instead of 64 for a group of 32 blocks, which is what decides how many workgroups a group needs.
-template <class Chain, int I, class SQ>
+template <class Chain, int I, class SQ, int PD = 0>
 __device__ __forceinline__ void pipe_isse_packed_unit(PipeLane<Chain>& L, unsigned* tab, const SQ& squash, int lane, bool load_tab) {
   constexpr unsigned G = Chain::PIPE_G;
   constexpr CompK c = Chain::comp[I];
@@ -1903,17 +2007,10 @@ __device__ __forceinline__ void pipe_isse_packed_unit(PipeLane<Chain>& L, unsign
       lo[(e + 1u) * G + lane] = (q.z & 0xFFFFFu) | (q.w << 20);
       hi[hi_at(e + 1u)] = (unsigned char)(q.w >> 12);
     }
-  unsigned byte = L.byte_at(0);
-  uint2 w = L.bh(ri, 0);
-  uint4 vj = L.p(J, 0);
-  unsigned s = pipe_bh_get(w, 0);
-  unsigned l0 = lo[s * G + lane], h0 = hi[hi_at(s)];
-  int w0 = w0_of(l0), w1 = w1_of(l0, h0);
-  for (unsigned k = 0; k < L.nb; ++k) {
-    const unsigned kn = L.next(k);
-    const unsigned byten = L.byte_at(kn);
-    const uint2 wn = L.bh(ri, kn);
-    const uint4 vjn = L.p(J, kn);
+  const unsigned last = L.nb - 1u;
+  unsigned s;
+  int w0, w1;
+  auto do_byte = [&](unsigned k, unsigned byte, const uint2& w, const uint2& wn, const uint4& vj) __attribute__((always_inline)) {
     PipeP8 out;
 #pragma unroll
     for (int B = 0; B < 8; ++B) {
@@ -1932,7 +2029,40 @@ __device__ __forceinline__ void pipe_isse_packed_unit(PipeLane<Chain>& L, unsign
       s = sn;
     }
     L.put_p(I, k, out.get());
-    byte = byten; w = wn; vj = vjn;
+  };
+  if constexpr (PD > 0) {
+    constexpr int U = PD + 1;            // (ring of U slots, unrolled U times, no lane leaving the loop early: see pipe_icm_unit)
+    static_assert(Chain::PIPE_C % U == 0, "ring of U slots");
+    unsigned bq[U];
+    uint2 wq[U];
+    uint4 vq[U];
+#pragma unroll
+    for (int sl = 0; sl < U; ++sl) { const unsigned kd = min((unsigned)sl, last); bq[sl] = L.byte_at(kd); wq[sl] = L.bh(ri, kd); vq[sl] = L.p(J, kd); }
+    s = pipe_bh_get(wq[0], 0);
+    { const unsigned l0 = lo[s * G + lane], h0 = hi[hi_at(s)]; w0 = w0_of(l0); w1 = w1_of(l0, h0); }
+    for (unsigned kb = 0; pipe_any(kb < L.nb); kb += (unsigned)U) {
+#pragma unroll
+      for (int sl = 0; sl < U; ++sl) {
+        const unsigned k = kb + (unsigned)sl;
+        do_byte(k, bq[sl], wq[sl], wq[(sl + 1) % U], vq[sl]);
+        const unsigned kf = min(k + (unsigned)U, last);
+        bq[sl] = L.byte_at(kf); wq[sl] = L.bh(ri, kf); vq[sl] = L.p(J, kf);
+      }
+    }
+  } else {
+    unsigned byte = L.byte_at(0);
+    uint2 w = L.bh(ri, 0);
+    uint4 vj = L.p(J, 0);
+    s = pipe_bh_get(w, 0);
+    { const unsigned l0 = lo[s * G + lane], h0 = hi[hi_at(s)]; w0 = w0_of(l0); w1 = w1_of(l0, h0); }
+    for (unsigned k = 0; k < L.nb; ++k) {
+      const unsigned kn = L.next(k);
+      const unsigned byten = L.byte_at(kn);
+      const uint2 wn = L.bh(ri, kn);
+      const uint4 vjn = L.p(J, kn);
+      do_byte(k, byte, w, wn, vj);
+      byte = byten; w = wn; vj = vjn;
+    }
   }
 }
 

@@ -90,6 +90,8 @@ template <class Chain, class = void> struct PipeCoderFast { static constexpr boo
 template <class Chain> struct PipeCoderFast<Chain, decltype((void)Chain::PS_CODER_FAST)> { static constexpr bool value = Chain::PS_CODER_FAST; };
 template <class Chain, class = void> struct PipeAhead { static constexpr int value = 0; };          // stream elements read value + 1 bytes ahead
 template <class Chain> struct PipeAhead<Chain, decltype((void)Chain::PS_AHEAD)> { static constexpr int value = Chain::PS_AHEAD; };
+template <class Chain, class = void> struct PipeRowRing { static constexpr bool value = false; };   // lane-per-block ROW units two bytes ahead in the table
+template <class Chain> struct PipeRowRing<Chain, decltype((void)Chain::PS_ROW_RING)> { static constexpr bool value = Chain::PS_ROW_RING; };
 template <class Chain, class = void> struct PipeSmallChain { static constexpr bool value = false; };
 template <class Chain> struct PipeSmallChain<Chain, decltype((void)Chain::PS_SMALL)> { static constexpr bool value = Chain::PS_SMALL; };
 
@@ -237,6 +239,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       pipe_hcomp_unit<Chain>(L, (unsigned*)priv, lane, c == 0, false);
     } else if constexpr (kind == 1) {
       if constexpr (pipe_row_in_halves<Chain>(role)) { if (pipe_any(L.nb > 0)) pipe_row_halves<Chain, Chain::ROW_COMP[role]>(L, ro.ns, (unsigned)lane >> 5); }
+      else if constexpr (PipeRowRing<Chain>::value) { if (pipe_any(L.nb > 0)) pipe_row_ring<Chain, Chain::ROW_COMP[role]>(L, ro.ns); }
       else if (pipe_any(L.nb > 0)) pipe_row<Chain, Chain::ROW_COMP[role]>(L, ro.ns);
     } else if constexpr (kind == 3) {
       if constexpr (PipeSmallChain<Chain>::value) {
@@ -247,7 +250,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
         }
         if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role], PipeStretchFull, PipeAhead<Chain>::value>(L, (unsigned*)priv, PipeStretchFull{st}, lane, c == 0, false);
       } else {
-        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role]>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
+        if (pipe_any(L.nb > 0)) pipe_icm_unit<Chain, Chain::ICM_COMP[role], PipeStretch, PipeAhead<Chain>::value>(L, (unsigned*)priv, ro.stretch, lane, c == 0, false);
       }
     } else if constexpr (kind == 4) {
       if constexpr (PipeSmallChain<Chain>::value) {
@@ -259,7 +262,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
         }
         if (pipe_any(L.nb > 0)) pipe_isse_unit<Chain, Chain::ISSE_COMP[role], PipeSquashFull, PipeAhead<Chain>::value>(L, (unsigned*)priv, PipeSquashFull{sq}, lane, c == 0, false);
       } else {
-        if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role]>(L, (unsigned*)priv, ro.squash, lane, c == 0);
+        if (pipe_any(L.nb > 0)) pipe_isse_packed_unit<Chain, Chain::ISSE_COMP[role], PipeSquash, PipeAhead<Chain>::value>(L, (unsigned*)priv, ro.squash, lane, c == 0);
       }
     } else if constexpr (kind == 5) {
       if (pipe_any(L.nb > 0)) {

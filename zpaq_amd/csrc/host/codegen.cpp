@@ -387,10 +387,17 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
-  L.ps_ahead = L.ps_small ? ahead : 0;
+  // (the other chains: measured behind knobs -- ZPAQ_AMD_STREAM_AHEAD_BIG for the ICM / ISSE maps, ZPAQ_AMD_ROW_RING for the ROW units)
+  static const int ahead_big = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD_BIG"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 0; }();
+  static const bool row_ring = [] { const char* v = getenv("ZPAQ_AMD_ROW_RING"); return v && v[0] == '1'; }();
+  L.ps_ahead = L.ps_small ? ahead : ahead_big;
+  L.ps_row_ring = row_ring;
   const bool small = L.ps_small;
   const int hl = std::min(L.hcomp_lanes, G);
-  const int hbytes = L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16;
+  // HCOMP's M array of up to 256 bytes beside H (round 6: the legacy models' programs write the byte into M and read the last
+  // seven back -- loads behind a store, a memory round trip per byte: mid.cfg's HCOMP unit set the pace of its launch)
+  L.hcomp_m_lds = ph.mmask + 1u <= 256u;
+  const int hbytes = (L.hcomp_h_lds ? (int)(4u * (ph.hmask + 1u)) * L.hcomp_lanes : 16) + (L.hcomp_m_lds ? (int)(ph.mmask + 1u) * L.hcomp_lanes : 0);
   // relative time per chunk of a unit wavefront inside a full launch (-m5, 1024 blocks, profiles/r05/call5: ms per 2049 chunks / 1000)
   for (int sub = 0; sub < G / hl; ++sub) add(0, 0, sub, 0, hbytes, 0.94f, 0.f, (float)L.nctx * ctx_l * hl / G);
   for (size_t r = 0; r < L.rows.size(); ++r)      // two finds per byte and block: two lines
@@ -887,7 +894,9 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
     o << "struct ChainP : Chain {\n"
          "  static constexpr bool PIPE_PERSIST = true;\n"
          "  static constexpr int PS_MIX_NH = " << L.ps_mix_nh << ";\n"
+         "  static constexpr bool HCOMP_M_LDS = " << (L.hcomp_m_lds ? "true" : "false") << ";\n"
          "  static constexpr int PS_AHEAD = " << L.ps_ahead << ";\n"
+         "  static constexpr bool PS_ROW_RING = " << (L.ps_row_ring ? "true" : "false") << ";\n"
          "  static constexpr bool PS_CODER_FAST = " << (L.ps_coder_fast ? "true" : "false") << ", PS_SMALL = " << (L.ps_small ? "true" : "false") << ";\n"
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
       << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";

@@ -57,6 +57,7 @@ struct PipeLayout {
   int coder_level = 0, coder_state = 0, hcomp_state = 0;
   int hcomp_lanes = 64;        // blocks per HCOMP workgroup
   bool hcomp_h_lds = false;    // H staged in LDS
+  bool hcomp_m_lds = false;    // persistent launch: M (up to 256 bytes) lives in LDS beside H
   std::vector<std::pair<int, int>> light;   // (PipeKind, component): CONS, CM, MATCH, AVG, MIX2, SSE units and the coder
   std::vector<int> rows, icm, isse, mix, mix_ql;
   std::vector<int> mix_packed;   // per MIX role: 1 = weight rows as 24-bit quads (device/pipe_kernel.h pipe_mix_packed_unit); the arena holds them so
@@ -91,6 +92,7 @@ struct PipeLayout {
   int ps_nunit = 0;
   int ps_lds_bytes = 0;        // per workgroup: shared tables + the largest flavour's private tables
   bool ps_coder_fast = false;  // latency shape: the coder with one store per bit (device pipe_coder_fast; 16 KiB of LDS)
+  bool ps_row_ring = false;    // lane-per-block ROW units with the table two bytes ahead (device pipe_row_ring)
   int ps_ahead = 0;            // a small chain's units read their streams ps_ahead + 1 bytes ahead
   bool ps_small = false;       // a chain of at most 16 unit wavefronts in the latency shape: one wavefront per SIMD, ISSE pairs unpacked
   int ps_mix_nh = 1;           // lane groups a MIX unit gives a block: 2 = bits 0 .. 3 and bits 4 .. 7 apart (half the chain per byte)

@@ -45,6 +45,14 @@ def standard_headers():
                 except z.ZpaqError:
                     continue
                 hs[h] = f"method {level}{hint} arg0={arg0}"
+    # BASELINE configs[1]: -m3 on 256 KiB blocks of LCG bytes (bench.py's `configs1` object)
+    try:
+        from zpaq_amd import corpus
+        h, _, _ = z.method_to_header(z.expand_method("3", corpus.block("lcg", 1 << 18, corpus.BASE_SEED)))
+        if h[6]:
+            hs.setdefault(h, "method 3, configs[1]")
+    except z.ZpaqError:
+        pass
     gpath = os.path.join(ROOT, "tests", "golden", "golden.json")
     if os.path.exists(gpath):
         g = json.load(open(gpath))
