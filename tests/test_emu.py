@@ -398,6 +398,8 @@ SMALL_CHAIN_CFGS = [
     "comp 2 0 0 0 2\n  0 icm 4\n  1 isse 4 0\nhcomp\n  b=a a=*d a<<= 4 a+=b *d=a d++ a<<= 3 a+=b *d=a halt\nend\n",
     "comp 2 0 0 0 2\n  0 icm 10\n  1 isse 10 0\nhcomp\n  b=a a=*d a<<= 8 a+=b *d=a d++ a<<= 5 a+=b *d=a halt\nend\n",
     "comp 2 0 0 0 4\n  0 cm 9 255\n  1 icm 9\n  2 isse 10 1\n  3 isse 11 2\nhcomp\n  b=a *d=a d++ a=*d a<<= 8 a+=b *d=a d++ a<<= 2 a+=b *d=a d++ hash *d=a halt\nend\n",
+    # an M array of 8 bytes, written and read back by the program (HCOMP keeps it in LDS inside the persistent launch)
+    "comp 2 3 0 0 2\n  0 icm 10\n  1 isse 10 0\nhcomp\n  c++ *c=a b=c a=0 d=0 hash b-- hash *d=a d++ b-- hash *d=a halt\nend\n",
 ]
 
 

@@ -618,6 +618,46 @@ def test_method_3_known_answer_and_preprocessing_levels(gpu, ref):
         assert gpu.decompress(b"".join(ours)) == b"".join(b.tobytes() for b in blocks), m
 
 
+SMALL_CHAIN_CFGS = [
+    "comp 1 0 0 0 1\n  0 icm 12\nhcomp\n  *d=a halt\nend\n",
+    "comp 2 0 0 0 2\n  0 icm 4\n  1 isse 4 0\nhcomp\n  b=a a=*d a<<= 4 a+=b *d=a d++ a<<= 3 a+=b *d=a halt\nend\n",
+    "comp 2 3 0 0 2\n  0 icm 10\n  1 isse 10 0\nhcomp\n  c++ *c=a b=c a=0 d=0 hash b-- hash *d=a d++ b-- hash *d=a halt\nend\n",
+    "comp 2 0 0 0 4\n  0 cm 9 255\n  1 icm 9\n  2 isse 10 1\n  3 isse 11 2\nhcomp\n  b=a *d=a d++ a=*d a<<= 8 a+=b *d=a d++ a<<= 2 a+=b *d=a d++ hash *d=a halt\nend\n",
+]
+
+
+def test_small_chains_in_the_latency_shape(gpu, oracle):
+    """Round 6: the latency shape of a chain of a few unit wavefronts (BASELINE configs[1]'s n = 2) -- workgroups of 4, ISSE pairs
+    unpacked, whole squash / stretch tables, ROW units with a lane per nibble and the table two bytes ahead, streams four bytes
+    ahead in rings of fixed slots, HCOMP's small M array in LDS, the coder with a window per input byte (tests/test_emu.py has the
+    same cases on the emulator).  Against the oracle: ragged, empty and one-byte blocks, zeros (every next row is the row being
+    stored), incompressible bytes (the coder emits at nearly every bit; ~10^7 coded bits, some of which fail the fast form's
+    test), several groups, output capacities around the coded length (status 3 exactly when it does not fit)."""
+    assert gpu.lib().zpq_engine_count() >= 1
+    blk = corpus.block("lcg", 1 << 18, corpus.BASE_SEED)
+    h3, _, _ = gpu.method_to_header(gpu.expand_method("3", blk))
+    kinds = ["text", "lcg", "zeros", "records", "pattern"]
+    ragged = [b"\0" + corpus.block(kinds[i % 5], n, 40 + i).tobytes() for i, n in enumerate([300, 150, 200, 97, 0, 1, 63, 64, 65, 2000, 777, 5000, 513, 512, 511])]
+    many = [b"\0" + corpus.block(kinds[i % 5], 100 + 131 * i, i).tobytes() for i in range(100)]
+    long_ones = [corpus.block("lcg", 40000, 100 + i).tobytes() for i in range(33)]
+    headers = [h3] + [gpu.assemble(c)[0] for c in SMALL_CHAIN_CFGS]
+    for hdr in headers:
+        plan = gpu.Plan(hdr)
+        for inputs in ([ragged, many, long_ones] if hdr is h3 else [ragged]):
+            got = gpu.encode_batch([plan] * len(inputs), inputs)
+            assert gpu.lib().zpq_last_persistent() == 1
+            for i, (g, d) in enumerate(zip(got, inputs)):
+                assert g == oracle.encode(hdr, d), i
+    plan = gpu.Plan(h3)
+    data = [b"\0" + corpus.block("lcg", 400, 7).tobytes(), b"\0" + corpus.block("text", 400, 8).tobytes(), b"\0" + bytes(300)]
+    want = [oracle.encode(h3, d) for d in data]
+    for cap in (8, 40, 41, len(want[1]), len(want[0]) - 1, len(want[0]), len(want[0]) + 3, len(want[0]) + 39, len(want[0]) + 41):
+        got, st, ol = gpu.encode_batch([plan] * 3, data, out_cap=[cap] * 3, check=False)
+        for w, g, s_ in zip(want, got, st):
+            assert (s_ == 0) == (len(w) <= cap), (cap, len(w), s_)
+            assert g == w[:cap]
+
+
 def test_sha1_on_the_device(gpu):
     """sha1_blocks_kernel against hashlib: lengths around every padding boundary, unaligned starts come from the
     PP-byte offset inside compress_blocks (whole-archive tests cover that), a few MiB-sized buffers."""

@@ -379,11 +379,12 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   // pairs and whole squash tables.
   static const bool fast_off = [] { const char* v = getenv("ZPAQ_AMD_CODER_FAST"); return v && v[0] == '0'; }();
   static const bool small_off = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN"); return v && v[0] == '0'; }();
+  static const int small_max = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN_WAVES"); return v ? atoi(v) : 16; }();
   L.ps_coder_fast = L.mode == 1 && !fast_off;
   {
     int waves = std::max(1, G / std::min(L.hcomp_lanes, G)) + (int)L.rows.size() + (int)L.light.size() + (int)L.icm.size() + (int)L.isse.size();
     for (size_t r = 0; r < L.mix.size(); ++r) waves += L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
-    L.ps_small = L.mode == 1 && !small_off && waves <= 16;
+    L.ps_small = L.mode == 1 && !small_off && waves <= small_max;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
