@@ -10,6 +10,7 @@
 #include "guard_alloc.h"
 #include "wave_emu.h"
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -53,20 +54,24 @@ void kernel_thunk(void* p) {
   }
 }
 
+// init_arena_kernel's statement (kernels.hip), over an arena that starts DIRTY: the engine's arenas hold the previous batch's
+// state, so whatever the fill leaves out is garbage there -- 16-byte stores over sg.bytes >> 4 units, like the kernel
+// (round 6: a 4-byte H array -- hh = 0 -- fell through the fill and the GPU coded with the previous batch's H[0])
 void init_arena(uint8_t* arena, const uint8_t* blob, const zpq::DeviceTables& tb) {
   const zpq::PlanHeader* ph = (const zpq::PlanHeader*)blob;
   const zpq::Segment* segs = (const zpq::Segment*)(blob + ph->off_seg);
+  memset(arena, 0xC3, ph->arena_bytes);
   for (uint32_t s = 0; s < ph->nseg; ++s) {
     const zpq::Segment& sg = segs[s];
     uint32_t* dst = (uint32_t*)(arena + sg.off);
-    const uint64_t n = sg.bytes / 4;
+    const uint64_t n = (sg.bytes >> 4) * 4;
     switch (sg.kind) {
-      case zpq::F_ZERO: break;
+      case zpq::F_ZERO: for (uint64_t i = 0; i < n; ++i) dst[i] = 0; break;
       case zpq::F_U32: for (uint64_t i = 0; i < n; ++i) dst[i] = sg.value; break;
       case zpq::F_SSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.sse_row[i & 31] | sg.value; break;
       case zpq::F_ICM: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.icm_init[i]; break;
       case zpq::F_ISSE: for (uint64_t i = 0; i < n; ++i) dst[i] = tb.isse_init[i]; break;
-      case zpq::F_MATCHBUF: dst[0] = 1; break;
+      case zpq::F_MATCHBUF: for (uint64_t i = 0; i < n; ++i) dst[i] = i == 0 ? 1u : 0u; break;
       default: fprintf(stderr, "pipe_emu_run: unknown segment kind %u\n", sg.kind); exit(2);
     }
   }

@@ -40,8 +40,13 @@ zpq_plan* plan_from_header(const U8* h, size_t hlen, bool list_only) {
   auto seg = [&](uint64_t bytes, uint32_t kind, uint32_t value) {
     uint64_t o = off;
     uint64_t padded = align_up(bytes, 256);
-    segs.push_back(Segment{o, bytes, kind, value});
-    if (padded > bytes) segs.push_back(Segment{o + bytes, padded - bytes, F_ZERO, 0});
+    // init_arena_kernel fills in 16-byte stores: a table of 4 or 8 bytes (H with hh < 2, a CM / MATCH index of one or two
+    // entries) was left as the previous batch had it and its padding was written through a misaligned pointer (round 6: found
+    // by the GPU test of the small chains -- a one-ICM chain with hh = 0 behind another chain's batch).  The fill covers whole
+    // 16-byte units; what it writes past the table lies in the table's own padding.
+    const uint64_t fill = align_up(bytes, 16);
+    segs.push_back(Segment{o, fill, kind, value});
+    if (padded > fill) segs.push_back(Segment{o + fill, padded - fill, F_ZERO, 0});
     off += padded;
     return o;
   };
