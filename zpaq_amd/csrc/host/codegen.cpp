@@ -376,15 +376,19 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   // longest per-bit instruction stream.  Its coder stores once per bit instead of keeping a window (pipe_coder_fast), and a
   // chain of a few units (configs[1]'s n = 2: six wavefronts per group) gets a SIMD per wavefront -- two workgroups of 4 instead
   // of one of 6, where the ROW units shared their SIMDs with the ICM map and HCOMP -- and, with LDS to spare, unpacked ISSE
-  // pairs and whole squash tables.
+  // pairs and whole squash / stretch tables, ROW units with a lane per nibble, streams read four bytes ahead.  "A few": up to 32
+  // unit wavefronts per group -- mid.cfg (24) went from 139 to 205 MB/s on 256 blocks when it was let in (profiles/r06 call 19);
+  // the -m5 chains (110 and more) keep the general latency shape.
   static const bool fast_off = [] { const char* v = getenv("ZPAQ_AMD_CODER_FAST"); return v && v[0] == '0'; }();
   static const bool small_off = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN"); return v && v[0] == '0'; }();
-  static const int small_max = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN_WAVES"); return v ? atoi(v) : 16; }();
+  static const int small_max = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN_WAVES"); return v ? atoi(v) : 32; }();
   L.ps_coder_fast = L.mode == 1 && !fast_off;
+  int small_waves = 0;
   {
     int waves = std::max(1, G / std::min(L.hcomp_lanes, G)) + (int)L.rows.size() + (int)L.light.size() + (int)L.icm.size() + (int)L.isse.size();
     for (size_t r = 0; r < L.mix.size(); ++r) waves += L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
     L.ps_small = L.mode == 1 && !small_off && waves <= small_max;
+    small_waves = waves;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
@@ -509,7 +513,9 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   // 7 x 32 = 224 workgroups); otherwise the fewest that hold the units.  The tables go first (largest first, each into the
   // bin it fits best -- tried emptiest-first as well), then the units without tables to the bin with the least work.
   static const int wpg_floor = [] { const char* v = getenv("ZPAQ_AMD_PERSIST_WPG_MIN"); return v ? atoi(v) : -1; }();      // (experiments)
-  const int Wmax = small ? 4 : 8;
+  // (a wavefront per SIMD while that takes at most 8 workgroups per group; the larger chains of the latency shape keep 8 per workgroup)
+  static const int small_w4 = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN_W4_WAVES"); return v ? atoi(v) : 32; }();
+  const int Wmax = small && small_waves <= small_w4 ? 4 : 8;
   const int wpg_min = (total + Wmax - 1) / Wmax;
   std::vector<int> tries;
   if (wpg_floor >= 0) { for (int w = std::max(wpg_min, std::min(wpg_floor, total)); w <= total; ++w) tries.push_back(w); }
