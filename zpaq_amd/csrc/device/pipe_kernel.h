@@ -116,6 +116,15 @@ __device__ __forceinline__ void pipe_stores_done() {
 #endif
 }
 
+// The same between lanes of ONE wavefront when the re-fetch is simply issued behind the store: the hardware performs a
+// wavefront's memory operations on one address in program order (a wavefront-scope fence emits no instruction); this only keeps
+// the compiler from moving the load above the store.
+__device__ __forceinline__ void pipe_wave_order() {
+#ifndef ZPQ_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
+}
+
 // A value the compiler must treat as per-lane data.  When all lanes of a wavefront serve one block the compiler proves
 // stream addresses uniform, moves every loaded context into a scalar register with v_readfirstlane right behind the load
 // -- and so waits for a fetch that was issued bytes ahead precisely in order not to be waited for.
@@ -613,9 +622,12 @@ __device__ __forceinline__ void pipe_row_halves(PipeLane<Chain>& L, const NS& ns
       const unsigned o = pipe_row_bits(r, half ? byte & 15u : byte >> 4, ns);
       L.A128(ht + r.off) = make_uint4(r.w0, r.w1, r.w2, r.w3);
       L.put_bh_half(ri, k, half, o);
-      // byte k + 1's rows again, if their line was one this byte or the one before stored into (the other half's store as well)
+      // byte k + 1's rows again, if their line was one this byte or the one before stored into -- the other half's store as well:
+      // another lane's, but the same wavefront's, and a wavefront's memory operations on one address are performed in program
+      // order (the re-fetch is issued behind the store; waiting for the store's acknowledgement first -- on text some lane of
+      // the 64 is late at nearly every byte -- put a memory round trip into every byte: profiles/r06 call 23)
       if (pipe_any(late[s1])) {
-        pipe_stores_done();
+        pipe_wave_order();
         if (late[s1]) { r0[s1] = L.A128(ht + hmq[s1]); r1[s1] = L.A128(ht + (hmq[s1] ^ 16u)); r2[s1] = L.A128(ht + (hmq[s1] ^ 32u)); }
       }
       // byte k + 2: its lines from the stream elements asked for two bytes ago, its rows now
@@ -690,7 +702,7 @@ __device__ __forceinline__ void pipe_row_ring(PipeLane<Chain>& L, const NS& ns) 
       L.put_bh(ri, k, o);
       // byte k + 1's rows again, if one of their lines was a line this byte or the one before stored into
       if (pipe_any(late[s1])) {
-        pipe_stores_done();
+        pipe_wave_order();
         if (late[s1]) fetch(s1);
       }
       // byte k + 2: its lines from the stream elements asked for two bytes ago, its rows now
