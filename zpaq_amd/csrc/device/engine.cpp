@@ -349,7 +349,7 @@ void engine_plan_release(zpq_plan* p) {
   (void)hipGetDevice(&before);
   for (int id = 0; id < zpq_plan::kMaxDevices; ++id) {
     zpq_plan::OnDevice& od = p->dev[id];
-    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.pipe[2] && !od.spec[0] && !od.spec[1] && !od.spec[2]) continue;
+    if (!od.d_blob && !od.pipe[0] && !od.pipe[1] && !od.pipe[2] && !od.pipe[3] && !od.spec[0] && !od.spec[1] && !od.spec[2]) continue;
     if (hipSetDevice(g_engines[id].device >= 0 ? g_engines[id].device : id) != hipSuccess) continue;
     set_plan_device_index(id);
     if (od.d_blob) { (void)hipFree(od.d_blob); od.d_blob = nullptr; }
@@ -415,7 +415,20 @@ static int pipe_mode_for(uint32_t blocks_of_plan, uint32_t longest_block, uint32
   // (long steps exist to spread the per-step launch cost; the persistent launch has none and takes the 512-byte shape)
   const bool long_steps = persist_off && longest_block >= kLongStepBytes && stream_bytes_per_byte &&
                           (uint64_t)blocks_of_plan * 2048u * stream_bytes_per_byte <= kLongStepStreamBytes;
-  return long_steps ? 2 : 1;
+  if (long_steps) return 2;
+  // Variant 3: the latency shape with a wavefront per SIMD (twice the workgroups per group) while THOSE all fit the device
+  // (round 6, call 29: -m5 on 64 / 128 / 256 blocks +17 / +20 / +26 %); a small chain's variant 1 is that shape already.
+  static const bool wide_off = [] { const char* v = getenv("ZPAQ_AMD_PIPE_WIDE"); return v && v[0] == '0'; }();
+  if (plan && !persist_off && !wide_off && !getenv("ZPAQ_AMD_PIPE_MODE")) {
+    PipeLayout L1, L3;
+    std::string why;
+    if (pipe_layout(*plan, pipe_options(1), L1, why) && L1.persist_ok && pipe_layout(*plan, pipe_options(3), L3, why) && L3.persist_ok &&
+        L3.ps_waves < L1.ps_waves) {
+      const uint64_t groups = (blocks_of_plan + (uint32_t)L3.G - 1) / (uint32_t)L3.G;
+      if (groups * (uint64_t)L3.ps_wpg <= (uint64_t)g_cus_hint.load()) return 3;
+    }
+  }
+  return 1;
 }
 // bytes the units of a chain pass each other per input byte (ctx 4, bh 8, p 16 per stream); 0: no pipelined encoder
 static uint32_t pipe_stream_bytes_per_byte(const zpq_plan* plan) {
@@ -1067,6 +1080,8 @@ static std::map<const zpq_plan*, int> pipe_modes(const std::vector<uint32_t>& or
   // are resident TOGETHER, so chains go from the latency shape to the throughput shape (fewer workgroups per group), the one
   // that frees the most first, until the batch fits
   const char* pp = getenv("ZPAQ_AMD_PIPE_PERSIST");
+  // (several chains in one batch: variant 3's workgroups are not part of the arithmetic below -- variant 1 there)
+  if (cnt.size() > 1) for (auto& kv : mode) if (kv.second == 3) kv.second = 1;
   if (cnt.size() > 1 && !(pp && !strcmp(pp, "0")) && persist_expected && !getenv("ZPAQ_AMD_PIPE_MODE")) {
     struct Need { const zpq_plan* p; uint64_t lat, thr; };      // what an XCD has to hold of the chain in either shape
     std::vector<Need> need;

@@ -22,8 +22,8 @@ struct zpq_plan {
     int spec_state[4] = {0, 0, 0, 0};              // 0 not tried, 1 loaded, -1 unavailable
     // PipeKernel*: the pipelined encoder (device/pipe_kernel.h) in its variants (host/codegen.hpp pipe_options):
     // [0] throughput shape, [1] latency shape, [2] latency shape with 2048-byte steps
-    void* pipe[3] = {nullptr, nullptr, nullptr};
-    int pipe_state[3] = {0, 0, 0};
+    void* pipe[4] = {nullptr, nullptr, nullptr, nullptr};      // per encoder variant (host/codegen.hpp pipe_options)
+    int pipe_state[4] = {0, 0, 0, 0};
     std::string pipe_note, spec_note;     // where the last kernel came from / why it is unavailable
   };
   static const int kMaxDevices = 16;

@@ -322,6 +322,7 @@ PipeOptions pipe_options(int variant) {
   PipeOptions o;
   o.mode = variant ? 1 : 0;
   o.chunk = variant == 2 ? 2048 : 0;
+  o.wide = variant == 3;
   return o;
 }
 
@@ -515,7 +516,12 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
   static const int wpg_floor = [] { const char* v = getenv("ZPAQ_AMD_PERSIST_WPG_MIN"); return v ? atoi(v) : -1; }();      // (experiments)
   // (a wavefront per SIMD while that takes at most 8 workgroups per group; the larger chains of the latency shape keep 8 per workgroup)
   static const int small_w4 = [] { const char* v = getenv("ZPAQ_AMD_SMALL_CHAIN_W4_WAVES"); return v ? atoi(v) : 32; }();
-  const int Wmax = small && small_waves <= small_w4 ? 4 : 8;
+  // (experiment of call 29: a wavefront per SIMD for EVERY latency-shape chain, without the small chains' LDS-rich units)
+  static const bool latency_w4 = [] { const char* v = getenv("ZPAQ_AMD_LATENCY_W4"); return v && v[0] == '1'; }();
+  // Variant 3 (round 6, profiles/r06 call 29): the latency shape of the LARGER chains with a wavefront per SIMD as well -- -m5 on
+  // 64 / 128 / 256 blocks 40.2 / 78.8 / 141.0 -> 47.1 / 94.2 / 177.6 MB/s -- at twice the workgroups per group (28 for -m5), so the
+  // engine takes it while those fit the device (up to 9 groups) and variant 1 beyond (up to 18).
+  const int Wmax = (small && small_waves <= small_w4) || ((latency_w4 || L.ps_wide) && L.mode == 1) ? 4 : 8;
   const int wpg_min = (total + Wmax - 1) / Wmax;
   std::vector<int> tries;
   if (wpg_floor >= 0) { for (int w = std::max(wpg_min, std::min(wpg_floor, total)); w <= total; ++w) tries.push_back(w); }
@@ -670,6 +676,7 @@ bool pipe_layout(const zpq_plan& plan, const PipeOptions& opt, PipeLayout& L, st
   std::string key((const char*)plan.header.data(), plan.header.size());
   key += '|'; key += std::to_string(opt.mode); key += ','; key += std::to_string(opt.chunk); key += ','; key += std::to_string(opt.group);
   key += ','; key += opt.persist ? '1' : '0';
+  key += opt.wide ? 'w' : 'n';
   {
     std::lock_guard<std::mutex> g(mu);
     auto it = memo.find(key);
@@ -693,6 +700,7 @@ static bool pipe_layout_compute(const zpq_plan& plan, const PipeOptions& opt, Pi
   L = PipeLayout();
   L.n = n;
   L.mode = opt.mode ? 1 : 0;
+  L.ps_wide = opt.wide && L.mode == 1;
   if (opt.chunk >= 64 && opt.chunk <= 8192 && (opt.chunk & (opt.chunk - 1)) == 0) L.C = opt.chunk;
   if (opt.group == 8 || opt.group == 16 || opt.group == 32 || opt.group == 64) L.G = opt.group;
   enum { K_ROW = 1, K_CONS, K_CM, K_MATCH, K_AVG, K_MIX2, K_SSE, K_CODER };     // = device PipeKind

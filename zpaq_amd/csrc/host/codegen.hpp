@@ -37,14 +37,17 @@ struct PipeOptions {
   int chunk = 0;
   int group = 0;
   bool persist = true;         // also emit the persistent launch (device/pipe_persist.h) when the chain can be packed
+  bool wide = false;           // latency shape with a wavefront per SIMD (workgroups of 4): twice the workgroups per group
 };
 // The product's variants of a chain's encoder: 0 = throughput shape, 1 = latency shape, 2 = latency shape with steps
 // of 2048 bytes instead of 512.  A step costs a fixed ~0.3 ms of launches and dependencies between the six streams
 // whatever it holds; a batch that fills the GPU hides that behind 2 ms of work, a small one does not (-m5 on 64 blocks:
 // 0.98 ms per 512-byte step against 0.65 ms for the longest chain), so blocks long enough to fill a long pipeline
 // (128 KiB and more: 16 levels x 2048 bytes of fill) take four times fewer, four times longer steps -- as long as the
-// streams of one step stay cache-sized (engine.cpp::pipe_mode_for has the rule and the measurements).
-static const int kPipeVariants = 3;
+// streams of one step stay cache-sized (engine.cpp::pipe_mode_for has the rule and the measurements).  3 = latency shape with
+// a wavefront per SIMD (workgroups of 4 wavefronts: twice the workgroups per group), taken by the persistent launch while those
+// all fit the device (round 6; a chain of up to 32 unit wavefronts has that shape as its variant 1 already).
+static const int kPipeVariants = 4;
 PipeOptions pipe_options(int variant);
 
 struct PipeLayout {
@@ -94,6 +97,7 @@ struct PipeLayout {
   bool ps_coder_fast = false;  // latency shape: the coder with one store per bit (device pipe_coder_fast; 16 KiB of LDS)
   bool ps_row_ring = false;    // lane-per-block ROW units with the table two bytes ahead (device pipe_row_ring)
   int ps_ahead = 0;            // a small chain's units read their streams ps_ahead + 1 bytes ahead
+  bool ps_wide = false;        // variant 3: workgroups of 4 wavefronts whatever the chain's size
   bool ps_small = false;       // a chain of at most 16 unit wavefronts in the latency shape: one wavefront per SIMD, ISSE pairs unpacked
   int ps_mix_nh = 1;           // lane groups a MIX unit gives a block: 2 = bits 0 .. 3 and bits 4 .. 7 apart (half the chain per byte)
   std::vector<Slot> ps_slots;  // ps_wpg * ps_waves, flavour-major

@@ -228,7 +228,7 @@ def main(verbose=True, clean=True):
     # workgroup for batches of up to 4 x CUs blocks, 8 per workgroup (two wavefronts per SIMD) beyond that
     forced = os.environ.get("ZPAQ_AMD_SPEC_WAVES")
     for h, why in standard_headers().items():
-        for mode in (0, 1, 2):        # throughput, latency, latency with 2048-byte steps (host/codegen.hpp pipe_options)
+        for mode in (0, 1, 2, 3):     # throughput, latency, latency with 2048-byte steps, latency with a wavefront per SIMD (host/codegen.hpp pipe_options)
             src, key = pipe_source_and_key(h, mode)
             if src is not None and key not in seen:
                 seen.add(key)
