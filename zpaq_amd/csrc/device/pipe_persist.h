@@ -95,10 +95,13 @@ template <class Chain> struct PipeRowRing<Chain, decltype((void)Chain::PS_ROW_RI
 template <class Chain, class = void> struct PipeSmallChain { static constexpr bool value = false; };
 template <class Chain> struct PipeSmallChain<Chain, decltype((void)Chain::PS_SMALL)> { static constexpr bool value = Chain::PS_SMALL; };
 
-// ROW unit `role` with a lane per nibble (pipe_row_halves): small chains, groups of 32 blocks, tables of 8 KiB or more
+// ROW unit `role` with a lane per nibble (pipe_row_halves): small chains (PS_ROW_HALVES, where the generated source says otherwise:
+// variant 3 of a larger chain has the small chains' LDS-rich maps but not this), groups of 32 blocks, tables of 8 KiB or more
+template <class Chain, class = void> struct PipeRowHalves { static constexpr bool value = PipeSmallChain<Chain>::value; };
+template <class Chain> struct PipeRowHalves<Chain, decltype((void)Chain::PS_ROW_HALVES)> { static constexpr bool value = Chain::PS_ROW_HALVES; };
 template <class Chain>
 __device__ __forceinline__ constexpr bool pipe_row_in_halves(int role) {
-  return PipeSmallChain<Chain>::value && Chain::PIPE_G == 32u && Chain::comp[Chain::ROW_COMP[role]].mask1 + 1u >= 8192u;
+  return PipeRowHalves<Chain>::value && Chain::PIPE_G == 32u && Chain::comp[Chain::ROW_COMP[role]].mask1 + 1u >= 8192u;
 }
 
 // a pointer every lane holds the same value of, as a value the compiler knows to be wave-uniform (function arguments and

@@ -390,6 +390,13 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     for (size_t r = 0; r < L.mix.size(); ++r) waves += L.mix_bits ? L.mix_waves_of(L.mix_ql[r]) : std::max(1, G * L.mix_ql[r] / 64);
     L.ps_small = L.mode == 1 && !small_off && waves <= small_max;
     small_waves = waves;
+    // Variant 3 of a larger chain (a wavefront per SIMD: 28 workgroups per group for -m5, LDS to spare in every one) takes the
+    // small chains' LDS-rich ICM / ISSE maps as well -- the packed ISSE maps set its pace (profiles/r06 call 29) -- but keeps the
+    // ROW units with a lane per block: with a lane per nibble some lane of the 64 re-fetches a clashing row at nearly every
+    // byte of text (call 30).  ZPAQ_AMD_WIDE_RICH=0: without.
+    static const bool wide_rich_off = [] { const char* v = getenv("ZPAQ_AMD_WIDE_RICH"); return v && v[0] == '0'; }();
+    L.ps_row_halves = L.ps_small;
+    if (L.ps_wide && L.mode == 1 && !small_off && !wide_rich_off) L.ps_small = true;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
@@ -913,6 +920,9 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
          "  static constexpr int PS_AHEAD = " << L.ps_ahead << ";\n"
          "  static constexpr bool PS_ROW_RING = " << (L.ps_row_ring ? "true" : "false") << ";\n"
          "  static constexpr bool PS_CODER_FAST = " << (L.ps_coder_fast ? "true" : "false") << ", PS_SMALL = " << (L.ps_small ? "true" : "false") << ";\n"
+      << (L.ps_small && !L.ps_row_halves ? "  static constexpr bool PS_ROW_HALVES = false;\n" : "")
+      << "";
+    o <<
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()
       << ", PS_NUNIT = " << L.ps_nunit << ", PS_LDS_BYTES = " << L.ps_lds_bytes << ";\n";
     arr("PS_KIND", kind.data(), (int)kind.size());
