@@ -397,6 +397,10 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     static const bool wide_rich_off = [] { const char* v = getenv("ZPAQ_AMD_WIDE_RICH"); return v && v[0] == '0'; }();
     L.ps_row_halves = L.ps_small;
     if (L.ps_wide && L.mode == 1 && !small_off && !wide_rich_off) L.ps_small = true;
+    // ... and so does variant 1 of a larger chain (workgroups of 8; -m5: 16 per group instead of 14, so up to 16 groups): call 34,
+    // 320 / 384 / 512 blocks 167.1 / 201.5 / 254.8 -> 199.9 / 238.4 / 301.0 MB/s.  ZPAQ_AMD_LATENCY_RICH=0: without.
+    static const bool latency_rich_off = [] { const char* v = getenv("ZPAQ_AMD_LATENCY_RICH"); return v && v[0] == '0'; }();
+    if (!latency_rich_off && L.mode == 1 && !small_off) L.ps_small = true;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
