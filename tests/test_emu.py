@@ -370,7 +370,7 @@ def test_persistent_launch_of_the_pipelined_encoder(zlib_, oracle, golden):
         _pipe_check(oracle, h5, ragged + [b""], chunk=64, mode=mode, persist=True)
         _pipe_check(oracle, h4, [b"\0" + corpus.block(kinds[i % 3], 20 + (i * 37) % 180, i).tobytes() for i in range(40)], chunk=64, group=16, mode=mode, persist=True)
     # variant 3 (round 6): the latency shape with a wavefront per SIMD -- workgroups of 4, twice as many per group
-    assert "PS_WAVES = 4, PS_WPG = 28" in emu.pipe_source(h5, 64, mode=3) and "PS_WAVES = 8, PS_WPG = 16" in emu.pipe_source(h5, 64, mode=1)
+    assert "PS_WAVES = 4, PS_WPG = 28" in emu.pipe_source(h5, 64, mode=3) and "PS_WAVES = 8, PS_WPG = 14" in emu.pipe_source(h5, 64, mode=1)
     _pipe_check(oracle, h5, ragged + [b""], chunk=64, mode=3, persist=True)
     # more chunks than ring slots: producers have to wait for their consumers' progress
     _pipe_check(oracle, h5, [b"\0" + corpus.block("text", 64 * 45 + 7, 3).tobytes(), b"\0" + corpus.block("records", 64 * 30, 4).tobytes()], chunk=64, mode=0, persist=True)

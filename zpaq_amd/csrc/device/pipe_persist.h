@@ -97,6 +97,9 @@ template <class Chain> struct PipeSmallChain<Chain, decltype((void)Chain::PS_SMA
 
 // ROW unit `role` with a lane per nibble (pipe_row_halves): small chains (PS_ROW_HALVES, where the generated source says otherwise:
 // variant 3 of a larger chain has the small chains' LDS-rich maps but not this), groups of 32 blocks, tables of 8 KiB or more
+// ICM maps with the whole stretch table (PS_ICM_FULL where the generated source says otherwise: variant 1 of a larger chain keeps the compact one)
+template <class Chain, class = void> struct PipeIcmFull { static constexpr bool value = PipeSmallChain<Chain>::value; };
+template <class Chain> struct PipeIcmFull<Chain, decltype((void)Chain::PS_ICM_FULL)> { static constexpr bool value = Chain::PS_ICM_FULL; };
 template <class Chain, class = void> struct PipeRowHalves { static constexpr bool value = PipeSmallChain<Chain>::value; };
 template <class Chain> struct PipeRowHalves<Chain, decltype((void)Chain::PS_ROW_HALVES)> { static constexpr bool value = Chain::PS_ROW_HALVES; };
 template <class Chain>
@@ -245,7 +248,7 @@ __device__ __attribute__((noinline)) void pipe_persist_unit(const PipeArgs& a, u
       else if constexpr (PipeRowRing<Chain>::value) { if (pipe_any(L.nb > 0)) pipe_row_ring<Chain, Chain::ROW_COMP[role]>(L, ro.ns); }
       else if (pipe_any(L.nb > 0)) pipe_row<Chain, Chain::ROW_COMP[role]>(L, ro.ns);
     } else if constexpr (kind == 3) {
-      if constexpr (PipeSmallChain<Chain>::value) {
+      if constexpr (PipeIcmFull<Chain>::value) {
         short* const st = (short*)(priv + 256u * G * 4u);          // the whole stretch table behind the side table
         if (c == 0) {
           for (int i = lane; i < 16384; i += 64) ((unsigned*)st)[i] = ((const unsigned*)a.tb->stretch)[i];

@@ -400,6 +400,10 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     // ... and so does variant 1 of a larger chain (workgroups of 8; -m5: 16 per group instead of 14, so up to 16 groups): call 34,
     // 320 / 384 / 512 blocks 167.1 / 201.5 / 254.8 -> 199.9 / 238.4 / 301.0 MB/s.  ZPAQ_AMD_LATENCY_RICH=0: without.
     static const bool latency_rich_off = [] { const char* v = getenv("ZPAQ_AMD_LATENCY_RICH"); return v && v[0] == '0'; }();
+    L.ps_icm_full = L.ps_small;
+    // (in workgroups of 8 an ICM map keeps the compact stretch table: with 64 KiB more per ICM map every one of the -m5 chain's 16
+    //  maps needs a workgroup of its own, 16 per group -- and two chains of 8 groups each, the archiver's batch, then need every
+    //  compute unit of the device at once: call 36, `add` 3.1 -> 4.3 s; without, 14 per group as before)
     if (!latency_rich_off && L.mode == 1 && !small_off) L.ps_small = true;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
@@ -448,7 +452,7 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     add(2, code_role, L.light_sub[r], k == K_CODER ? coder_unit : p_unit[i], lds, lds && k != K_CODER ? 0.9f : lc[k < 12 ? k : 0], lines, sl);
   }
   // (a small chain: the whole stretch table behind the ICM's side table, device PipeStretchFull)
-  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4 + (small ? 65536 : 0), 1.1f, 0.f, bh_l + p_l);
+  for (size_t r = 0; r < L.icm.size(); ++r) add(3, (int)r, 0, p_unit[L.icm[r]], 256 * G * 4 + (small && L.ps_icm_full ? 65536 : 0), 1.1f, 0.f, bh_l + p_l);
   // (packed pairs: pipe_isse_packed_unit; a small chain: two words per pair and the whole squash table, pipe_isse_unit)
   for (size_t r = 0; r < L.isse.size(); ++r) add(4, (int)r, 0, p_unit[L.isse[r]], small ? 512 * G * 4 + 8192 : 256 * G * 4 + 64 * G * 4, 1.5f, 0.f, bh_l + 2.f * p_l);
   // (a wavefront of the persistent launch is 64 lanes wide whatever the group size: a MIX unit's lane groups fill it --
@@ -925,6 +929,7 @@ bool generate_pipe_source(const zpq_plan& plan, const PipeOptions& opt, std::str
          "  static constexpr bool PS_ROW_RING = " << (L.ps_row_ring ? "true" : "false") << ";\n"
          "  static constexpr bool PS_CODER_FAST = " << (L.ps_coder_fast ? "true" : "false") << ", PS_SMALL = " << (L.ps_small ? "true" : "false") << ";\n"
       << (L.ps_small && !L.ps_row_halves ? "  static constexpr bool PS_ROW_HALVES = false;\n" : "")
+      << (L.ps_small && !L.ps_icm_full ? "  static constexpr bool PS_ICM_FULL = false;\n" : "")
       << "";
     o <<
          "  static constexpr int PS_WAVES = " << L.ps_waves << ", PS_WPG = " << L.ps_wpg << ", PS_NSLOT = " << L.ps_slots.size()

@@ -98,6 +98,7 @@ struct PipeLayout {
   bool ps_row_ring = false;    // lane-per-block ROW units with the table two bytes ahead (device pipe_row_ring)
   int ps_ahead = 0;            // a small chain's units read their streams ps_ahead + 1 bytes ahead
   bool ps_wide = false;        // variant 3: workgroups of 4 wavefronts whatever the chain's size
+  bool ps_icm_full = false;    // ICM maps with the whole stretch table behind their side table (not variant 1 of a larger chain)
   bool ps_row_halves = false;  // ROW units with a lane per nibble (the small chains proper; not variant 3 of a larger chain)
   bool ps_small = false;       // a chain of at most 16 unit wavefronts in the latency shape: one wavefront per SIMD, ISSE pairs unpacked
   int ps_mix_nh = 1;           // lane groups a MIX unit gives a block: 2 = bits 0 .. 3 and bits 4 .. 7 apart (half the chain per byte)
