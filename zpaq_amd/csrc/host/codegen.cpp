@@ -405,6 +405,10 @@ static void plan_persistent(const zpq_plan& plan, PipeLayout& L, int lds_rows_wi
     //  maps needs a workgroup of its own, 16 per group -- and two chains of 8 groups each, the archiver's batch, then need every
     //  compute unit of the device at once: call 36, `add` 3.1 -> 4.3 s; without, 14 per group as before)
     if (!latency_rich_off && L.mode == 1 && !small_off) L.ps_small = true;
+    // (ZPAQ_AMD_LATENCY_ICM_FULL=1: call 34's form -- whole stretch tables there too, 16 workgroups per group: 320 / 384 / 512 blocks
+    //  200 / 238 / 301 MB/s against this form's 168 / 199 / 248 (call 37), at the price named above)
+    static const bool latency_icm_full = [] { const char* v = getenv("ZPAQ_AMD_LATENCY_ICM_FULL"); return v && v[0] == '1'; }();
+    if (latency_icm_full && L.ps_small) L.ps_icm_full = true;
   }
   // (a small chain's units read their streams four bytes ahead: device pipe_icm_unit)
   static const int ahead = [] { const char* v = getenv("ZPAQ_AMD_STREAM_AHEAD"); return v ? (atoi(v) >= 3 ? 3 : (atoi(v) >= 1 ? 1 : 0)) : 3; }();        // (rings of 1, 2 or 4 slots: a chunk's length is a multiple)
